@@ -1,0 +1,214 @@
+/*
+ * fusionpic.h — C ABI of libfusionpic.so, the MI355X (gfx950) implementation of
+ * fusion-sim's per-step particle-in-cell hot path.
+ *
+ * The library replaces the object returned by the reference factory
+ *     empic.makeCylindricalParticlePusher(spec)          (empic.js:30-1529)
+ * for the calls that sit on the hot path.  Every entry point names the
+ * reference interface it stands in for (file:line under
+ * /root/reference/public/javascripts/).  The JavaScript host keeps the reference's
+ * method names through an N-API addon (fusion-sim_amd/js/); the binding a
+ * maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  No C++ exception crosses the ABI.
+ *   - Every call returns FPIC_OK (0) or a negative fpic_status.  The text of the
+ *     last failure on a handle is fpic_last_error(h); for a failed fpic_create it
+ *     is fpic_last_error(NULL).  The N-API layer turns a non-zero status into a
+ *     synchronous `throw new Error(msg)`, which is how the reference reports
+ *     spec and GL failures (utilities.js:118-127, :213-259).
+ *   - Host buffers are caller-owned and copied during the call; no host pointer
+ *     is kept.  Device buffers belong to the handle and die with fpic_destroy.
+ *   - A handle is not thread-safe (the reference runs on one JS thread).
+ *   - Calls enqueue on the handle's HIP stream and return; fpic_read_*,
+ *     fpic_get_particles and fpic_sync wait for the stream.
+ *   - There is NO CPU fallback: without a gfx950 device fpic_create fails with
+ *     FPIC_ERR_NO_DEVICE.
+ *
+ * Grid layout at the boundary (reference: empic.js:1162, texture index
+ * 4*(i + j*nr) + c with i = r index, j = z index): fpic_read_grid returns
+ * exactly that RGBA float layout.  fpic_set_grid takes the reference's nested
+ * JavaScript order value[i][j][k], flattened as ((i*nz + j)*ncomp + k).
+ */
+#ifndef FUSIONPIC_H
+#define FUSIONPIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPIC_ABI_VERSION 1
+
+typedef enum fpic_status {
+    FPIC_OK = 0,
+    FPIC_ERR_INVALID_ARG = -1, /* bad spec / argument; message keeps ".prop <- ..." form */
+    FPIC_ERR_NO_DEVICE = -2,   /* no gfx950 device visible: the product path has no CPU fallback */
+    FPIC_ERR_HIP = -3,         /* a HIP runtime call failed */
+    FPIC_ERR_OOM = -4,         /* device or host allocation failed */
+    FPIC_ERR_STATE = -5        /* call made in the wrong state (e.g. step before set) */
+} fpic_status;
+
+typedef enum fpic_dtype {
+    FPIC_F32 = 0,
+    FPIC_F64 = 1
+} fpic_dtype;
+
+/* Grids accepted by fpic_set_grid (reference: out.set, empic.js:1157-1350). */
+typedef enum fpic_grid_in {
+    FPIC_GRID_E = 0,          /* [nr][nz][3]  V/m   (empic.js:1159-1177) */
+    FPIC_GRID_B = 1,          /* [nr][nz][3]  T     (empic.js:1179-1197) */
+    FPIC_GRID_SINK_MASK = 2,  /* [nr][nz]     alive where > 0.5 (empic.js:1246-1260) */
+    FPIC_GRID_SOURCE_PDF = 3  /* [nr][nz]     un-normalised pdf -> 512x512 inverse CDF (empic.js:1263-1349) */
+} fpic_grid_in;
+
+/* Grids returned by fpic_read_grid, all RGBA, index 4*(i + j*W) + c. */
+typedef enum fpic_grid_out {
+    FPIC_READ_MOMENTS = 0, /* moments01      nr x nz  (empic.js:933, K4)  */
+    FPIC_READ_NORM = 1,    /* moments01_norm nr x nz  (empic.js:1040, K5) */
+    FPIC_READ_AVG = 2,     /* moments01_avgA nr x nz  (empic.js:1071, K6) */
+    FPIC_READ_R1 = 3,      /* nr x nz, w = 1 (empic.js:506-542) */
+    FPIC_READ_R2 = 4,      /* (empic.js:545-581) */
+    FPIC_READ_R3 = 5,      /* (empic.js:585-621) */
+    FPIC_READ_A = 6,       /* (empic.js:625-659) */
+    FPIC_READ_B = 7,       /* B frame buffer incl. painters' alpha (empic.js:197) */
+    FPIC_READ_E = 8,       /* (empic.js:186) */
+    FPIC_READ_SINK = 9,    /* red channel only is written (empic.js:1249) */
+    FPIC_READ_INV_CDF = 10 /* 512 x 512, .xy used (empic.js:228-241, :1328-1339) */
+} fpic_grid_out;
+
+/* Device buffers whose address can be handed to a collective (see fpic_device_buffer). */
+typedef enum fpic_buffer {
+    FPIC_BUF_CELL_SUMS = 0 /* per-cell sums 0.001*(vr,vtheta,vz,1), (nr+1)*(nz+1)*4 scalars */
+} fpic_buffer;
+
+/*
+ * Construction parameters.  The first eight fields are the reference's spec
+ * (empic.js:31-41, all 'number').  `nparticles` is the side of the reference's
+ * particle texture: the particle count is nparticles*nparticles (empic.js:107-109)
+ * unless `count` is non-zero (extension).
+ */
+typedef struct fpic_spec {
+    double radius;          /* m */
+    double height;          /* m */
+    int32_t nr;
+    int32_t nz;
+    double dt;              /* s, fixed for the life of the handle (empic.js:44, :852) */
+    int32_t nparticles;     /* texture side; count = nparticles^2 */
+    double particle_mass;   /* kg */
+    double particle_charge; /* C  */
+    /* ---- extensions (zero = reference behaviour) ---- */
+    uint64_t count;         /* exact particle count overriding nparticles^2 */
+    int32_t precision;      /* fpic_dtype of the device state; reference is F32 */
+    int32_t device;         /* HIP device ordinal */
+    int32_t physical_a;     /* 0: reference's K9 formula incl. quirk Q1 (empic.js:645);
+                               1: h(E.B)B vector form */
+    int32_t sort_interval;  /* re-bin particles every k density() calls; 0 = adaptive */
+    int32_t reserved[8];
+} fpic_spec;
+
+typedef struct fpic_handle fpic_handle;
+
+/* Counters and timings; all times are HIP-event milliseconds on the handle's stream
+ * and are gathered only while profiling is enabled (fpic_profile). */
+typedef struct fpic_stats {
+    uint64_t n_particles;
+    uint64_t particle_updates;   /* sub-steps x particles since create */
+    uint64_t step_launches;      /* push kernel launches */
+    uint64_t deposit_launches;
+    uint64_t sort_passes;
+    uint64_t deposit_spilled;    /* particles of the last deposit that missed their LDS tile */
+    double ms_push;              /* sum over push launches */
+    double ms_deposit;           /* sum over cell-sum (scatter) launches */
+    double ms_stamp;             /* sum over stamp-convolution + normalise + EMA launches */
+    double ms_precalc;
+    double ms_sort;
+    uint64_t bytes_particle_state; /* device bytes held for particle state */
+    uint64_t bytes_grid_state;
+    double reserved[8];
+} fpic_stats;
+
+/* Last error text.  h may be NULL after a failed fpic_create. */
+const char* fpic_last_error(const fpic_handle* h);
+
+/* Library/ABI version, and the code-object architecture it was built for ("gfx950"). */
+int fpic_abi_version(void);
+const char* fpic_build_arch(void);
+
+/* empic.makeCylindricalParticlePusher(spec): validation (empic.js:31-41,
+ * utilities.js:118-127), derived constants h, factor_r, factor_z (empic.js:44-46),
+ * all state buffers (empic.js:123-241, :499-502, :666-672, :933-1072), the 11x11
+ * stamp (empic.js:949-971). */
+int fpic_create(const fpic_spec* spec, fpic_handle** out);
+int fpic_destroy(fpic_handle* h);
+
+/* out.set({position, velocity}) (empic.js:1199-1244).  pos/vel are AoS [n][3] in
+ * metres / units of c, dtype F32 or F64; either may be NULL.  n must equal the
+ * handle's particle count.  Normalisation by factor_r, factor_r, factor_z is done
+ * in double and rounded once, as the reference's Float32Array store does. */
+int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype);
+
+/* out.set({E, B, sink_mask, source_pdf}) (empic.js:1159-1197, :1246-1349).
+ * data is value[i][j][k] flattened, i over nr, j over nz, k over ncomp (3 or 1). */
+int fpic_set_grid(fpic_handle* h, int which, const void* data, int nr, int nz, int ncomp, int dtype);
+
+/* Reproducible replacement for window.crypto / Math.random (empic.js:142-180, quirk
+ * Q8): entropy is 1024*1024*4 floats (index 4*(i + 1024*j)), rand is n*4 floats
+ * (u1,u2,c1,c2).  Either may be NULL to keep the current one. */
+int fpic_set_random_state(fpic_handle* h, const float* entropy, const float* rand);
+
+/* Static field painters, additive into B (empic.js:1352-1363, :1380-1411). */
+int fpic_add_current_loop(fpic_handle* h, double r, double z, double current);
+int fpic_add_current_z(fpic_handle* h, double current);
+int fpic_add_bz(fpic_handle* h, double bz);
+int fpic_add_btheta(fpic_handle* h, double btheta);
+
+/* out.precalc() (empic.js:1413-1434): B,E -> R1,R2,R3,A. */
+int fpic_precalc(fpic_handle* h);
+
+/* out.step() (empic.js:1436-1469) ncalls times; each call is two leap-frog
+ * sub-steps (RandB,VelB,PosB,RandA,VelA,PosA). */
+int fpic_step(fpic_handle* h, int ncalls);
+
+/* out.density() (empic.js:1471-1495): scatter (K4), normalise (K5), EMA (K6),
+ * avgB <- avgA (K7).  fpic_density == fpic_deposit then fpic_density_finish; the
+ * split exists so that a multi-GPU host can sum FPIC_BUF_CELL_SUMS across ranks
+ * in between. */
+int fpic_density(fpic_handle* h);
+int fpic_deposit(fpic_handle* h);
+int fpic_density_finish(fpic_handle* h);
+
+/* fb.readPixels (utilities.js:701-711) for the grids above.  out holds
+ * 4*W*H floats (dtype F32) or doubles (F64). */
+int fpic_read_grid(fpic_handle* h, int which, void* out, int dtype);
+
+/* Particle read-back in the caller's original order (normalised units as stored:
+ * x/R, y/R, z/H and v/c scaled the same way).  pos_aos/vel_aos are [n][3] of
+ * dtype, rand is [n][4] float, alive is [n] bytes; any may be NULL. */
+int fpic_get_particles(fpic_handle* h, void* pos_aos, void* vel_aos, float* rand, uint8_t* alive, int dtype);
+
+/* NGP cell index i + j*nr of every particle as the push sees it (integer parity
+ * check; same order as fpic_get_particles). */
+int fpic_get_cells(fpic_handle* h, int32_t* cells);
+
+/* Multi-GPU plumbing: the raw device address/byte size of a buffer (for an RCCL
+ * collective issued by the host), and the HIP stream the handle enqueues on.
+ * fpic_set_stream(h, NULL) restores the handle's own stream. */
+int fpic_device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
+int fpic_set_stream(fpic_handle* h, void* hip_stream);
+int fpic_get_stream(fpic_handle* h, void** hip_stream);
+
+/* Force a re-bin of the particle arrays by cell tile now (normally automatic). */
+int fpic_sort(fpic_handle* h);
+
+int fpic_sync(fpic_handle* h);
+int fpic_profile(fpic_handle* h, int enable);
+int fpic_get_stats(fpic_handle* h, fpic_stats* out);
+int fpic_reset_stats(fpic_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUSIONPIC_H */
