@@ -1,0 +1,925 @@
+// fpic_api.hip — the C ABI of libfusionpic.so (include/fusionpic.h) on top of the
+// gfx950 kernels in fpic_kernels.hpp.  One handle = one reference pusher object
+// (empic.js:30-1529) on one GPU; all work is enqueued on the handle's HIP stream.
+//
+// There is no CPU fallback in this file or anywhere in the library: a handle
+// cannot be created without a gfx950 device.
+#include "fpic_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace fpic;
+
+namespace {
+
+enum KernelClass { KC_PUSH = 0, KC_DEPOSIT, KC_STAMP, KC_PRECALC, KC_SORT, KC_COUNT };
+
+struct PendingTiming {
+    hipEvent_t a, b;
+    int cls;
+};
+
+thread_local std::string g_create_error;
+
+} // namespace
+
+struct fpic_handle {
+    fpic_spec spec{};
+    Constants k{};
+    int prec = FPIC_F32;
+    int device = 0;
+    size_t n = 0, n_pad = 0;
+    int nr = 0, nz = 0;
+    size_t ncell = 0;
+    size_t esize = 4;
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // particle state, two sets (binning is out of place), cur selects the live one
+    void* part[2][10] = {};
+    uint8_t* alive[2] = {};
+    uint32_t* id[2] = {};
+    int cur = 0;
+
+    // grid state
+    void* E = nullptr;
+    void* B = nullptr;
+    void* sink = nullptr;
+    uint8_t* sink_alive = nullptr;
+    void* inv_cdf_xy = nullptr;
+    void* entropy = nullptr;
+    void* coef = nullptr;
+    void* cell_sums = nullptr;
+    void* moments = nullptr;
+    void* norm = nullptr;
+    void* avg = nullptr;
+    float* stamp = nullptr;
+    void* shape_half = nullptr;
+    void* shape_tenth = nullptr;
+    bool shapes_ready = false;
+
+    // binning by cell tile
+    int ntx = 0, ntz = 0;
+    uint32_t ntiles = 0; // real tiles + 1 bin for clipped particles
+    uint32_t* tile_count = nullptr;
+    uint32_t* tile_start = nullptr;
+    uint32_t* tile_cursor = nullptr;
+    uint32_t* nwork = nullptr;
+    BlockWork* work = nullptr;
+    size_t work_cap = 0;
+    bool binned = false;
+    int deposits_since_bin = 0;
+    unsigned long long* spilled = nullptr;      // device counter
+    unsigned long long* spilled_host = nullptr; // pinned
+    hipEvent_t spill_event = nullptr;
+    bool spill_pending = false;
+    unsigned long long last_spill = 0;
+
+    // statistics
+    bool profiling = false;
+    std::vector<PendingTiming> pending;
+    std::vector<hipEvent_t> event_pool;
+    double ms[KC_COUNT] = {};
+    uint64_t particle_updates = 0, step_launches = 0, deposit_launches = 0, sort_passes = 0;
+    uint64_t bytes_particles = 0, bytes_grid = 0;
+};
+
+namespace {
+
+int fail(fpic_handle* h, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                                      \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(h, e_ == hipErrorOutOfMemory ? FPIC_ERR_OOM : FPIC_ERR_HIP, "%s failed: %s", #expr,   \
+                        hipGetErrorString(e_));                                                               \
+    } while (0)
+
+#define CHECK_HANDLE(h)                                                                                       \
+    do {                                                                                                      \
+        if (!(h)) return fail(nullptr, FPIC_ERR_INVALID_ARG, "null handle");                                  \
+        hipError_t e_ = hipSetDevice((h)->device);                                                            \
+        if (e_ != hipSuccess) return fail(h, FPIC_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+inline unsigned blocks_for(size_t n, unsigned per = 256) { return static_cast<unsigned>((n + per - 1) / per); }
+
+template <typename T>
+ParticleArrays<T> arrays(fpic_handle* h, int which)
+{
+    ParticleArrays<T> p;
+    void** a = h->part[which];
+    p.x = static_cast<T*>(a[0]); p.y = static_cast<T*>(a[1]); p.z = static_cast<T*>(a[2]);
+    p.vx = static_cast<T*>(a[3]); p.vy = static_cast<T*>(a[4]); p.vz = static_cast<T*>(a[5]);
+    p.u1 = static_cast<T*>(a[6]); p.u2 = static_cast<T*>(a[7]); p.c1 = static_cast<T*>(a[8]); p.c2 = static_cast<T*>(a[9]);
+    p.alive = h->alive[which];
+    p.id = h->id[which];
+    return p;
+}
+
+int dev_alloc(fpic_handle* h, void** p, size_t bytes, uint64_t* account)
+{
+    HIP_TRY(h, hipMalloc(p, bytes ? bytes : 16));
+    HIP_TRY(h, hipMemsetAsync(*p, 0, bytes ? bytes : 16, h->stream));
+    if (account) *account += bytes;
+    return FPIC_OK;
+}
+
+void timing_begin(fpic_handle* h, int cls)
+{
+    if (!h->profiling) return;
+    PendingTiming t;
+    t.cls = cls;
+    for (hipEvent_t* e : { &t.a, &t.b }) {
+        if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); }
+        else (void)hipEventCreate(e);
+    }
+    (void)hipEventRecord(t.a, h->stream);
+    h->pending.push_back(t);
+}
+
+void timing_collect(fpic_handle* h)
+{
+    if (h->pending.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (PendingTiming& t : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) h->ms[t.cls] += ms;
+        h->event_pool.push_back(t.a);
+        h->event_pool.push_back(t.b);
+    }
+    h->pending.clear();
+}
+
+void timing_end(fpic_handle* h)
+{
+    if (!h->profiling) return;
+    (void)hipEventRecord(h->pending.back().b, h->stream);
+    if (h->pending.size() > 2048) timing_collect(h);
+}
+
+// default random state when the host never injects one: the reference seeds from
+// window.crypto / Math.random (empic.js:148-173, quirk Q8)
+__global__ __launch_bounds__(256) void default_random_kernel(float* out, size_t n, unsigned long long seed)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[i] = static_cast<float>(z >> 40) * (1.0f / 16777216.0f);
+}
+
+template <typename T>
+int upload_entropy(fpic_handle* h, const float* dev_f32)
+{
+    const size_t n = static_cast<size_t>(4) * kEntropySide * kEntropySide;
+    convert_kernel<T, float><<<blocks_for(n), 256, 0, h->stream>>>(dev_f32, static_cast<T*>(h->entropy), n);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int upload_rand_chunked(fpic_handle* h, const float* host_rand, const float* dev_all)
+{
+    // host_rand: [n][4] on the host, staged in chunks; dev_all: [n][4] already on the device
+    const size_t chunk = 16u << 20;
+    if (dev_all) {
+        set_rand_kernel<T><<<blocks_for(h->n), 256, 0, h->stream>>>(dev_all, 0, h->n, arrays<T>(h, h->cur), h->n);
+        HIP_TRY(h, hipGetLastError());
+        return FPIC_OK;
+    }
+    float* stage = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, h->n) * 4 * sizeof(float)));
+    for (size_t b = 0; b < h->n; b += chunk) {
+        const size_t m = std::min(chunk, h->n - b);
+        hipError_t e = hipMemcpyAsync(stage, host_rand + 4 * b, m * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            set_rand_kernel<T><<<blocks_for(h->n), 256, 0, h->stream>>>(stage, b, m, arrays<T>(h, h->cur), h->n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { (void)hipFree(stage); return fail(h, FPIC_ERR_HIP, "random-state upload failed: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(h, hipFree(stage));
+    return FPIC_OK;
+}
+
+template <typename T, typename In>
+int upload_vec3(fpic_handle* h, const In* host, int first_array, double fxy, double fz, bool set_alive)
+{
+    const size_t chunk = 8u << 20;
+    In* stage = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, h->n) * 3 * sizeof(In)));
+    void** a = h->part[h->cur];
+    for (size_t b = 0; b < h->n; b += chunk) {
+        const size_t m = std::min(chunk, h->n - b);
+        hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            set_vec3_kernel<T, In><<<blocks_for(h->n), 256, 0, h->stream>>>(
+                stage, b, m, fxy, fz, static_cast<T*>(a[first_array]), static_cast<T*>(a[first_array + 1]),
+                static_cast<T*>(a[first_array + 2]), set_alive ? h->alive[h->cur] : nullptr, h->id[h->cur], h->n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { (void)hipFree(stage); return fail(h, FPIC_ERR_HIP, "particle upload failed: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(h, hipFree(stage));
+    return FPIC_OK;
+}
+
+template <typename T, typename Out>
+int download_vec3(fpic_handle* h, Out* host, int first_array)
+{
+    const size_t chunk = 8u << 20;
+    Out* stage = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, h->n) * 3 * sizeof(Out)));
+    void** a = h->part[h->cur];
+    for (size_t b = 0; b < h->n; b += chunk) {
+        const size_t m = std::min(chunk, h->n - b);
+        get_vec3_kernel<T, Out><<<blocks_for(h->n), 256, 0, h->stream>>>(
+            static_cast<const T*>(a[first_array]), static_cast<const T*>(a[first_array + 1]),
+            static_cast<const T*>(a[first_array + 2]), h->id[h->cur], h->n, b, m, stage);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(host + 3 * b, stage, m * 3 * sizeof(Out), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { (void)hipFree(stage); return fail(h, FPIC_ERR_HIP, "particle read-back failed: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(h, hipFree(stage));
+    return FPIC_OK;
+}
+
+template <typename T>
+int download_misc(fpic_handle* h, float* rand, uint8_t* alive, int32_t* cells)
+{
+    const size_t chunk = 16u << 20;
+    const size_t m0 = std::min(chunk, h->n);
+    float* srand = nullptr;
+    uint8_t* salive = nullptr;
+    int32_t* scells = nullptr;
+    if (rand) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&srand), m0 * 4 * sizeof(float)));
+    if (alive) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&salive), m0));
+    if (cells) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&scells), m0 * sizeof(int32_t)));
+    int rc = FPIC_OK;
+    for (size_t b = 0; b < h->n && rc == FPIC_OK; b += chunk) {
+        const size_t m = std::min(chunk, h->n - b);
+        get_rand_kernel<T><<<blocks_for(h->n), 256, 0, h->stream>>>(arrays<T>(h, h->cur), h->n, b, m, srand, salive, scells,
+                                                                  h->nr, h->nz);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && rand) e = hipMemcpyAsync(rand + 4 * b, srand, m * 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && alive) e = hipMemcpyAsync(alive + b, salive, m, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && cells) e = hipMemcpyAsync(cells + b, scells, m * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, FPIC_ERR_HIP, "particle read-back failed: %s", hipGetErrorString(e));
+    }
+    if (srand) (void)hipFree(srand);
+    if (salive) (void)hipFree(salive);
+    if (scells) (void)hipFree(scells);
+    return rc;
+}
+
+template <typename T>
+int launch_precalc(fpic_handle* h)
+{
+    T h_, fr, fz, f_rz, f_zr;
+    if (sizeof(T) == 4) {
+        // u_h goes through uniform1f; the factors are decimal literals in the shader text
+        h_ = static_cast<T>(h->k.h);
+        fr = static_cast<T>(shader_literal(h->k.factor_r));
+        fz = static_cast<T>(shader_literal(h->k.factor_z));
+        f_rz = static_cast<T>(shader_literal(h->k.f_rz));
+        f_zr = static_cast<T>(shader_literal(h->k.f_zr));
+    } else {
+        h_ = static_cast<T>(h->k.h); fr = static_cast<T>(h->k.factor_r); fz = static_cast<T>(h->k.factor_z);
+        f_rz = static_cast<T>(h->k.f_rz); f_zr = static_cast<T>(h->k.f_zr);
+    }
+    timing_begin(h, KC_PRECALC);
+    precalc_kernel<T><<<blocks_for(h->ncell), 256, 0, h->stream>>>(static_cast<const T*>(h->B), static_cast<const T*>(h->E),
+                                                                 h->ncell, h_, fr, fz, f_rz, f_zr, h->spec.physical_a,
+                                                                 static_cast<T*>(h->coef));
+    timing_end(h);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int launch_push(fpic_handle* h, int nsub)
+{
+    PushArgs<T> a;
+    a.p = arrays<T>(h, h->cur);
+    a.coef = static_cast<const T*>(h->coef);
+    a.sink_alive = h->sink_alive;
+    a.inv_cdf_xy = static_cast<const T*>(h->inv_cdf_xy);
+    a.entropy = static_cast<const T*>(h->entropy);
+    a.nr = h->nr; a.nz = h->nz;
+    a.step_factor = static_cast<T>(h->k.step_factor); // uniform1f(u_step_factor) (empic.js:852)
+    a.n = h->n;
+    a.nsub = nsub;
+    const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
+    timing_begin(h, KC_PUSH);
+    push_kernel<T><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+    timing_end(h);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int launch_bin(fpic_handle* h)
+{
+    const size_t shmem = static_cast<size_t>(h->ntiles) * sizeof(uint32_t);
+    const unsigned nb = blocks_for(h->n, 256 * kBinPer);
+    ParticleArrays<T> src = arrays<T>(h, h->cur), dst = arrays<T>(h, h->cur ^ 1);
+    timing_begin(h, KC_SORT);
+    HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
+    bin_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_count);
+    bin_scan_kernel<<<1, 1024, 0, h->stream>>>(h->tile_count, h->ntiles, h->tile_start, h->tile_cursor, h->work, h->nwork);
+    bin_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_start,
+                                                       h->tile_cursor);
+    timing_end(h);
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;
+    h->binned = true;
+    h->deposits_since_bin = 0;
+    h->last_spill = 0;
+    h->spill_pending = false;
+    h->sort_passes++;
+    return FPIC_OK;
+}
+
+template <typename T>
+int launch_cell_sums(fpic_handle* h)
+{
+    const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
+    timing_begin(h, KC_DEPOSIT);
+    HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color [0,0,0,0] (empic.js:1476)
+    HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
+    cell_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), 256, 0, h->stream>>>(
+        arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work, h->nwork, static_cast<T*>(h->cell_sums), h->spilled);
+    timing_end(h);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->spilled_host, h->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->spill_event, h->stream));
+    h->spill_pending = true;
+    return FPIC_OK;
+}
+
+template <typename T>
+int launch_stamp_finish(fpic_handle* h)
+{
+    dim3 grid((h->nr + 31) / 32, (h->nz + 31) / 32);
+    timing_begin(h, KC_STAMP);
+    stamp_finish_kernel<T><<<grid, 256, 0, h->stream>>>(static_cast<const T*>(h->cell_sums), h->nr, h->nz, h->stamp,
+                                                     static_cast<T*>(h->moments), static_cast<T*>(h->norm),
+                                                     static_cast<T*>(h->avg), static_cast<T>(0.01)); // u_ratio (empic.js:1083)
+    timing_end(h);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T, typename In>
+int set_grid_t(fpic_handle* h, int which, const In* host, int ncomp)
+{
+    In* stage = nullptr;
+    const size_t bytes = h->ncell * ncomp * sizeof(In);
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), bytes));
+    hipError_t e = hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        T* dst = static_cast<T*>(which == FPIC_GRID_E ? h->E : (which == FPIC_GRID_B ? h->B : h->sink));
+        pack_grid_kernel<T, In><<<blocks_for(h->ncell), 256, 0, h->stream>>>(stage, h->nr, h->nz, ncomp, dst,
+                                                                           which == FPIC_GRID_SINK_MASK ? h->sink_alive : nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) return fail(h, FPIC_ERR_HIP, "grid upload failed: %s", hipGetErrorString(e));
+    return FPIC_OK;
+}
+
+template <typename T, typename Out>
+int read_grid_t(fpic_handle* h, int which, Out* host)
+{
+    size_t cells = h->ncell;
+    if (which == FPIC_READ_INV_CDF) cells = static_cast<size_t>(kCdfSide) * kCdfSide;
+    Out* stage = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), cells * 4 * sizeof(Out)));
+    const unsigned nb = blocks_for(cells), nb4 = blocks_for(cells * 4);
+    switch (which) {
+    case FPIC_READ_MOMENTS: convert_kernel<Out, T><<<nb4, 256, 0, h->stream>>>(static_cast<const T*>(h->moments), stage, cells * 4); break;
+    case FPIC_READ_NORM: convert_kernel<Out, T><<<nb4, 256, 0, h->stream>>>(static_cast<const T*>(h->norm), stage, cells * 4); break;
+    case FPIC_READ_AVG: convert_kernel<Out, T><<<nb4, 256, 0, h->stream>>>(static_cast<const T*>(h->avg), stage, cells * 4); break;
+    case FPIC_READ_B: convert_kernel<Out, T><<<nb4, 256, 0, h->stream>>>(static_cast<const T*>(h->B), stage, cells * 4); break;
+    case FPIC_READ_E: convert_kernel<Out, T><<<nb4, 256, 0, h->stream>>>(static_cast<const T*>(h->E), stage, cells * 4); break;
+    case FPIC_READ_SINK: convert_kernel<Out, T><<<nb4, 256, 0, h->stream>>>(static_cast<const T*>(h->sink), stage, cells * 4); break;
+    case FPIC_READ_R1: case FPIC_READ_R2: case FPIC_READ_R3: case FPIC_READ_A:
+        unpack_coef_kernel<T, Out><<<nb, 256, 0, h->stream>>>(static_cast<const T*>(h->coef), cells, which - FPIC_READ_R1, stage);
+        break;
+    case FPIC_READ_INV_CDF: unpack_xy_kernel<T, Out><<<nb, 256, 0, h->stream>>>(static_cast<const T*>(h->inv_cdf_xy), cells, stage); break;
+    default: (void)hipFree(stage); return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown grid %d", which);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host, stage, cells * 4 * sizeof(Out), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) return fail(h, FPIC_ERR_HIP, "grid read-back failed: %s", hipGetErrorString(e));
+    return FPIC_OK;
+}
+
+template <typename T>
+int paint_uniform(fpic_handle* h, int kind, double value)
+{
+    add_uniform_kernel<T><<<blocks_for(h->ncell), 256, 0, h->stream>>>(static_cast<T*>(h->B), h->nr, h->nz, kind,
+                                                                     static_cast<T>(value));
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int paint_loop(fpic_handle* h, double r, double z, double current)
+{
+    if (!h->shapes_ready) { // the reference draws both shapes inside the factory (empic.js:333-345)
+        loop_shape_kernel<T><<<blocks_for(h->ncell), 256, 0, h->stream>>>(static_cast<T>(0.5), h->nr, h->nz, static_cast<T*>(h->shape_half));
+        loop_shape_kernel<T><<<blocks_for(h->ncell), 256, 0, h->stream>>>(static_cast<T>(0.1), h->nr, h->nz, static_cast<T*>(h->shape_tenth));
+        HIP_TRY(h, hipGetLastError());
+        h->shapes_ready = true;
+    }
+    current_loop_kernel<T><<<blocks_for(h->ncell), 256, 0, h->stream>>>(
+        static_cast<T*>(h->B), static_cast<const T*>(h->shape_half), static_cast<const T*>(h->shape_tenth), h->nr, h->nz,
+        static_cast<T>(r * h->k.factor_r), static_cast<T>(z * h->k.factor_z), static_cast<T>(current));
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int create_state(fpic_handle* h)
+{
+    for (int s = 0; s < 2; ++s) {
+        for (int a = 0; a < 10; ++a)
+            if (int rc = dev_alloc(h, &h->part[s][a], h->n_pad * sizeof(T), &h->bytes_particles)) return rc;
+        if (int rc = dev_alloc(h, reinterpret_cast<void**>(&h->alive[s]), h->n_pad, &h->bytes_particles)) return rc;
+        if (int rc = dev_alloc(h, reinterpret_cast<void**>(&h->id[s]), h->n_pad * sizeof(uint32_t), &h->bytes_particles)) return rc;
+    }
+    const size_t rgba = h->ncell * 4 * sizeof(T);
+    const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
+    struct { void** p; size_t bytes; } grids[] = {
+        { &h->E, rgba }, { &h->B, rgba }, { &h->sink, rgba }, { &h->moments, rgba }, { &h->norm, rgba }, { &h->avg, rgba },
+        { &h->shape_half, rgba }, { &h->shape_tenth, rgba },
+        { &h->coef, h->ncell * 12 * sizeof(T) },
+        { &h->cell_sums, gcells * 4 * sizeof(T) },
+        { &h->inv_cdf_xy, static_cast<size_t>(kCdfSide) * kCdfSide * 2 * sizeof(T) },
+        { &h->entropy, static_cast<size_t>(kEntropySide) * kEntropySide * 4 * sizeof(T) },
+    };
+    for (auto& g : grids)
+        if (int rc = dev_alloc(h, g.p, g.bytes, &h->bytes_grid)) return rc;
+    if (int rc = dev_alloc(h, reinterpret_cast<void**>(&h->sink_alive), h->ncell, &h->bytes_grid)) return rc;
+    if (int rc = dev_alloc(h, reinterpret_cast<void**>(&h->stamp), kStampCells * sizeof(float), &h->bytes_grid)) return rc;
+
+    float w[kStampCells];
+    build_stamp(w);
+    HIP_TRY(h, hipMemcpyAsync(h->stamp, w, sizeof w, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+
+    for (int s = 0; s < 2; ++s) {
+        init_particles_kernel<T><<<blocks_for(h->n_pad), 256, 0, h->stream>>>(arrays<T>(h, s), h->n_pad);
+        HIP_TRY(h, hipGetLastError());
+    }
+    // default entropy table and per-particle random state
+    float* tmp = nullptr;
+    const size_t ne = static_cast<size_t>(4) * kEntropySide * kEntropySide;
+    const size_t chunk = 16u << 20;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&tmp), std::max(ne, std::min(chunk, h->n) * 4) * sizeof(float)));
+    const unsigned long long seed = 0x5EEDF051ull ^ (reinterpret_cast<uintptr_t>(h) * 0x9E3779B97F4A7C15ull);
+    default_random_kernel<<<blocks_for(ne), 256, 0, h->stream>>>(tmp, ne, seed);
+    int rc = upload_entropy<T>(h, tmp);
+    for (size_t b = 0; b < h->n && rc == FPIC_OK; b += chunk) {
+        const size_t m = std::min(chunk, h->n - b);
+        default_random_kernel<<<blocks_for(m * 4), 256, 0, h->stream>>>(tmp, m * 4, seed + 0x1234567ull * (b + 1));
+        set_rand_kernel<T><<<blocks_for(h->n), 256, 0, h->stream>>>(tmp, b, m, arrays<T>(h, h->cur), h->n);
+        if (hipGetLastError() != hipSuccess) rc = fail(h, FPIC_ERR_HIP, "default random state failed");
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(h, FPIC_ERR_HIP, "state initialisation failed: %s", hipGetErrorString(e));
+    return FPIC_OK;
+}
+
+void release(fpic_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (int s = 0; s < 2; ++s) {
+        for (int a = 0; a < 10; ++a) if (h->part[s][a]) (void)hipFree(h->part[s][a]);
+        if (h->alive[s]) (void)hipFree(h->alive[s]);
+        if (h->id[s]) (void)hipFree(h->id[s]);
+    }
+    void* bufs[] = { h->E, h->B, h->sink, h->sink_alive, h->inv_cdf_xy, h->entropy, h->coef, h->cell_sums, h->moments,
+                     h->norm, h->avg, h->stamp, h->shape_half, h->shape_tenth, h->tile_count, h->tile_start,
+                     h->tile_cursor, h->nwork, h->work, h->spilled };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->spilled_host) (void)hipHostFree(h->spilled_host);
+    if (h->spill_event) (void)hipEventDestroy(h->spill_event);
+    for (PendingTiming& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+// The reference validates with typeof === 'number' (utilities.js:118-127); over a C
+// struct the equivalent failure is a non-finite or out-of-domain value.
+int validate_spec(const fpic_spec* s)
+{
+    struct { const char* name; double v; bool positive; } fields[] = {
+        { "radius", s->radius, true }, { "height", s->height, true }, { "dt", s->dt, false },
+        { "particle_mass", s->particle_mass, true }, { "particle_charge", s->particle_charge, false },
+    };
+    for (auto& f : fields) {
+        if (!std::isfinite(f.v)) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".%s <- Property does not match any given possible types!", f.name);
+        if (f.positive && !(f.v > 0)) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".%s <- must be positive", f.name);
+    }
+    if (s->nr < 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".nr <- must be a positive integer");
+    if (s->nz < 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".nz <- must be a positive integer");
+    if (s->count == 0 && s->nparticles < 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".nparticles <- must be a positive integer");
+    if (s->precision != FPIC_F32 && s->precision != FPIC_F64) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".precision <- must be 0 (f32) or 1 (f64)");
+    return FPIC_OK;
+}
+
+} // namespace
+
+// =============================================================================== ABI
+
+extern "C" {
+
+const char* fpic_last_error(const fpic_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+int fpic_abi_version(void) { return FPIC_ABI_VERSION; }
+const char* fpic_build_arch(void) { return "gfx950"; }
+
+int fpic_create(const fpic_spec* spec, fpic_handle** out)
+{
+    if (!out) return fail(nullptr, FPIC_ERR_INVALID_ARG, "null output pointer");
+    *out = nullptr;
+    if (!spec) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".spec <- Non-optional property is undefined!");
+    if (int rc = validate_spec(spec)) return rc;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, FPIC_ERR_NO_DEVICE, "no HIP device visible (%s): libfusionpic has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (spec->device < 0 || spec->device >= ndev) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".device <- ordinal %d out of range [0,%d)", spec->device, ndev);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, spec->device)) != hipSuccess)
+        return fail(nullptr, FPIC_ERR_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, FPIC_ERR_NO_DEVICE, "device %d is %s; libfusionpic carries gfx950 code objects only", spec->device, prop.gcnArchName);
+
+    fpic_handle* h = new (std::nothrow) fpic_handle();
+    if (!h) return fail(nullptr, FPIC_ERR_OOM, "host allocation failed");
+    h->spec = *spec;
+    h->k = derive_constants(*spec);
+    h->prec = spec->precision;
+    h->esize = spec->precision == FPIC_F64 ? 8 : 4;
+    h->device = spec->device;
+    h->nr = spec->nr;
+    h->nz = spec->nz;
+    h->ncell = static_cast<size_t>(spec->nr) * spec->nz;
+    h->n = spec->count ? static_cast<size_t>(spec->count) : static_cast<size_t>(spec->nparticles) * spec->nparticles; // empic.js:107-109
+    h->n_pad = (h->n + 1023) / 1024 * 1024;
+    h->ntx = (h->nr + 1 + kTileSide - 1) / kTileSide;
+    h->ntz = (h->nz + 1 + kTileSide - 1) / kTileSide;
+    h->ntiles = static_cast<uint32_t>(h->ntx) * h->ntz + 1;
+    int rc = FPIC_OK;
+    if (h->n >= 0xFFFFFFFFull - 4096) rc = fail(nullptr, FPIC_ERR_INVALID_ARG, ".nparticles <- at most 2^32 particles per device");
+    else if (h->ntiles > static_cast<uint32_t>(kMaxTiles)) rc = fail(nullptr, FPIC_ERR_INVALID_ARG, ".nr <- grid of %d x %d cells exceeds %d tiles of %d^2 cells", h->nr, h->nz, kMaxTiles, kTileSide);
+    if (rc) { delete h; return rc; }
+
+    auto bail = [&](int code) { g_create_error = h->err; release(h); return code; };
+    if (hipSetDevice(h->device) != hipSuccess) return bail(fail(h, FPIC_ERR_HIP, "hipSetDevice failed"));
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(fail(h, FPIC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)));
+    h->stream = h->own_stream;
+
+    rc = (h->prec == FPIC_F32) ? create_state<float>(h) : create_state<double>(h);
+    if (rc) return bail(rc);
+
+    h->work_cap = (h->n + kDepositChunk - 1) / kDepositChunk + h->ntiles;
+    uint64_t* acc = &h->bytes_grid;
+    if ((rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_count), sizeof(uint32_t) * h->ntiles, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_start), sizeof(uint32_t) * (h->ntiles + 1), acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_cursor), sizeof(uint32_t) * h->ntiles, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->nwork), sizeof(uint32_t), acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work), sizeof(BlockWork) * h->work_cap, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->spilled), sizeof(unsigned long long), acc)))
+        return bail(rc);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->spilled_host), sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->spill_event, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipStreamSynchronize(h->stream)) != hipSuccess)
+        return bail(fail(h, FPIC_ERR_HIP, "handle setup failed: %s", hipGetErrorString(e)));
+    *h->spilled_host = 0;
+    *out = h;
+    return FPIC_OK;
+}
+
+int fpic_destroy(fpic_handle* h)
+{
+    if (!h) return FPIC_OK;
+    release(h);
+    return FPIC_OK;
+}
+
+int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype)
+{
+    CHECK_HANDLE(h);
+    if (n != h->n) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- expected %zu particles, got %llu", h->n, static_cast<unsigned long long>(n));
+    if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
+    const double fr = h->k.factor_r, fz = h->k.factor_z;
+    int rc = FPIC_OK;
+    for (int pass = 0; pass < 2 && rc == FPIC_OK; ++pass) {
+        const void* src = pass == 0 ? pos_aos : vel_aos;
+        if (!src) continue;
+        const int first = pass == 0 ? 0 : 3;
+        const bool al = pass == 0;
+        if (h->prec == FPIC_F32)
+            rc = dtype == FPIC_F32 ? upload_vec3<float, float>(h, static_cast<const float*>(src), first, fr, fz, al)
+                                   : upload_vec3<float, double>(h, static_cast<const double*>(src), first, fr, fz, al);
+        else
+            rc = dtype == FPIC_F32 ? upload_vec3<double, float>(h, static_cast<const float*>(src), first, fr, fz, al)
+                                   : upload_vec3<double, double>(h, static_cast<const double*>(src), first, fr, fz, al);
+    }
+    if (pos_aos) h->binned = false; // positions changed under the bins
+    return rc;
+}
+
+int fpic_set_grid(fpic_handle* h, int which, const void* data, int nr, int nz, int ncomp, int dtype)
+{
+    CHECK_HANDLE(h);
+    if (!data) return fail(h, FPIC_ERR_INVALID_ARG, ".data <- Non-optional property is undefined!");
+    if (nr != h->nr || nz != h->nz) return fail(h, FPIC_ERR_INVALID_ARG, ".grid <- expected %d x %d, got %d x %d", h->nr, h->nz, nr, nz);
+    if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
+    const bool vec = which == FPIC_GRID_E || which == FPIC_GRID_B;
+    if (which < FPIC_GRID_E || which > FPIC_GRID_SOURCE_PDF) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown grid %d", which);
+    if (ncomp != (vec ? 3 : 1)) return fail(h, FPIC_ERR_INVALID_ARG, ".ncomp <- expected %d", vec ? 3 : 1);
+
+    if (which == FPIC_GRID_SOURCE_PDF) {
+        std::vector<double> pdf(h->ncell);
+        for (size_t c = 0; c < h->ncell; ++c)
+            pdf[c] = dtype == FPIC_F32 ? static_cast<const float*>(data)[c] : static_cast<const double*>(data)[c];
+        std::vector<float> xy;
+        if (!build_inverse_cdf(pdf.data(), h->nr, h->nz, xy))
+            return fail(h, FPIC_ERR_INVALID_ARG, ".source_pdf <- the first grid row carries no weight (the reference throws a TypeError here)");
+        float* stage = nullptr;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), xy.size() * sizeof(float)));
+        hipError_t e = hipMemcpyAsync(stage, xy.data(), xy.size() * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            if (h->prec == FPIC_F32) convert_kernel<float, float><<<blocks_for(xy.size()), 256, 0, h->stream>>>(stage, static_cast<float*>(h->inv_cdf_xy), xy.size());
+            else convert_kernel<double, float><<<blocks_for(xy.size()), 256, 0, h->stream>>>(stage, static_cast<double*>(h->inv_cdf_xy), xy.size());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(stage);
+        if (e != hipSuccess) return fail(h, FPIC_ERR_HIP, "inverse-CDF upload failed: %s", hipGetErrorString(e));
+        return FPIC_OK;
+    }
+    if (h->prec == FPIC_F32)
+        return dtype == FPIC_F32 ? set_grid_t<float, float>(h, which, static_cast<const float*>(data), ncomp)
+                                 : set_grid_t<float, double>(h, which, static_cast<const double*>(data), ncomp);
+    return dtype == FPIC_F32 ? set_grid_t<double, float>(h, which, static_cast<const float*>(data), ncomp)
+                             : set_grid_t<double, double>(h, which, static_cast<const double*>(data), ncomp);
+}
+
+int fpic_set_random_state(fpic_handle* h, const float* entropy, const float* rand)
+{
+    CHECK_HANDLE(h);
+    if (entropy) {
+        const size_t ne = static_cast<size_t>(4) * kEntropySide * kEntropySide;
+        float* stage = nullptr;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), ne * sizeof(float)));
+        hipError_t e = hipMemcpyAsync(stage, entropy, ne * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        int rc = FPIC_OK;
+        if (e == hipSuccess) rc = h->prec == FPIC_F32 ? upload_entropy<float>(h, stage) : upload_entropy<double>(h, stage);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(stage);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(h, FPIC_ERR_HIP, "entropy upload failed: %s", hipGetErrorString(e));
+    }
+    if (rand) return h->prec == FPIC_F32 ? upload_rand_chunked<float>(h, rand, nullptr) : upload_rand_chunked<double>(h, rand, nullptr);
+    return FPIC_OK;
+}
+
+int fpic_add_current_loop(fpic_handle* h, double r, double z, double current)
+{
+    CHECK_HANDLE(h);
+    return h->prec == FPIC_F32 ? paint_loop<float>(h, r, z, current) : paint_loop<double>(h, r, z, current);
+}
+int fpic_add_current_z(fpic_handle* h, double current)
+{
+    CHECK_HANDLE(h);
+    return h->prec == FPIC_F32 ? paint_uniform<float>(h, 0, current) : paint_uniform<double>(h, 0, current);
+}
+int fpic_add_bz(fpic_handle* h, double bz)
+{
+    CHECK_HANDLE(h);
+    return h->prec == FPIC_F32 ? paint_uniform<float>(h, 1, bz) : paint_uniform<double>(h, 1, bz);
+}
+int fpic_add_btheta(fpic_handle* h, double btheta)
+{
+    CHECK_HANDLE(h);
+    return h->prec == FPIC_F32 ? paint_uniform<float>(h, 2, btheta) : paint_uniform<double>(h, 2, btheta);
+}
+
+int fpic_precalc(fpic_handle* h)
+{
+    CHECK_HANDLE(h);
+    return h->prec == FPIC_F32 ? launch_precalc<float>(h) : launch_precalc<double>(h);
+}
+
+int fpic_step(fpic_handle* h, int ncalls)
+{
+    CHECK_HANDLE(h);
+    if (ncalls < 0) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- must be >= 0");
+    if (ncalls == 0) return FPIC_OK;
+    if (ncalls > (1 << 29)) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- too large");
+    const int rc = h->prec == FPIC_F32 ? launch_push<float>(h, 2 * ncalls) : launch_push<double>(h, 2 * ncalls);
+    if (rc == FPIC_OK) {
+        h->step_launches++;
+        h->particle_updates += static_cast<uint64_t>(2) * ncalls * h->n;
+    }
+    return rc;
+}
+
+int fpic_sort(fpic_handle* h)
+{
+    CHECK_HANDLE(h);
+    return h->prec == FPIC_F32 ? launch_bin<float>(h) : launch_bin<double>(h);
+}
+
+int fpic_deposit(fpic_handle* h)
+{
+    CHECK_HANDLE(h);
+    bool rebin = !h->binned;
+    if (!rebin) {
+        if (h->spec.sort_interval > 0) {
+            rebin = h->deposits_since_bin >= h->spec.sort_interval;
+        } else {
+            if (h->spill_pending && hipEventQuery(h->spill_event) == hipSuccess) {
+                h->last_spill = *h->spilled_host;
+                h->spill_pending = false;
+            }
+            rebin = h->last_spill * 50 > h->n; // more than 2 % of the particles missed their LDS tile
+        }
+    }
+    if (rebin)
+        if (int rc = fpic_sort(h)) return rc;
+    const int rc = h->prec == FPIC_F32 ? launch_cell_sums<float>(h) : launch_cell_sums<double>(h);
+    if (rc == FPIC_OK) { h->deposit_launches++; h->deposits_since_bin++; }
+    return rc;
+}
+
+int fpic_density_finish(fpic_handle* h)
+{
+    CHECK_HANDLE(h);
+    return h->prec == FPIC_F32 ? launch_stamp_finish<float>(h) : launch_stamp_finish<double>(h);
+}
+
+int fpic_density(fpic_handle* h)
+{
+    if (int rc = fpic_deposit(h)) return rc;
+    return fpic_density_finish(h);
+}
+
+int fpic_read_grid(fpic_handle* h, int which, void* out, int dtype)
+{
+    CHECK_HANDLE(h);
+    if (!out) return fail(h, FPIC_ERR_INVALID_ARG, ".out <- Non-optional property is undefined!");
+    if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
+    if (h->prec == FPIC_F32)
+        return dtype == FPIC_F32 ? read_grid_t<float, float>(h, which, static_cast<float*>(out))
+                                 : read_grid_t<float, double>(h, which, static_cast<double*>(out));
+    return dtype == FPIC_F32 ? read_grid_t<double, float>(h, which, static_cast<float*>(out))
+                             : read_grid_t<double, double>(h, which, static_cast<double*>(out));
+}
+
+int fpic_get_particles(fpic_handle* h, void* pos_aos, void* vel_aos, float* rand, uint8_t* alive, int dtype)
+{
+    CHECK_HANDLE(h);
+    if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
+    int rc = FPIC_OK;
+    for (int pass = 0; pass < 2 && rc == FPIC_OK; ++pass) {
+        void* dst = pass == 0 ? pos_aos : vel_aos;
+        if (!dst) continue;
+        const int first = pass == 0 ? 0 : 3;
+        if (h->prec == FPIC_F32)
+            rc = dtype == FPIC_F32 ? download_vec3<float, float>(h, static_cast<float*>(dst), first)
+                                   : download_vec3<float, double>(h, static_cast<double*>(dst), first);
+        else
+            rc = dtype == FPIC_F32 ? download_vec3<double, float>(h, static_cast<float*>(dst), first)
+                                   : download_vec3<double, double>(h, static_cast<double*>(dst), first);
+    }
+    if (rc == FPIC_OK && (rand || alive))
+        rc = h->prec == FPIC_F32 ? download_misc<float>(h, rand, alive, nullptr) : download_misc<double>(h, rand, alive, nullptr);
+    return rc;
+}
+
+int fpic_get_cells(fpic_handle* h, int32_t* cells)
+{
+    CHECK_HANDLE(h);
+    if (!cells) return fail(h, FPIC_ERR_INVALID_ARG, ".cells <- Non-optional property is undefined!");
+    return h->prec == FPIC_F32 ? download_misc<float>(h, nullptr, nullptr, cells) : download_misc<double>(h, nullptr, nullptr, cells);
+}
+
+int fpic_device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes)
+{
+    CHECK_HANDLE(h);
+    if (which != FPIC_BUF_CELL_SUMS) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown buffer %d", which);
+    if (dptr) *dptr = h->cell_sums;
+    if (bytes) *bytes = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1) * 4 * h->esize;
+    return FPIC_OK;
+}
+
+int fpic_set_stream(fpic_handle* h, void* hip_stream)
+{
+    CHECK_HANDLE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    timing_collect(h);
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return FPIC_OK;
+}
+
+int fpic_get_stream(fpic_handle* h, void** hip_stream)
+{
+    CHECK_HANDLE(h);
+    if (hip_stream) *hip_stream = h->stream;
+    return FPIC_OK;
+}
+
+int fpic_sync(fpic_handle* h)
+{
+    CHECK_HANDLE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FPIC_OK;
+}
+
+int fpic_profile(fpic_handle* h, int enable)
+{
+    CHECK_HANDLE(h);
+    timing_collect(h);
+    h->profiling = enable != 0;
+    return FPIC_OK;
+}
+
+int fpic_get_stats(fpic_handle* h, fpic_stats* out)
+{
+    CHECK_HANDLE(h);
+    if (!out) return fail(h, FPIC_ERR_INVALID_ARG, ".out <- Non-optional property is undefined!");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    timing_collect(h);
+    if (h->spill_pending) { h->last_spill = *h->spilled_host; h->spill_pending = false; }
+    std::memset(out, 0, sizeof *out);
+    out->n_particles = h->n;
+    out->particle_updates = h->particle_updates;
+    out->step_launches = h->step_launches;
+    out->deposit_launches = h->deposit_launches;
+    out->sort_passes = h->sort_passes;
+    out->deposit_spilled = h->last_spill;
+    out->ms_push = h->ms[KC_PUSH];
+    out->ms_deposit = h->ms[KC_DEPOSIT];
+    out->ms_stamp = h->ms[KC_STAMP];
+    out->ms_precalc = h->ms[KC_PRECALC];
+    out->ms_sort = h->ms[KC_SORT];
+    out->bytes_particle_state = h->bytes_particles;
+    out->bytes_grid_state = h->bytes_grid;
+    return FPIC_OK;
+}
+
+int fpic_reset_stats(fpic_handle* h)
+{
+    CHECK_HANDLE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    timing_collect(h);
+    for (double& m : h->ms) m = 0;
+    h->particle_updates = h->step_launches = h->deposit_launches = h->sort_passes = 0;
+    return FPIC_OK;
+}
+
+} // extern "C"

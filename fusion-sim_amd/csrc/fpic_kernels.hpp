@@ -1,0 +1,800 @@
+// fpic_kernels.hpp — CDNA4 (gfx950) kernels of the particle-in-cell hot path.
+//
+// One template per kernel, instantiated for float (the reference's precision) and
+// double.  Each kernel names the reference GLSL program it computes
+// (/root/reference/public/javascripts/empic.js).  Expression order follows the
+// shader text; the library is built with -ffp-contract=off and correctly rounded
+// sqrt / divide so that float results agree with the CPU oracle bit for bit.
+//
+// Device layout
+//   particles : structure of arrays x,y,z,vx,vy,vz,u1,u2,c1,c2 (T) + alive (u8) + id (u32);
+//               16-byte vector loads, 4 (float) or 2 (double) particles per lane.
+//               id is the caller's particle index: binning permutes the arrays.
+//   coef      : 12 T per cell, [R11 R12 R13 A1 | R21 R22 R23 A2 | R31 R32 R33 A3],
+//               cell = i + j*nr, so a lane's gather is three 16-byte loads of one record.
+//   sink_alive: 1 byte per cell (sink.r > 0.5 evaluated once at set()).
+//   inv_cdf_xy: 2 T per texel of the 512x512 injection table.
+//   entropy   : 4 T per texel of the 1024x1024 table.
+//   cell_sums : 4 T per cell of an (nr+1) x (nz+1) grid: sums of 0.001*(vr,vtheta,vz,1)
+//               over the particles whose nearest cell it is.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fpic_internal.hpp"
+
+namespace fpic {
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+template <typename T> __device__ __forceinline__ T sqrt_(T v);
+template <> __device__ __forceinline__ float sqrt_<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ double sqrt_<double>(double v) { return sqrt(v); }
+template <typename T> __device__ __forceinline__ T cos_(T v);
+template <> __device__ __forceinline__ float cos_<float>(float v) { return cosf(v); }
+template <> __device__ __forceinline__ double cos_<double>(double v) { return cos(v); }
+
+template <typename T>
+struct ParticleArrays {
+    T *x, *y, *z, *vx, *vy, *vz, *u1, *u2, *c1, *c2;
+    uint8_t* alive;
+    uint32_t* id;
+};
+
+struct BlockWork {
+    uint32_t tile, begin, end, pad;
+};
+
+// NEAREST + CLAMP_TO_EDGE texel index (utilities.js:528-531); NaN selects texel 0.
+template <typename T>
+__device__ __forceinline__ int ngp(T u, int W)
+{
+    const T t = u * static_cast<T>(W);
+    if (!(t >= static_cast<T>(0))) return 0;
+    if (t >= static_cast<T>(W)) return W - 1;
+    return static_cast<int>(t);
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, T (&o)[4])
+{
+    if constexpr (sizeof(T) == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+        const double2 a = *reinterpret_cast<const double2*>(p);
+        const double2 b = *reinterpret_cast<const double2*>(p + 2);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void load_lane(const T* arr, size_t base, T (&o)[N])
+{
+    using V = typename Vec16<T>::type;
+    static_assert(N == Vec16<T>::N, "one 16-byte vector per lane");
+    const V v = *reinterpret_cast<const V*>(arr + base);
+    if constexpr (N == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else { o[0] = v.x; o[1] = v.y; }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void store_lane(T* arr, size_t base, const T (&o)[N])
+{
+    using V = typename Vec16<T>::type;
+    V v;
+    if constexpr (N == 4) { v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3]; }
+    else { v.x = o[0]; v.y = o[1]; }
+    *reinterpret_cast<V*>(arr + base) = v;
+}
+
+// ------------------------------------------------------------------ push (K3 + K1 + K2)
+
+template <typename T>
+struct PushArgs {
+    ParticleArrays<T> p;
+    const T* coef;
+    const uint8_t* sink_alive;
+    const T* inv_cdf_xy;
+    const T* entropy;
+    int nr, nz;
+    T step_factor;
+    unsigned long long n;
+    int nsub;
+};
+
+template <typename T>
+struct Particle {
+    T x, y, z, vx, vy, vz, u1, u2, c1, c2;
+    bool alive;
+};
+
+// One leap-frog sub-step of one particle: step_velocity_frag (empic.js:749-773), then
+// step_position_frag on the NEW velocity (empic.js:714-719), both reading the OLD
+// random state, then the random state's own advance (empic.js:800-807).  This is the
+// order of bindings in out.step (empic.js:815-853, :890-928).
+template <typename T>
+__device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a)
+{
+    // entropy texel for the random advance depends on nothing below: issue it first
+    const int et = ngp(q.c1, kEntropySide) + kEntropySide * ngp(q.c2, kEntropySide);
+    T s[4];
+    load4(a.entropy + 4 * static_cast<size_t>(et), s);
+
+    // K1: velocity in local cylindrical components, v' = R v + A at the nearest cell
+    const T r = sqrt_(q.x * q.x + q.y * q.y);
+    const T dx = q.x / r, dy = q.y / r;
+    const T vr = q.vx * dx + q.vy * dy;
+    const T va = q.vy * dx - q.vx * dy;
+    const int cell = ngp(r, a.nr) + a.nr * ngp(q.z, a.nz);
+    const T* cf = a.coef + 12 * static_cast<size_t>(cell);
+    T R1[4], R2[4], R3[4];
+    load4(cf, R1);
+    load4(cf + 4, R2);
+    load4(cf + 8, R3);
+    const T cx = ((R1[0] * vr + R1[1] * va) + R1[2] * q.vz) + R1[3];
+    const T cy = ((R2[0] * vr + R2[1] * va) + R2[2] * q.vz) + R2[3];
+    const T cz = ((R3[0] * vr + R3[1] * va) + R3[2] * q.vz) + R3[3];
+    T nvx = cx * dx - cy * dy;
+    T nvy = cx * dy + cy * dx;
+    T nvz = cz;
+    if (!q.alive) { // re-injected on the previous sub-step (empic.js:772, quirk Q4)
+        nvx = static_cast<T>(0.001) * (static_cast<T>(2) * q.u1 - static_cast<T>(1));
+        nvy = static_cast<T>(0.001) * (static_cast<T>(2) * q.u2 - static_cast<T>(1));
+        nvz = static_cast<T>(0.001) * (static_cast<T>(2) * q.c1 - static_cast<T>(1));
+    }
+
+    // K2: drift, boundary test, re-injection from the inverse-CDF table
+    const T nx = q.x + a.step_factor * nvx;
+    const T ny = q.y + a.step_factor * nvy;
+    const T nzp = q.z + a.step_factor * nvz;
+    const T r2 = sqrt_(nx * nx + ny * ny);
+    const int cell2 = ngp(r2, a.nr) + a.nr * ngp(nzp, a.nz);
+    const bool keep = a.sink_alive[cell2] != 0;
+    if (keep) {
+        q.x = nx; q.y = ny; q.z = nzp;
+    } else {
+        const int t = ngp(q.u1, kCdfSide) + kCdfSide * ngp(q.u2, kCdfSide);
+        q.x = a.inv_cdf_xy[2 * static_cast<size_t>(t)];
+        q.y = static_cast<T>(0);
+        q.z = a.inv_cdf_xy[2 * static_cast<size_t>(t) + 1];
+    }
+    q.alive = keep;
+    q.vx = nvx; q.vy = nvy; q.vz = nvz;
+
+    // K3: additive walk on (u1,u2), logistic map on (c1,c2) (quirk Q5: m == 1 stays 1)
+    const T x0 = static_cast<T>(0.999) * q.c1 + static_cast<T>(0.001) * s[2];
+    const T x1 = static_cast<T>(0.999) * q.c2 + static_cast<T>(0.001) * s[3];
+    const T m0 = q.u1 + s[0], m1 = q.u2 + s[1];
+    q.u1 = (m0 > static_cast<T>(1)) ? m0 - static_cast<T>(1) : m0;
+    q.u2 = (m1 > static_cast<T>(1)) ? m1 - static_cast<T>(1) : m1;
+    q.c1 = static_cast<T>(4) * x0 * (static_cast<T>(1) - x0);
+    q.c2 = static_cast<T>(4) * x1 * (static_cast<T>(1) - x1);
+}
+
+// out.step (empic.js:1436-1469) fused: nsub = 2 * ncalls sub-steps per launch, state
+// held in registers between them.  Traffic per launch: one read and one write of
+// the particle state (10 T + 1 byte each way) however many sub-steps are taken.
+template <typename T>
+__global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
+{
+    constexpr int PPT = Vec16<T>::N;
+    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
+    if (base >= a.n) return;
+    const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+
+    T x[PPT], y[PPT], z[PPT], vx[PPT], vy[PPT], vz[PPT], u1[PPT], u2[PPT], c1[PPT], c2[PPT];
+    uint8_t al[PPT];
+    // arrays are padded to a multiple of the vector width, so the vector load is in bounds
+    load_lane<T, PPT>(a.p.x, base, x);
+    load_lane<T, PPT>(a.p.y, base, y);
+    load_lane<T, PPT>(a.p.z, base, z);
+    load_lane<T, PPT>(a.p.vx, base, vx);
+    load_lane<T, PPT>(a.p.vy, base, vy);
+    load_lane<T, PPT>(a.p.vz, base, vz);
+    load_lane<T, PPT>(a.p.u1, base, u1);
+    load_lane<T, PPT>(a.p.u2, base, u2);
+    load_lane<T, PPT>(a.p.c1, base, c1);
+    load_lane<T, PPT>(a.p.c2, base, c2);
+    if constexpr (PPT == 4) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(a.p.alive + base);
+        al[0] = v.x; al[1] = v.y; al[2] = v.z; al[3] = v.w;
+    } else {
+        const uchar2 v = *reinterpret_cast<const uchar2*>(a.p.alive + base);
+        al[0] = v.x; al[1] = v.y;
+    }
+
+    Particle<T> q[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        q[k].x = x[k]; q[k].y = y[k]; q[k].z = z[k];
+        q[k].vx = vx[k]; q[k].vy = vy[k]; q[k].vz = vz[k];
+        q[k].u1 = u1[k]; q[k].u2 = u2[k]; q[k].c1 = c1[k]; q[k].c2 = c2[k];
+        q[k].alive = al[k] != 0;
+        if (k >= cnt) { // padding lanes: keep every gather in range, results are discarded
+            q[k].x = static_cast<T>(0.5); q[k].y = static_cast<T>(0); q[k].z = static_cast<T>(0.5);
+            q[k].vx = q[k].vy = q[k].vz = static_cast<T>(0);
+            q[k].u1 = q[k].u2 = q[k].c1 = q[k].c2 = static_cast<T>(0.5);
+        }
+    }
+    for (int s = 0; s < a.nsub; ++s) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) substep(q[k], a);
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        x[k] = q[k].x; y[k] = q[k].y; z[k] = q[k].z;
+        vx[k] = q[k].vx; vy[k] = q[k].vy; vz[k] = q[k].vz;
+        u1[k] = q[k].u1; u2[k] = q[k].u2; c1[k] = q[k].c1; c2[k] = q[k].c2;
+        al[k] = q[k].alive ? 1 : 0;
+    }
+    if (cnt == PPT) {
+        store_lane<T, PPT>(a.p.x, base, x);
+        store_lane<T, PPT>(a.p.y, base, y);
+        store_lane<T, PPT>(a.p.z, base, z);
+        store_lane<T, PPT>(a.p.vx, base, vx);
+        store_lane<T, PPT>(a.p.vy, base, vy);
+        store_lane<T, PPT>(a.p.vz, base, vz);
+        store_lane<T, PPT>(a.p.u1, base, u1);
+        store_lane<T, PPT>(a.p.u2, base, u2);
+        store_lane<T, PPT>(a.p.c1, base, c1);
+        store_lane<T, PPT>(a.p.c2, base, c2);
+        if constexpr (PPT == 4) {
+            *reinterpret_cast<uchar4*>(a.p.alive + base) = make_uchar4(al[0], al[1], al[2], al[3]);
+        } else {
+            *reinterpret_cast<uchar2*>(a.p.alive + base) = make_uchar2(al[0], al[1]);
+        }
+    } else {
+        for (int k = 0; k < cnt; ++k) {
+            a.p.x[base + k] = x[k]; a.p.y[base + k] = y[k]; a.p.z[base + k] = z[k];
+            a.p.vx[base + k] = vx[k]; a.p.vy[base + k] = vy[k]; a.p.vz[base + k] = vz[k];
+            a.p.u1[base + k] = u1[k]; a.p.u2[base + k] = u2[k];
+            a.p.c1[base + k] = c1[k]; a.p.c2[base + k] = c2[k];
+            a.p.alive[base + k] = al[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ scatter (K4), stage 1
+//
+// programMoments01 (empic.js:980-1035) draws every particle as an 11x11 sprite whose
+// texel weights do not depend on the sub-cell offset (NEAREST lookup of
+// gl_PointCoord).  The blended result is therefore the per-cell sums of the vertex
+// colour 0.001*(vr,vtheta,vz,1) convolved with the stamp.  Stage 1 forms the
+// per-cell sums; stage 2 (stamp_finish_kernel) applies the stamp.
+
+// Deposit cell of a particle, or false when the point is clipped (centre outside
+// the clip volume, or NaN).  ic in [0,nr], jc in [0,nz]: r = 1 lands on column nr.
+template <typename T>
+__device__ __forceinline__ bool deposit_cell(T x, T y, T z, int nr, int nz, T& r, int& ic, int& jc)
+{
+    r = sqrt_(x * x + y * y);
+    if (!(r >= static_cast<T>(0) && r <= static_cast<T>(1) && z >= static_cast<T>(0) && z <= static_cast<T>(1)))
+        return false;
+    ic = static_cast<int>(r * static_cast<T>(nr));
+    jc = static_cast<int>(z * static_cast<T>(nz));
+    return true;
+}
+
+// One workgroup sums one chunk of the particles binned to one tile.  The tile and an
+// 8-cell halo live in LDS; lanes add with LDS float atomics, then the non-zero part
+// of the tile is flushed with global atomics in 256-byte contiguous pieces.  A
+// particle that has drifted beyond the halo since the last binning goes straight to
+// global memory (counted in *spilled); correctness never depends on the binning.
+template <typename T>
+__global__ __launch_bounds__(256) void cell_sums_kernel(ParticleArrays<T> p, int nr, int nz, int ntx,
+                                                        const BlockWork* __restrict__ work,
+                                                        const uint32_t* __restrict__ nwork, T* __restrict__ cell_sums,
+                                                        unsigned long long* spilled)
+{
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int LW = kTileLds;
+    __shared__ T tile[LW * LW * 4];
+    if (blockIdx.x >= *nwork) return;
+    const BlockWork w = work[blockIdx.x];
+    const int i0 = static_cast<int>(w.tile % ntx) * kTileSide - kTileHalo;
+    const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kTileHalo;
+    for (int k = threadIdx.x; k < LW * LW * 4; k += 256) tile[k] = static_cast<T>(0);
+    __syncthreads();
+
+    const size_t gw = static_cast<size_t>(nr) + 1;
+    unsigned int my_spill = 0;
+    const size_t first = (static_cast<size_t>(w.begin) / PPT) * PPT;
+    for (size_t base = first + static_cast<size_t>(threadIdx.x) * PPT; base < w.end; base += 256 * PPT) {
+        T x[PPT], y[PPT], z[PPT], vx[PPT], vy[PPT], vz[PPT];
+        load_lane<T, PPT>(p.x, base, x);
+        load_lane<T, PPT>(p.y, base, y);
+        load_lane<T, PPT>(p.z, base, z);
+        load_lane<T, PPT>(p.vx, base, vx);
+        load_lane<T, PPT>(p.vy, base, vy);
+        load_lane<T, PPT>(p.vz, base, vz);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const size_t i = base + k;
+            if (i < w.begin || i >= w.end) continue;
+            T r;
+            int ic, jc;
+            if (!deposit_cell(x[k], y[k], z[k], nr, nz, r, ic, jc)) continue;
+            const T dx = x[k] / r, dy = y[k] / r;
+            const T vr = vx[k] * dx + vy[k] * dy;
+            const T va = vy[k] * dx - vx[k] * dy;
+            const T c0 = static_cast<T>(0.001) * vr;
+            const T c1 = static_cast<T>(0.001) * va;
+            const T c2 = static_cast<T>(0.001) * vz[k];
+            const T c3 = static_cast<T>(0.001) * static_cast<T>(1);
+            const int li = ic - i0, lj = jc - j0;
+            if (li >= 0 && li < LW && lj >= 0 && lj < LW) {
+                T* t = tile + 4 * (lj * LW + li);
+                atomicAdd(t, c0);
+                atomicAdd(t + 1, c1);
+                atomicAdd(t + 2, c2);
+                atomicAdd(t + 3, c3);
+            } else {
+                T* g = cell_sums + 4 * (static_cast<size_t>(ic) + gw * jc);
+                atomicAdd(g, c0);
+                atomicAdd(g + 1, c1);
+                atomicAdd(g + 2, c2);
+                atomicAdd(g + 3, c3);
+                ++my_spill;
+            }
+        }
+    }
+    __syncthreads();
+    // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
+    // global addresses, so a wave's atomic is one 256-byte piece
+    for (int k = threadIdx.x; k < LW * LW * 4; k += 256) {
+        const T v = tile[k];
+        if (v == static_cast<T>(0)) continue;
+        const int lj = k / (LW * 4);
+        const int rem = k - lj * (LW * 4);
+        const int gi = i0 + (rem >> 2), gj = j0 + lj;
+        if (gi < 0 || gi > nr || gj < 0 || gj > nz) continue;
+        atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), v);
+    }
+    if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
+}
+
+// ------------------------------------------------------------------ scatter stage 2 + K5 + K6 + K7
+//
+// moments01 = stamp (*) cell_sums, cropped at the grid's edges (empic.js:1473-1478);
+// programNormalizeMoments01 (empic.js:1052-1057); avg_frag with u_ratio
+// (empic.js:273-278, :1083); the avgA -> avgB copy (empic.js:1490-1495) is the
+// in-place update of the single avg buffer.
+// A particle in cell (ic,jc) adds weight[(di+5) + 11*(5-dj)] to cell (ic+di, jc+dj)
+// (gl_PointCoord.t runs downwards; the stamp is symmetric).
+template <typename T>
+__global__ __launch_bounds__(256) void stamp_finish_kernel(const T* __restrict__ cell_sums, int nr, int nz,
+                                                           const float* __restrict__ stamp, T* __restrict__ moments,
+                                                           T* __restrict__ norm, T* __restrict__ avg, T ratio)
+{
+    constexpr int OT = 32;                      // output tile edge
+    constexpr int LW = OT + 2 * kStampReach;    // staged cell_sums tile edge
+    __shared__ T g[LW * LW * 4];
+    __shared__ float w[kStampCells];
+    const int i0 = blockIdx.x * OT, j0 = blockIdx.y * OT;
+    const size_t gw = static_cast<size_t>(nr) + 1;
+    for (int k = threadIdx.x; k < kStampCells; k += 256) w[k] = stamp[k];
+    for (int k = threadIdx.x; k < LW * LW; k += 256) {
+        const int lj = k / LW, li = k - lj * LW;
+        const int gi = i0 - kStampReach + li, gj = j0 - kStampReach + lj;
+        T v[4] = { 0, 0, 0, 0 };
+        if (gi >= 0 && gi <= nr && gj >= 0 && gj <= nz) load4(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj), v);
+        g[4 * k] = v[0]; g[4 * k + 1] = v[1]; g[4 * k + 2] = v[2]; g[4 * k + 3] = v[3];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const T keep = static_cast<T>(1) - ratio;
+    for (int m = 0; m < OT / 8; ++m) {
+        const int lj = ty + 8 * m;
+        const int i = i0 + tx, j = j0 + lj;
+        if (i >= nr || j >= nz) continue;
+        T acc[4] = { 0, 0, 0, 0 };
+        for (int b = 0; b < kStampSide; ++b) {
+#pragma unroll
+            for (int a = 0; a < kStampSide; ++a) {
+                // source cell (i - di, j - dj) with di = 5 - a, dj = 5 - b
+                const T wt = static_cast<T>(w[(10 - a) + kStampSide * b]);
+                const T* s = g + 4 * ((lj + b) * LW + (tx + a));
+                acc[0] += wt * s[0];
+                acc[1] += wt * s[1];
+                acc[2] += wt * s[2];
+                acc[3] += wt * s[3];
+            }
+        }
+        const size_t c = 4 * (static_cast<size_t>(i) + static_cast<size_t>(nr) * j);
+        const T xc = (static_cast<T>(i) + static_cast<T>(0.5)) / static_cast<T>(nr);
+        T nm[4] = { 0, 0, 0, 0 };
+        if (acc[3] > static_cast<T>(0)) {
+            nm[0] = acc[0] / acc[3]; nm[1] = acc[1] / acc[3]; nm[2] = acc[2] / acc[3]; nm[3] = acc[3];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T nv = static_cast<T>(1000) * nm[k] * static_cast<T>(0.5) / xc;
+            moments[c + k] = acc[k];
+            norm[c + k] = nv;
+            avg[c + k] = ratio * nv + keep * avg[c + k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ precalc (K8 + K9)
+
+// programPre1/2/3 and programPreA (empic.js:506-659) in one pass over the cells.
+// Bf/Ef are RGBA; h is u_h; f_rz, f_zr, fr, fz are the literals baked into the
+// shader text (empic.js:527, :566, :606, :647).
+template <typename T>
+__global__ __launch_bounds__(256) void precalc_kernel(const T* __restrict__ Bf, const T* __restrict__ Ef, size_t ncell,
+                                                      T h, T fr, T fz, T f_rz, T f_zr, int physical_a,
+                                                      T* __restrict__ coef)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    T B[4], E[4];
+    load4(Bf + 4 * c, B);
+    load4(Ef + 4 * c, E);
+    const T Bx = B[0], By = B[1], Bz = B[2];
+    const T Ex = E[0], Ey = E[1], Ez = E[2];
+    const T Bmag = sqrt_((Bx * Bx + By * By) + Bz * Bz);
+    const T hB2 = h * h * Bmag * Bmag;
+    const T factor = static_cast<T>(2) / (static_cast<T>(1) + hB2);
+    const T diag = static_cast<T>(1) - hB2 * factor;
+    const T fh = factor * h;
+    T* o = coef + 12 * c;
+
+    o[0] = diag + fh * h * Bx * Bx;
+    o[1] = fh * (Bz + h * Bx * By);
+    o[2] = (fh * (-By + h * Bx * Bz)) * f_rz;
+
+    o[4] = fh * (-Bz + h * By * Bx);
+    o[5] = diag + fh * h * By * By;
+    o[6] = (fh * (Bx + h * By * Bz)) * f_rz;
+
+    o[8] = (fh * (By + h * Bz * Bx)) * f_zr;
+    o[9] = (fh * (-Bx + h * Bz * By)) * f_zr;
+    o[10] = diag + fh * h * Bz * Bz;
+
+    const T a = h * (static_cast<T>(2) - hB2 * factor);
+    const T b = h * h * factor;
+    const T cx = Ey * Bz - Ez * By;
+    const T cy = Ez * Bx - Ex * Bz;
+    const T cz = Ex * By - Ey * Bx;
+    const T dot = (Ex * Bx + Ey * By) + Ez * Bz;
+    const T hd = h * dot;
+    // quirk Q1 (empic.js:645): the reference adds the scalar u_h*dot(E,B) to every
+    // component; physical_a selects h (E.B) B instead
+    const T kx = physical_a ? hd * Bx : hd;
+    const T ky = physical_a ? hd * By : hd;
+    const T kz = physical_a ? hd * Bz : hd;
+    const T Ax = (a * Ex + b * (cx + kx)) / static_cast<T>(2.998e8);
+    const T Ay = (a * Ey + b * (cy + ky)) / static_cast<T>(2.998e8);
+    const T Az = (a * Ez + b * (cz + kz)) / static_cast<T>(2.998e8);
+    o[3] = Ax * fr;
+    o[7] = Ay * fr;
+    o[11] = Az * fz;
+}
+
+// ------------------------------------------------------------------ static field painters (K10-K12)
+
+// programCurrentLoopShape (empic.js:295-345): 1000-segment Biot-Savart sum.
+template <typename T>
+__global__ __launch_bounds__(256) void loop_shape_kernel(T u_R, int nr, int nz, T* __restrict__ out)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nr) * nz) return;
+    const int i = static_cast<int>(c % nr), j = static_cast<int>(c / nr);
+    const T pi = static_cast<T>(3.14159265359);
+    const T constant = u_R * static_cast<T>(0.001) * static_cast<T>(1.25663706e-6) / (static_cast<T>(4.0) * pi);
+    const T tx = (static_cast<T>(i) + static_cast<T>(0.5)) / static_cast<T>(nr);
+    const T ty = (static_cast<T>(j) + static_cast<T>(0.5)) / static_cast<T>(nz);
+    T Bx = 0, Bz = 0;
+    for (int k = 0; k < 1000; ++k) {
+        const T cosine = cos_(pi * (static_cast<T>(k) + static_cast<T>(0.5)) / static_cast<T>(1000.0));
+        const T r = sqrt_(u_R * u_R + tx * tx + ty * ty - static_cast<T>(2.0) * tx * u_R * cosine);
+        const T factor = (r > static_cast<T>(0)) ? constant * static_cast<T>(1.0) / (r * r * r) : static_cast<T>(0);
+        Bx += ty * factor * cosine;
+        Bz += factor * (u_R - tx * cosine);
+    }
+    out[4 * c] = Bx; out[4 * c + 1] = static_cast<T>(0); out[4 * c + 2] = Bz; out[4 * c + 3] = static_cast<T>(1);
+}
+
+// programCurrentLoop (empic.js:349-389) blended ONE,ONE into B (empic.js:1352-1363).
+template <typename T>
+__global__ __launch_bounds__(256) void current_loop_kernel(T* __restrict__ Bf, const T* __restrict__ half,
+                                                           const T* __restrict__ tenth, int nr, int nz, T u_R, T u_Z,
+                                                           T u_I)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nr) * nz) return;
+    const int i = static_cast<int>(c % nr), j = static_cast<int>(c / nr);
+    const T tx = (static_cast<T>(i) + static_cast<T>(0.5)) / static_cast<T>(nr);
+    const T ty = (static_cast<T>(j) + static_cast<T>(0.5)) / static_cast<T>(nz);
+    const T a = tx / u_R;
+    const T b = (ty - u_Z) / u_R;
+    const T sgn = (b > static_cast<T>(0)) ? static_cast<T>(1) : ((b < static_cast<T>(0)) ? static_cast<T>(-1) : static_cast<T>(0));
+    const T ab = (b < static_cast<T>(0)) ? -b : b;
+    const T* t;
+    if (a > static_cast<T>(2.0) || b > static_cast<T>(2.0)) // quirk Q6: no abs on b
+        t = tenth + 4 * (static_cast<size_t>(ngp(a / static_cast<T>(10.0), nr)) + static_cast<size_t>(nr) * ngp(ab / static_cast<T>(10.0), nz));
+    else
+        t = half + 4 * (static_cast<size_t>(ngp(a / static_cast<T>(2.0), nr)) + static_cast<size_t>(nr) * ngp(ab / static_cast<T>(2.0), nz));
+    T* o = Bf + 4 * c;
+    o[0] += (u_I * sgn) * t[0];
+    o[1] += (u_I * static_cast<T>(1)) * t[1];
+    o[2] += (u_I * static_cast<T>(1)) * t[2];
+    o[3] += (u_I * static_cast<T>(1)) * t[3];
+}
+
+// programCurrentZ / programBZ / programBTheta (empic.js:392-464, :1380-1411);
+// kind 0: line current on the axis, 1: uniform Bz, 2: uniform Btheta (quirk Q7:
+// the undefined initial gl_FragColor is taken as 0).
+template <typename T>
+__global__ __launch_bounds__(256) void add_uniform_kernel(T* __restrict__ Bf, int nr, int nz, int kind, T value)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nr) * nz) return;
+    T* o = Bf + 4 * c;
+    if (kind == 0) {
+        const T tx = (static_cast<T>(c % nr) + static_cast<T>(0.5)) / static_cast<T>(nr);
+        o[1] += value * static_cast<T>(1.25663706e-6) / (static_cast<T>(2.0) * static_cast<T>(3.14159265359) * tx);
+    } else if (kind == 1) {
+        o[2] += value;
+    } else {
+        o[1] += value;
+    }
+    o[3] += static_cast<T>(1);
+}
+
+// ------------------------------------------------------------------ uploads, read-back
+
+template <typename T>
+__global__ __launch_bounds__(256) void init_particles_kernel(ParticleArrays<T> p, size_t n_padded)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_padded) return;
+    p.x[i] = p.y[i] = p.z[i] = p.vx[i] = p.vy[i] = p.vz[i] = static_cast<T>(0);
+    p.u1[i] = p.u2[i] = p.c1[i] = p.c2[i] = static_cast<T>(0);
+    p.alive[i] = 0; // null-data float textures start at 0 (utilities.js:533-539)
+    p.id[i] = static_cast<uint32_t>(i);
+}
+
+// out.set({position|velocity}) (empic.js:1199-1244): value*factor in double, one
+// rounding into T.  The caller's particle i lives in the slot s with id[s] == i.
+template <typename T, typename In>
+__global__ __launch_bounds__(256) void set_vec3_kernel(const In* __restrict__ aos, size_t chunk_begin, size_t chunk_n,
+                                                       double fxy, double fz, T* a, T* b, T* c, uint8_t* alive,
+                                                       const uint32_t* __restrict__ id, size_t n)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t i = id[s];
+    if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
+    const In* v = aos + 3 * (i - chunk_begin);
+    a[s] = static_cast<T>(static_cast<double>(v[0]) * fxy);
+    b[s] = static_cast<T>(static_cast<double>(v[1]) * fxy);
+    c[s] = static_cast<T>(static_cast<double>(v[2]) * fz);
+    if (alive) alive[s] = 1; // position.w = 1 (empic.js:1205)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void set_rand_kernel(const float* __restrict__ aos4, size_t chunk_begin, size_t chunk_n,
+                                                       ParticleArrays<T> p, size_t n)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t i = p.id[s];
+    if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
+    const float4 v = *reinterpret_cast<const float4*>(aos4 + 4 * (i - chunk_begin));
+    p.u1[s] = static_cast<T>(v.x); p.u2[s] = static_cast<T>(v.y);
+    p.c1[s] = static_cast<T>(v.z); p.c2[s] = static_cast<T>(v.w);
+}
+
+template <typename T, typename Out>
+__global__ __launch_bounds__(256) void get_vec3_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                       const T* __restrict__ c, const uint32_t* __restrict__ id,
+                                                       size_t n, size_t chunk_begin, size_t chunk_n, Out* __restrict__ aos)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t i = id[s];
+    if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
+    Out* o = aos + 3 * (i - chunk_begin);
+    o[0] = static_cast<Out>(a[s]); o[1] = static_cast<Out>(b[s]); o[2] = static_cast<Out>(c[s]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void get_rand_kernel(ParticleArrays<T> p, size_t n, size_t chunk_begin, size_t chunk_n,
+                                                       float* __restrict__ aos4, uint8_t* __restrict__ alive_out,
+                                                       int32_t* __restrict__ cells, int nr, int nz)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t i = p.id[s];
+    if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
+    const size_t o = i - chunk_begin;
+    if (aos4) {
+        aos4[4 * o] = static_cast<float>(p.u1[s]); aos4[4 * o + 1] = static_cast<float>(p.u2[s]);
+        aos4[4 * o + 2] = static_cast<float>(p.c1[s]); aos4[4 * o + 3] = static_cast<float>(p.c2[s]);
+    }
+    if (alive_out) alive_out[o] = p.alive[s];
+    if (cells) {
+        const T r = sqrt_(p.x[s] * p.x[s] + p.y[s] * p.y[s]);
+        cells[o] = ngp(r, nr) + nr * ngp(p.z[s], nz);
+    }
+}
+
+// out.set({E|B|sink_mask}) packing (empic.js:1159-1197, :1246-1260): value[i][j][k]
+// -> RGBA texel i + j*nr; ncomp 3 writes xyz and w = 1, ncomp 1 writes red only.
+template <typename T, typename In>
+__global__ __launch_bounds__(256) void pack_grid_kernel(const In* __restrict__ in, int nr, int nz, int ncomp,
+                                                        T* __restrict__ rgba, uint8_t* __restrict__ mask)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nr) * nz) return;
+    const int i = static_cast<int>(c % nr), j = static_cast<int>(c / nr);
+    const In* v = in + static_cast<size_t>(ncomp) * (static_cast<size_t>(i) * nz + j);
+    if (ncomp == 3) {
+        rgba[4 * c] = static_cast<T>(v[0]); rgba[4 * c + 1] = static_cast<T>(v[1]);
+        rgba[4 * c + 2] = static_cast<T>(v[2]); rgba[4 * c + 3] = static_cast<T>(1);
+    } else {
+        const T red = static_cast<T>(v[0]);
+        rgba[4 * c] = red;
+        if (mask) mask[c] = (red > static_cast<T>(0.5)) ? 1 : 0; // the test of empic.js:719
+    }
+}
+
+template <typename T, typename In>
+__global__ __launch_bounds__(256) void convert_kernel(const In* __restrict__ in, T* __restrict__ out, size_t n)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = static_cast<T>(in[i]);
+}
+
+// R1/R2/R3/A textures as the reference holds them (RGBA, w = 1), rebuilt from coef.
+template <typename T, typename Out>
+__global__ __launch_bounds__(256) void unpack_coef_kernel(const T* __restrict__ coef, size_t ncell, int row,
+                                                          Out* __restrict__ rgba)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const T* o = coef + 12 * c;
+    if (row < 3) {
+        rgba[4 * c] = static_cast<Out>(o[4 * row]); rgba[4 * c + 1] = static_cast<Out>(o[4 * row + 1]);
+        rgba[4 * c + 2] = static_cast<Out>(o[4 * row + 2]);
+    } else {
+        rgba[4 * c] = static_cast<Out>(o[3]); rgba[4 * c + 1] = static_cast<Out>(o[7]);
+        rgba[4 * c + 2] = static_cast<Out>(o[11]);
+    }
+    rgba[4 * c + 3] = static_cast<Out>(1);
+}
+
+// 512x512 (x,y) pairs -> RGBA with zeros in z,w (what inv_cdf_arr holds, empic.js:234).
+template <typename T, typename Out>
+__global__ __launch_bounds__(256) void unpack_xy_kernel(const T* __restrict__ xy, size_t n, Out* __restrict__ rgba)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    rgba[4 * c] = static_cast<Out>(xy[2 * c]); rgba[4 * c + 1] = static_cast<Out>(xy[2 * c + 1]);
+    rgba[4 * c + 2] = static_cast<Out>(0); rgba[4 * c + 3] = static_cast<Out>(0);
+}
+
+// ------------------------------------------------------------------ binning by cell tile
+
+template <typename T>
+__device__ __forceinline__ uint32_t tile_key(T x, T y, T z, int nr, int nz, int ntx, uint32_t garbage)
+{
+    T r;
+    int ic, jc;
+    if (!deposit_cell(x, y, z, nr, nz, r, ic, jc)) return garbage;
+    return static_cast<uint32_t>(ic / kTileSide) + static_cast<uint32_t>(ntx) * static_cast<uint32_t>(jc / kTileSide);
+}
+
+constexpr int kBinPer = 8; // particles per lane in the binning passes
+
+template <typename T>
+__global__ __launch_bounds__(256) void bin_count_kernel(ParticleArrays<T> p, size_t n, int nr, int nz, int ntx,
+                                                        uint32_t ntiles, uint32_t* __restrict__ tile_count)
+{
+    extern __shared__ uint32_t hist[];
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) hist[t] = 0;
+    __syncthreads();
+    const size_t base = static_cast<size_t>(blockIdx.x) * (256 * kBinPer);
+    for (int k = 0; k < kBinPer; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&hist[tile_key(p.x[i], p.y[i], p.z[i], nr, nz, ntx, ntiles - 1)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256)
+        if (hist[t]) atomicAdd(&tile_count[t], hist[t]);
+}
+
+// Exclusive scan of the tile counts, reset of the cursors, and the scatter's work
+// list: each real tile is cut into chunks of kDepositChunk particles.  One workgroup.
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t ntiles,
+                                                        uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                                        BlockWork* __restrict__ work, uint32_t* __restrict__ nwork)
+{
+    __shared__ uint32_t part_p[1024], part_b[1024];
+    const uint32_t per = (ntiles + 1023) / 1024;
+    const uint32_t t0 = threadIdx.x * per;
+    uint32_t sp = 0, sb = 0;
+    for (uint32_t t = t0; t < t0 + per && t < ntiles; ++t) {
+        const uint32_t c = tile_count[t];
+        sp += c;
+        if (t + 1 < ntiles) sb += (c + kDepositChunk - 1) / kDepositChunk; // the last bin holds clipped particles
+    }
+    part_p[threadIdx.x] = sp;
+    part_b[threadIdx.x] = sb;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t ap = 0, ab = 0;
+        if (static_cast<int>(threadIdx.x) >= off) { ap = part_p[threadIdx.x - off]; ab = part_b[threadIdx.x - off]; }
+        __syncthreads();
+        part_p[threadIdx.x] += ap;
+        part_b[threadIdx.x] += ab;
+        __syncthreads();
+    }
+    uint32_t run_p = part_p[threadIdx.x] - sp, run_b = part_b[threadIdx.x] - sb;
+    for (uint32_t t = t0; t < t0 + per && t < ntiles; ++t) {
+        const uint32_t c = tile_count[t];
+        tile_start[t] = run_p;
+        tile_cursor[t] = 0;
+        if (t + 1 < ntiles) {
+            for (uint32_t b = 0; b * kDepositChunk < c; ++b) {
+                BlockWork w;
+                w.tile = t;
+                w.begin = run_p + b * kDepositChunk;
+                w.end = run_p + ((b + 1) * kDepositChunk < c ? (b + 1) * kDepositChunk : c);
+                w.pad = 0;
+                work[run_b++] = w;
+            }
+        }
+        run_p += c;
+    }
+    if (threadIdx.x == 1023) {
+        tile_start[ntiles] = part_p[1023];
+        *nwork = part_b[1023];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bin_scatter_kernel(ParticleArrays<T> src, ParticleArrays<T> dst, size_t n, int nr,
+                                                          int nz, int ntx, uint32_t ntiles,
+                                                          const uint32_t* __restrict__ tile_start,
+                                                          uint32_t* __restrict__ tile_cursor)
+{
+    extern __shared__ uint32_t hist[];
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) hist[t] = 0;
+    __syncthreads();
+    const size_t base = static_cast<size_t>(blockIdx.x) * (256 * kBinPer);
+    uint32_t key[kBinPer], rank[kBinPer];
+#pragma unroll
+    for (int k = 0; k < kBinPer; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
+        key[k] = 0; rank[k] = 0;
+        if (i < n) {
+            key[k] = tile_key(src.x[i], src.y[i], src.z[i], nr, nz, ntx, ntiles - 1);
+            rank[k] = atomicAdd(&hist[key[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) {
+        const uint32_t c = hist[t];
+        if (c) hist[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBinPer; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const size_t d = static_cast<size_t>(hist[key[k]]) + rank[k];
+        dst.x[d] = src.x[i]; dst.y[d] = src.y[i]; dst.z[d] = src.z[i];
+        dst.vx[d] = src.vx[i]; dst.vy[d] = src.vy[i]; dst.vz[d] = src.vz[i];
+        dst.u1[d] = src.u1[i]; dst.u2[d] = src.u2[i]; dst.c1[d] = src.c1[i]; dst.c2[d] = src.c2[i];
+        dst.alive[d] = src.alive[i];
+        dst.id[d] = src.id[i];
+    }
+}
+
+} // namespace fpic

@@ -1,0 +1,313 @@
+"""fusionpic — Python host mirror of the reference's pusher object over the C ABI.
+
+The shipped host language is JavaScript (fusion-sim_amd/js/empic_native.js over an
+N-API addon).  This module binds the SAME C ABI (include/fusionpic.h) with ctypes
+for the Python tools of this repository: tests/, bench.py and __graft_entry__.py.
+It keeps the reference's factory and method names
+(empic.js:30 makeCylindricalParticlePusher, :1157 set, :1352 addCurrentLoop,
+:1380 addCurrentZ, :1391 addBZ, :1402 addBTheta, :1413 precalc, :1436 step,
+:1471 density) and its error behaviour: a failed call raises `FusionPicError`
+synchronously, with spec errors worded ".prop <- ..." (utilities.js:118-127).
+
+There is no CPU path here.  If libfusionpic.so is missing the import fails; if no
+gfx950 device is present the factory raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfusionpic.so")
+
+F32, F64 = 0, 1
+GRID_E, GRID_B, GRID_SINK_MASK, GRID_SOURCE_PDF = 0, 1, 2, 3
+(READ_MOMENTS, READ_NORM, READ_AVG, READ_R1, READ_R2, READ_R3, READ_A, READ_B, READ_E, READ_SINK,
+ READ_INV_CDF) = range(11)
+BUF_CELL_SUMS = 0
+
+ABI_FUNCTIONS = [
+    "fpic_last_error", "fpic_abi_version", "fpic_build_arch", "fpic_create", "fpic_destroy", "fpic_set_particles",
+    "fpic_set_grid", "fpic_set_random_state", "fpic_add_current_loop", "fpic_add_current_z", "fpic_add_bz",
+    "fpic_add_btheta", "fpic_precalc", "fpic_step", "fpic_density", "fpic_deposit", "fpic_density_finish",
+    "fpic_read_grid", "fpic_get_particles", "fpic_get_cells", "fpic_device_buffer", "fpic_set_stream",
+    "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
+]
+
+
+class FusionPicError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+class Spec(ctypes.Structure):
+    _fields_ = [
+        ("radius", ctypes.c_double), ("height", ctypes.c_double), ("nr", ctypes.c_int32), ("nz", ctypes.c_int32),
+        ("dt", ctypes.c_double), ("nparticles", ctypes.c_int32), ("particle_mass", ctypes.c_double),
+        ("particle_charge", ctypes.c_double), ("count", ctypes.c_uint64), ("precision", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("physical_a", ctypes.c_int32), ("sort_interval", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 8),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("n_particles", ctypes.c_uint64), ("particle_updates", ctypes.c_uint64), ("step_launches", ctypes.c_uint64),
+        ("deposit_launches", ctypes.c_uint64), ("sort_passes", ctypes.c_uint64), ("deposit_spilled", ctypes.c_uint64),
+        ("ms_push", ctypes.c_double), ("ms_deposit", ctypes.c_double), ("ms_stamp", ctypes.c_double),
+        ("ms_precalc", ctypes.c_double), ("ms_sort", ctypes.c_double), ("bytes_particle_state", ctypes.c_uint64),
+        ("bytes_grid_state", ctypes.c_uint64), ("reserved", ctypes.c_double * 8),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libfusionpic.so.  Fails loudly when the HIP library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("%s not found: build it with `make -C fusion-sim_amd` (hipcc, gfx950); "
+                          "there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.fpic_last_error.restype = ctypes.c_char_p
+    lib.fpic_last_error.argtypes = [vp]
+    lib.fpic_build_arch.restype = ctypes.c_char_p
+    lib.fpic_create.argtypes = [ctypes.POINTER(Spec), ctypes.POINTER(vp)]
+    lib.fpic_destroy.argtypes = [vp]
+    lib.fpic_set_particles.argtypes = [vp, vp, vp, ctypes.c_uint64, ci]
+    lib.fpic_set_grid.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+    lib.fpic_set_random_state.argtypes = [vp, vp, vp]
+    lib.fpic_add_current_loop.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    for f in ("fpic_add_current_z", "fpic_add_bz", "fpic_add_btheta"):
+        getattr(lib, f).argtypes = [vp, ctypes.c_double]
+    for f in ("fpic_precalc", "fpic_density", "fpic_deposit", "fpic_density_finish", "fpic_sort", "fpic_sync",
+              "fpic_reset_stats"):
+        getattr(lib, f).argtypes = [vp]
+    lib.fpic_step.argtypes = [vp, ci]
+    lib.fpic_profile.argtypes = [vp, ci]
+    lib.fpic_read_grid.argtypes = [vp, ci, vp, ci]
+    lib.fpic_get_particles.argtypes = [vp, vp, vp, vp, vp, ci]
+    lib.fpic_get_cells.argtypes = [vp, vp]
+    lib.fpic_device_buffer.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    lib.fpic_set_stream.argtypes = [vp, vp]
+    lib.fpic_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.fpic_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+_SPEC_KEYS = ("radius", "height", "nr", "nz", "dt", "nparticles", "particle_mass", "particle_charge")
+
+
+def _validate_spec(spec):
+    """validate_object(spec, {...: 'number'}) (empic.js:31-41, utilities.js:11-127)."""
+    for key in _SPEC_KEYS:
+        if key not in spec or spec[key] is None:
+            raise FusionPicError(-1, "." + key + " <- Non-optional property is undefined!")
+        if isinstance(spec[key], bool) or not isinstance(spec[key], (int, float, np.integer, np.floating)):
+            raise FusionPicError(-1, "." + key + " <- Property does not match any given possible types!")
+
+
+def _np_dtype(code):
+    return np.float32 if code == F32 else np.float64
+
+
+def _code(arr):
+    return F32 if arr.dtype == np.float32 else F64
+
+
+def _as_float_array(a):
+    a = np.asarray(a)
+    if a.dtype != np.float32:
+        a = a.astype(np.float64, copy=False)  # JavaScript numbers are doubles
+    return np.ascontiguousarray(a)
+
+
+class CylindricalParticlePusher:
+    """Object returned by makeCylindricalParticlePusher (empic.js:1528)."""
+
+    def __init__(self, spec, precision="fp32", device=0, count=0, compat=True, sort_interval=0, library=None):
+        _validate_spec(spec)
+        self._lib = library or load_library()
+        self.spec = dict(spec)
+        s = Spec()
+        for key in _SPEC_KEYS:
+            setattr(s, key, spec[key])
+        s.count = int(count)
+        s.precision = {"fp32": F32, "fp64": F64}[precision]
+        s.device = int(device)
+        s.physical_a = 0 if compat else 1
+        s.sort_interval = int(sort_interval)
+        self.precision = s.precision
+        self.nr, self.nz = int(spec["nr"]), int(spec["nz"])
+        self.n = int(count) if count else int(spec["nparticles"]) ** 2
+        h = ctypes.c_void_p()
+        rc = self._lib.fpic_create(ctypes.byref(s), ctypes.byref(h))
+        if rc != 0:
+            raise FusionPicError(rc, self._lib.fpic_last_error(None).decode())
+        self._h = h
+
+    # ---- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise FusionPicError(rc, self._lib.fpic_last_error(self._h).decode())
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            self._lib.fpic_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # ---- reference surface
+    def set(self, value=None, **kw):
+        """out.set({E, B, position, velocity, sink_mask, source_pdf}) (empic.js:1157-1350)."""
+        value = dict(value or {}, **kw)
+        for key, which, ncomp in (("E", GRID_E, 3), ("B", GRID_B, 3)):
+            if value.get(key) is not None:
+                a = _as_float_array(value[key])
+                if a.shape != (self.nr, self.nz, 3):
+                    raise FusionPicError(-1, ".%s <- expected [%d][%d][3]" % (key, self.nr, self.nz))
+                self._check(self._lib.fpic_set_grid(self._h, which, a.ctypes.data, self.nr, self.nz, ncomp, _code(a)))
+        pos = value.get("position")
+        vel = value.get("velocity")
+        for key, arr in (("position", pos), ("velocity", vel)):
+            if arr is not None:
+                a = _as_float_array(arr)
+                if a.shape != (self.n, 3):
+                    raise FusionPicError(-1, ".%s <- expected [%d][3]" % (key, self.n))
+                p = a.ctypes.data if key == "position" else None
+                v = a.ctypes.data if key == "velocity" else None
+                self._check(self._lib.fpic_set_particles(self._h, p, v, self.n, _code(a)))
+        for key, which in (("sink_mask", GRID_SINK_MASK), ("source_pdf", GRID_SOURCE_PDF)):
+            if value.get(key) is not None:
+                a = _as_float_array(value[key])
+                if a.shape != (self.nr, self.nz):
+                    raise FusionPicError(-1, ".%s <- expected [%d][%d]" % (key, self.nr, self.nz))
+                self._check(self._lib.fpic_set_grid(self._h, which, a.ctypes.data, self.nr, self.nz, 1, _code(a)))
+
+    def addCurrentLoop(self, r, z, current):
+        self._check(self._lib.fpic_add_current_loop(self._h, r, z, current))
+
+    def addCurrentZ(self, current):
+        self._check(self._lib.fpic_add_current_z(self._h, current))
+
+    def addBZ(self, bz):
+        self._check(self._lib.fpic_add_bz(self._h, bz))
+
+    def addBTheta(self, btheta):
+        self._check(self._lib.fpic_add_btheta(self._h, btheta))
+
+    def addSpindleCuspPlasmaField(self, r, B_c, beta_c=None):
+        """The reference's version is unfinished and has no effect on B (empic.js:1369-1378,
+        spindle.js:328, :624, :643 use undefined symbols)."""
+        raise FusionPicError(-5, "addSpindleCuspPlasmaField is not functional in the reference (spindle.js:328)")
+
+    def precalc(self):
+        self._check(self._lib.fpic_precalc(self._h))
+
+    def step(self, ncalls=1):
+        """One call = two leap-frog sub-steps, dt fixed at construction (empic.js:1436-1469)."""
+        self._check(self._lib.fpic_step(self._h, int(ncalls)))
+
+    def density(self):
+        self._check(self._lib.fpic_density(self._h))
+
+    # ---- extensions the boundary needs because `canvas` cannot exist off-browser
+    def deposit(self):
+        self._check(self._lib.fpic_deposit(self._h))
+
+    def densityFinish(self):
+        self._check(self._lib.fpic_density_finish(self._h))
+
+    def setRandomState(self, entropy=None, rand=None):
+        e = r = None
+        if entropy is not None:
+            e = np.ascontiguousarray(entropy, dtype=np.float32).ravel()
+            if e.size != 4 * 1024 * 1024:
+                raise FusionPicError(-1, ".entropy <- expected 1024*1024*4 floats")
+        if rand is not None:
+            r = np.ascontiguousarray(rand, dtype=np.float32).ravel()
+            if r.size != 4 * self.n:
+                raise FusionPicError(-1, ".rand <- expected %d*4 floats" % self.n)
+        self._check(self._lib.fpic_set_random_state(self._h, e.ctypes.data if e is not None else None,
+                                                    r.ctypes.data if r is not None else None))
+
+    def readGrid(self, which, dtype=None):
+        code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
+        cells = 512 * 512 if which == READ_INV_CDF else self.nr * self.nz
+        out = np.empty(4 * cells, dtype=_np_dtype(code))
+        self._check(self._lib.fpic_read_grid(self._h, which, out.ctypes.data, code))
+        return out
+
+    def readDensity(self, dtype=None):
+        """moments01_avgA, channels (v_r, v_theta, v_z, n), index 4*(i + j*nr) (empic.js:1071)."""
+        return self.readGrid(READ_AVG, dtype)
+
+    def readMoments(self, dtype=None):
+        return self.readGrid(READ_MOMENTS, dtype)
+
+    def getParticles(self, dtype=None, position=True, velocity=True, rand=True, alive=True):
+        code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
+        dt = _np_dtype(code)
+        out = {}
+        if position:
+            out["position"] = np.empty((self.n, 3), dtype=dt)
+        if velocity:
+            out["velocity"] = np.empty((self.n, 3), dtype=dt)
+        if rand:
+            out["rand"] = np.empty((self.n, 4), dtype=np.float32)
+        if alive:
+            out["alive"] = np.empty(self.n, dtype=np.uint8)
+        ptr = lambda k: out[k].ctypes.data if k in out else None
+        self._check(self._lib.fpic_get_particles(self._h, ptr("position"), ptr("velocity"), ptr("rand"), ptr("alive"), code))
+        return out
+
+    def getCells(self):
+        out = np.empty(self.n, dtype=np.int32)
+        self._check(self._lib.fpic_get_cells(self._h, out.ctypes.data))
+        return out
+
+    def deviceBuffer(self, which=BUF_CELL_SUMS):
+        p, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._lib.fpic_device_buffer(self._h, which, ctypes.byref(p), ctypes.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def setStream(self, stream_ptr):
+        self._check(self._lib.fpic_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def sort(self):
+        self._check(self._lib.fpic_sort(self._h))
+
+    def sync(self):
+        self._check(self._lib.fpic_sync(self._h))
+
+    def profile(self, enable=True):
+        self._check(self._lib.fpic_profile(self._h, 1 if enable else 0))
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.fpic_get_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def resetStats(self):
+        self._check(self._lib.fpic_reset_stats(self._h))
+
+
+def makeCylindricalParticlePusher(spec, **extensions):
+    """empic.makeCylindricalParticlePusher(spec) (empic.js:30)."""
+    return CylindricalParticlePusher(spec, **extensions)

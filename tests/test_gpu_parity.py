@@ -1,0 +1,416 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libfusionpic.so), against
+the CPU oracle on identical seeded inputs, and against the golden fixtures captured
+from the reference's host JavaScript.
+
+Bar (BASELINE.json north_star): integer outputs (alive flags, cell indices,
+particle counts) bit-exact; float values within 1e-3 relative (fp32) / 1e-6 (fp64).
+The push is built so that fp32 results are in fact bit-identical to the oracle
+(-ffp-contract=off, correctly rounded sqrt and divide on both sides), and the tests
+assert that stronger property; the scatter is order-dependent float summation and is
+held to the stated tolerance.
+"""
+import numpy as np
+import pytest
+
+from helpers import frame_sink, load_f32gz, load_json, make_spec, same_bits, uniform_plasma
+
+pytestmark = pytest.mark.gpu
+
+RTOL32, RTOL64 = 1e-3, 1e-6
+
+
+@pytest.fixture(scope="module")
+def fp():
+    import fusionpic
+    return fusionpic
+
+
+@pytest.fixture(scope="module")
+def po():
+    import pic_oracle
+    return pic_oracle
+
+
+def random_fields(rng, nr, nz, bscale=0.5, escale=2e4):
+    B = rng.normal(0, bscale, size=(nr, nz, 3))
+    B[..., 2] += 1.0
+    E = rng.normal(0, escale, size=(nr, nz, 3))
+    return E, B
+
+
+def build_pair(fp, po, spec, precision, seed, n=None, with_E=True, pdf=None, physical_a=False, margin=0.0, v_th=1e-3,
+               sort_interval=0):
+    """Identical scene on the HIP library and on the oracle."""
+    dtype = np.float32 if precision == "fp32" else np.float64
+    n = n or spec["nparticles"] ** 2
+    rng = np.random.default_rng(seed)
+    nr, nz = spec["nr"], spec["nz"]
+    E, B = random_fields(rng, nr, nz)
+    if not with_E:
+        E = np.zeros_like(E)
+    sink = frame_sink(nr, nz)
+    if pdf is None:
+        pdf = sink.copy()
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=seed + 1, v_th=v_th, margin=margin)
+    sim = fp.makeCylindricalParticlePusher(spec, precision=precision, compat=not physical_a, sort_interval=sort_interval)
+    ora = po.OracleSim(spec, dtype=dtype, physical_a=physical_a)
+    for s in (sim, ora):
+        s.set(E=E, B=B, position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
+    sim.setRandomState(entropy, rand)
+    ora.set_random_state(entropy, rand)
+    sim.precalc()
+    ora.precalc()
+    return sim, ora
+
+
+def assert_particles_equal(sim, ora, exact=True, rtol=0.0):
+    got = sim.getParticles()
+    want_pos, want_vel = ora.positions(), ora.velocities()
+    # integer outputs: always bit-exact
+    assert np.array_equal(got["alive"], ora.alive()), "alive flags differ"
+    assert np.array_equal(sim.getCells(), ora.cells()), "NGP cell indices differ"
+    if exact:
+        assert same_bits(got["position"], want_pos)
+        assert same_bits(got["velocity"], want_vel)
+        assert same_bits(got["rand"], ora.rand().astype(np.float32))
+    else:
+        np.testing.assert_allclose(got["position"], want_pos, rtol=rtol, atol=rtol * 1e-3)
+        np.testing.assert_allclose(got["velocity"], want_vel, rtol=rtol, atol=rtol * 1e-6)
+
+
+# ----------------------------------------------------------------------------- host side vs golden
+
+def test_library_reports_gfx950(fp):
+    lib = fp.load_library()
+    assert lib.fpic_build_arch() == b"gfx950"
+    assert lib.fpic_abi_version() == 1
+
+
+def test_upload_matches_reference_host_js(fp):
+    """set({position, velocity, E, B, sink_mask}) reproduces the Float32Arrays the
+    reference's own set() builds (tests/golden/upload_squat.json)."""
+    u = load_json("upload_squat.json")
+    sim = fp.makeCylindricalParticlePusher(u["spec"])
+    sim.set(position=u["position_in"], velocity=u["velocity_in"], E=u["E_in"], B=u["B_in"], sink_mask=u["sink_in"])
+    got = sim.getParticles()
+    n = sim.n
+    want_p = np.array(u["position_arr"], dtype=np.float32).reshape(n, 4)
+    want_v = np.array(u["velocity_arr"], dtype=np.float32).reshape(n, 4)
+    assert same_bits(got["position"], want_p[:, :3])
+    assert same_bits(got["velocity"], want_v[:, :3])
+    assert np.array_equal(got["alive"], (want_p[:, 3] > 0.5).astype(np.uint8))
+    assert same_bits(sim.readGrid(fp.READ_E), np.array(u["E_arr"], dtype=np.float32))
+    assert same_bits(sim.readGrid(fp.READ_B), np.array(u["B_arr"], dtype=np.float32))
+    assert same_bits(sim.readGrid(fp.READ_SINK), np.array(u["sink_mask_arr"], dtype=np.float32))
+
+
+@pytest.mark.parametrize("name", ["block", "ragged", "interior", "squat_random"])
+def test_inverse_cdf_matches_reference_host_js(fp, name):
+    j = load_json("inv_cdf_%s.json" % name)
+    want = load_f32gz(j["file"])
+    spec = make_spec(j["nr"], j["nz"], 2)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    sim.set(source_pdf=np.array(j["pdf"]))
+    got = sim.readGrid(fp.READ_INV_CDF)
+    assert same_bits(got, want)
+    assert int(np.isnan(got).sum()) == int(np.isnan(want).sum())
+
+
+def test_source_pdf_with_empty_first_row_throws(fp):
+    j = load_json("inv_cdf_throws.json")
+    assert j["threw"] == "TypeError"
+    sim = fp.makeCylindricalParticlePusher(make_spec(4, 4, 2))
+    with pytest.raises(fp.FusionPicError):
+        sim.set(source_pdf=np.array(j["pdf"], dtype=float))
+
+
+def test_spec_validation_messages(fp):
+    v = load_json("validation.json")
+    good = make_spec(4, 4, 2)
+    bad = dict(good); del bad["radius"]
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(bad)
+    assert str(e.value) == v["missing_radius"]
+    bad = dict(good, nr="4")
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(bad)
+    assert str(e.value) == v["string_nr"]
+
+
+# ----------------------------------------------------------------------------- precalc (K8, K9)
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("physical_a", [False, True])
+def test_precalc_parity(fp, po, precision, physical_a):
+    spec = make_spec(48, 40, 4, radius=0.35, height=0.2)
+    sim, ora = build_pair(fp, po, spec, precision, seed=11, physical_a=physical_a)
+    for which, want in ((fp.READ_R1, ora.R1), (fp.READ_R2, ora.R2), (fp.READ_R3, ora.R3), (fp.READ_A, ora.A)):
+        got = sim.readGrid(which)
+        assert same_bits(got, want), "grid %d differs" % which
+
+
+def test_precalc_quirk_q1_is_visible(fp, po):
+    """With E.B != 0 the reference formula (scalar added to a vector) and the physical
+    one differ; both must match their oracle twin and differ from each other."""
+    spec = make_spec(16, 16, 2)
+    a, _ = build_pair(fp, po, spec, "fp32", seed=5, physical_a=False)
+    b, _ = build_pair(fp, po, spec, "fp32", seed=5, physical_a=True)
+    assert not np.array_equal(a.readGrid(fp.READ_A), b.readGrid(fp.READ_A))
+    assert np.array_equal(a.readGrid(fp.READ_R1), b.readGrid(fp.READ_R1))
+
+
+# ----------------------------------------------------------------------------- push (K1, K2, K3)
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_step_parity_bit_exact(fp, po, precision):
+    """Several step() calls (two sub-steps each) on 40k particles in a non-uniform
+    E,B scene with a sink frame: every particle's state agrees with the oracle bit
+    for bit, so alive flags and cell indices are exact by construction."""
+    spec = make_spec(64, 48, 200, radius=1.0, height=2.0)
+    sim, ora = build_pair(fp, po, spec, precision, seed=21)
+    for calls in (1, 1, 3):
+        sim.step(calls)
+        ora.step(calls)
+        assert_particles_equal(sim, ora, exact=True)
+
+
+def test_step_ragged_count_and_tail_lanes(fp, po):
+    """Counts that are not a multiple of the 4-particle vector width (tail lanes) and a
+    single particle."""
+    for n in (1, 3, 1021, 4099):
+        spec = make_spec(32, 32, 1)
+        dtype = np.float32
+        rng = np.random.default_rng(n)
+        E, B = random_fields(rng, 32, 32)
+        pos, vel, entropy, rand = uniform_plasma(n, spec, seed=n)
+        sim = fp.makeCylindricalParticlePusher(spec, count=n)
+        ora = po.OracleSim(spec, dtype=dtype, count=n)
+        for s in (sim, ora):
+            s.set(E=E, B=B, position=pos, velocity=vel, sink_mask=frame_sink(32, 32), source_pdf=frame_sink(32, 32))
+        sim.setRandomState(entropy, rand); ora.set_random_state(entropy, rand)
+        sim.precalc(); ora.precalc()
+        sim.step(2); ora.step(2)
+        assert_particles_equal(sim, ora)
+
+
+def test_step_heavy_reinjection(fp, po):
+    """Fast particles in a small box: most particles hit the sink frame and are
+    re-injected through the inverse-CDF table several times (K2 else-branch, K1
+    re-seed branch, quirk Q4), including table sites that hold NaN (quirk Q3)."""
+    spec = make_spec(24, 16, 100, radius=0.35, height=0.2)
+    j = load_json("inv_cdf_ragged.json")
+    pdf = np.zeros((24, 16))
+    pdf[:16, :12] = np.array(j["pdf"])
+    pdf[0, 1:] += 0.5  # first row must carry weight or the reference throws
+    sim, ora = build_pair(fp, po, spec, "fp32", seed=31, pdf=pdf, v_th=0.05)
+    total_dead = 0
+    for _ in range(6):
+        sim.step(); ora.step()
+        assert_particles_equal(sim, ora)
+        total_dead += int((ora.alive() == 0).sum())
+    assert total_dead > 1000, "scene did not exercise re-injection"
+    got = sim.getParticles()
+    assert np.array_equal(np.isnan(got["position"]), np.isnan(ora.positions()))
+
+
+def test_step_before_precalc_uses_zero_coefficients(fp, po):
+    """Null textures start at 0 (utilities.js:533-539): step() before precalc() gives v' = 0."""
+    spec = make_spec(16, 16, 10)
+    pos, vel, entropy, rand = uniform_plasma(100, spec, seed=3, margin=0.1)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    ora = po.OracleSim(spec)
+    for s in (sim, ora):
+        s.set(position=pos, velocity=vel, sink_mask=np.ones((16, 16)), source_pdf=np.ones((16, 16)))
+    sim.setRandomState(entropy, rand); ora.set_random_state(entropy, rand)
+    sim.step(); ora.step()
+    assert_particles_equal(sim, ora)
+    assert np.all(sim.getParticles()["velocity"] == 0)
+
+
+def test_gyration_phase_advance(fp):
+    """Analytic anchor (the per-fragment arithmetic is not pinned by the reference):
+    in uniform Bz with E = 0 the Boris map rotates v by 2*atan(h*|B|) per sub-step and
+    conserves |v|."""
+    spec = make_spec(32, 32, 1, radius=1.0, height=1.0)
+    sim = fp.makeCylindricalParticlePusher(spec, precision="fp64", count=1)
+    Bz = 0.8
+    B = np.zeros((32, 32, 3)); B[..., 2] = Bz
+    sim.set(B=B, position=[[0.4, 0.3, 0.5]], velocity=[[1e-4, 2e-4, 0.0]], sink_mask=np.ones((32, 32)),
+            source_pdf=np.ones((32, 32)))
+    sim.precalc()
+    h = spec["particle_charge"] * spec["dt"] / (2 * spec["particle_mass"])
+    v0 = sim.getParticles()["velocity"][0].copy()
+    sim.step()
+    v1 = sim.getParticles()["velocity"][0]
+    ang = lambda v: np.arctan2(v[1], v[0])
+    # two sub-steps; the rotation is expressed in the local (r, theta) frame of each sub-step
+    dphi = (ang(v1) - ang(v0) + np.pi) % (2 * np.pi) - np.pi
+    assert abs(abs(dphi) - 2 * 2 * np.arctan(h * Bz)) < 1e-3 * abs(dphi)
+    assert abs(np.hypot(*v1[:2]) - np.hypot(*v0[:2])) < 1e-12
+
+
+# ----------------------------------------------------------------------------- scatter + normalise + EMA (K4-K7)
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_density_parity(fp, po, precision):
+    """density() after step(), three frames (the EMA of K6 needs history).  The oracle
+    of the SAME precision is the comparator: cell indices are then computed from
+    identical bits on both sides, and the only difference left is the order of the
+    float additions (the reference's blending order is itself undefined)."""
+    rtol = RTOL32 if precision == "fp32" else RTOL64
+    spec = make_spec(96, 80, 300, radius=1.0, height=2.0)
+    sim, ora = build_pair(fp, po, spec, precision, seed=41)
+    for k in range(3):
+        sim.step(); ora.step()
+        sim.density(); ora.density()
+        assert_particles_equal(sim, ora)
+        for which, want in ((fp.READ_MOMENTS, ora.moments), (fp.READ_NORM, ora.norm), (fp.READ_AVG, ora.avg_A)):
+            got = sim.readGrid(which, np.float64).reshape(-1, 4)
+            want = want.astype(np.float64).reshape(-1, 4)
+            # count channel: all-positive sums -> plain relative tolerance
+            np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=rtol, atol=0)
+            # velocity channels cancel: tolerance relative to the channel's scale
+            for c in range(3):
+                scale = np.abs(want[:, c]).max()
+                assert np.abs(got[:, c] - want[:, c]).max() <= rtol * scale, (which, c)
+            assert np.array_equal(got[:, 3] > 0, want[:, 3] > 0), "set of touched cells differs"
+
+
+def test_density_single_particle_is_the_stamp(fp, po):
+    """One particle: moments01 is exactly 0.001*(vr,vt,vz,1) x stamp around its cell,
+    cropped at the grid edge."""
+    spec = make_spec(20, 20, 1)
+    stamp = np.array(load_json("stamp.json")["red"], dtype=np.float32).reshape(11, 11)
+    for (x, y, z) in ((0.52, 0.1, 0.47), (0.03, 0.02, 0.98), (0.97, 0.05, 0.01)):
+        sim = fp.makeCylindricalParticlePusher(spec, count=1)
+        ora = po.OracleSim(spec, count=1)
+        for s in (sim, ora):
+            s.set(position=[[x, y, z]], velocity=[[3e-4, -2e-4, 5e-4]])
+        sim.density(); ora.density()
+        got = sim.readMoments()
+        np.testing.assert_allclose(got, ora.moments, rtol=1e-6, atol=1e-12)
+        r = np.hypot(np.float32(x), np.float32(y))
+        ic, jc = int(r * 20), int(np.float32(z) * 20)
+        m = got.reshape(20, 20, 4)  # [j][i][c]
+        for dj in range(-5, 6):
+            for di in range(-5, 6):
+                i, j = ic + di, jc + dj
+                if 0 <= i < 20 and 0 <= j < 20:
+                    assert abs(m[j, i, 3] - np.float32(0.001) * stamp[5 - dj, di + 5]) < 1e-9
+
+
+def test_density_clipping_and_edges(fp, po):
+    """Points outside the clip volume (r > 1, z outside [0,1]) and NaN positions deposit
+    nothing; points on r = 1 exactly land on column nr and are cropped."""
+    spec = make_spec(16, 16, 1)
+    pos = np.array([[1.2, 0.0, 0.5], [0.5, 0.0, 1.5], [0.5, 0.0, -0.1], [1.0, 0.0, 0.5], [0.3, 0.4, 1.0],
+                    [0.25, 0.0, 0.25], [0.0, 1.0, 0.999]])
+    vel = np.full((7, 3), 1e-4)
+    sim = fp.makeCylindricalParticlePusher(spec, count=7)
+    ora = po.OracleSim(spec, count=7)
+    for s in (sim, ora):
+        s.set(position=pos, velocity=vel)
+    sim.density(); ora.density()
+    np.testing.assert_allclose(sim.readMoments(), ora.moments, rtol=1e-6, atol=1e-12)
+    assert ora.moments.reshape(-1, 4)[:, 3].sum() > 0
+
+
+def test_density_without_binning_and_after_drift(fp, po):
+    """Correctness never depends on the binning: force one binning, then push many
+    steps with binning disabled (sort_interval huge) so that most particles have left
+    their tile's LDS halo and take the global-atomic path."""
+    spec = make_spec(128, 128, 200)
+    sim, ora = build_pair(fp, po, spec, "fp32", seed=51, v_th=4e-3, sort_interval=1 << 30)
+    sim.density(); ora.density()
+    sim.step(20); ora.step(20)
+    sim.density(); ora.density()
+    assert_particles_equal(sim, ora)
+    st = sim.stats()
+    assert st["sort_passes"] == 1
+    assert st["deposit_spilled"] > 0
+    got = sim.readMoments(np.float64).reshape(-1, 4)
+    want = ora.moments.astype(np.float64).reshape(-1, 4)
+    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=RTOL32)
+
+
+def test_binning_preserves_particles_and_order_of_readback(fp, po):
+    spec = make_spec(64, 64, 150)
+    sim, ora = build_pair(fp, po, spec, "fp32", seed=61)
+    before = sim.getParticles()
+    sim.sort()
+    after = sim.getParticles()
+    for k in before:
+        assert same_bits(before[k], after[k])
+    sim.step(); ora.step()
+    sim.sort()
+    sim.step(); ora.step()
+    assert_particles_equal(sim, ora)
+    # uploads after a binning address the caller's particle i, not slot i
+    pos, vel, entropy, rand = uniform_plasma(sim.n, spec, seed=99)
+    sim.set(velocity=vel); ora.set(velocity=vel)
+    sim.setRandomState(rand=rand); ora.set_random_state(rand=rand)
+    sim.step(); ora.step()
+    assert_particles_equal(sim, ora)
+
+
+# ----------------------------------------------------------------------------- painters (K10-K12)
+
+def test_uniform_painters_match_oracle(fp, po):
+    spec = make_spec(40, 24, 2, radius=0.35, height=0.2)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    ora = po.OracleSim(spec)
+    for s, names in ((sim, ("addBZ", "addBTheta", "addCurrentZ")), (ora, ("add_bz", "add_btheta", "add_current_z"))):
+        getattr(s, names[0])(0.25)
+        getattr(s, names[1])(-0.125)
+        getattr(s, names[2])(2e5)
+    assert same_bits(sim.readGrid(fp.READ_B), ora.B)
+
+
+def test_current_loop_matches_oracle(fp, po):
+    """K10/K11 call cos() 1000 times per cell; libm and the device differ in the last
+    ulp, so this is a tolerance test."""
+    spec = make_spec(40, 80, 2, radius=1.0, height=2.0)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    ora = po.OracleSim(spec)
+    sim.addCurrentLoop(0.8, 2.0, -1e7); ora.add_current_loop(0.8, 2.0, -1e7)
+    sim.addCurrentLoop(0.8, 0.0, 1e7); ora.add_current_loop(0.8, 0.0, 1e7)
+    got, want = sim.readGrid(fp.READ_B), ora.B
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-5 * scale
+
+
+# ----------------------------------------------------------------------------- size-independent properties
+
+def test_large_run_properties(fp):
+    """4e6 particles on 512x512 (too slow for the serial oracle): particle count is
+    constant, the count channel of the cell sums equals 0.001 x (points inside the clip
+    volume), moments01's count channel sums to the same (stamp is normalised) away
+    from the edges, and the deposit is linear in the velocities."""
+    spec = make_spec(512, 512, 2000)
+    n = 2000 * 2000
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=7, margin=0.02)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    B = np.zeros((512, 512, 3)); B[..., 2] = 0.01
+    sim.set(B=B, position=pos, velocity=vel, sink_mask=frame_sink(512, 512), source_pdf=frame_sink(512, 512))
+    sim.setRandomState(entropy, rand)
+    sim.precalc()
+    for _ in range(3):
+        sim.step(); sim.density()
+    got = sim.getParticles()
+    assert got["position"].shape == (n, 3)
+    assert np.isfinite(got["position"]).all()
+    r = np.hypot(got["position"][:, 0], got["position"][:, 1])
+    z = got["position"][:, 2]
+    inside = int(((r <= 1) & (z >= 0) & (z <= 1)).sum())
+    m = sim.readMoments(np.float64).reshape(512, 512, 4)
+    interior = (r < 1 - 6 / 512) & (z > 6 / 512) & (z < 1 - 6 / 512)
+    assert interior.sum() == inside, "synthetic scene keeps every particle clear of the crop region"
+    assert abs(m[..., 3].sum() - 0.001 * inside) <= 1e-4 * 0.001 * inside
+    # linearity: doubling every velocity doubles the velocity moments, leaves counts
+    m1 = m.copy()
+    sim.set(velocity=2 * got["velocity"].astype(np.float64) * np.array([spec["radius"], spec["radius"], spec["height"]]))
+    sim.density()
+    m2 = sim.readMoments(np.float64).reshape(512, 512, 4)
+    np.testing.assert_allclose(m2[..., 3], m1[..., 3], rtol=1e-5)
+    scale = np.abs(m1[..., :3]).max()
+    assert np.abs(m2[..., :3] - 2 * m1[..., :3]).max() <= 1e-3 * scale
