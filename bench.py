@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — particle-updates/s of the push + deposit + solve cycle on MI355X.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): axisymmetric (r,z) grid 1024 x 1024, 1e8 particles
+per GPU, fp32, single species, synthetic uniform plasma: uniform in the
+cylinder's volume, Maxwellian v_th = 1e-3 c, uniform Bz = 0.01 T, E = 0, sink frame,
+uniform interior source, dt = 2e-9 s, proton m/q; entropy table and per-particle
+random state injected from numpy's Philox generator, seed 0x5EEDF051.
+
+One "step" = one frame of the reference's loop (fusionsim.js:170-178) plus the
+field->coefficient stage: precalc() [solve stage, K8/K9], step() [two leap-frog
+sub-steps = two particle-updates per particle, K3/K1/K2], density() [scatter K4,
+normalise K5, EMA K6/K7].  value = 2 * N_particles_total * K / seconds.
+
+Multi-GPU (reference-parity mode): particles are sharded by index range,
+the grid tables are replicated, and the only exchange is one all-reduce (RCCL) of the
+per-cell sums between the scatter and the stamp/normalise/EMA stage.  Per-GPU work is
+fixed as N grows ("weak").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fusion-sim_amd"))
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0           # same guide: measured float4 copy
+ALGO_BYTES_PER_UPDATE = 48      # push, SoA fp32: read 6 + write 6 scalars
+
+
+def synthetic_inputs(n, spec, seed):
+    """SURVEY.md 8(d) uniform plasma, float32 host arrays (physical units)."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    pos = np.empty((n, 3), dtype=np.float32)
+    vel = np.empty((n, 3), dtype=np.float32)
+    chunk = 1 << 24
+    for b in range(0, n, chunk):
+        m = min(chunk, n - b)
+        rh = np.maximum(np.sqrt(rng.random(m, dtype=np.float32)), np.float32(1e-6))
+        th = np.float32(2 * np.pi) * rng.random(m, dtype=np.float32)
+        pos[b:b + m, 0] = rh * np.cos(th) * np.float32(spec["radius"])
+        pos[b:b + m, 1] = rh * np.sin(th) * np.float32(spec["radius"])
+        pos[b:b + m, 2] = rng.random(m, dtype=np.float32) * np.float32(spec["height"])
+        vel[b:b + m] = rng.standard_normal((m, 3), dtype=np.float32) * np.float32(1e-3)
+    entropy = rng.random(1024 * 1024 * 4, dtype=np.float32)
+    rand = rng.random((n, 4), dtype=np.float32)
+    return pos, vel, entropy, rand
+
+
+def scene_grids(nr, nz):
+    sink = np.ones((nr, nz), dtype=np.float32)  # fusionsim.js:94-112
+    sink[nr - 1, :] = 0
+    sink[1:nr - 1, 0] = 0
+    sink[1:nr - 1, nz - 1] = 0
+    return sink, sink.copy()
+
+
+def cpu_baseline(spec, seconds_target=12.0):
+    """The build's CPU restatement of the reference shaders (oracle/, kind "port"),
+    one thread, on a bounded sample of the same workload: same grid, 1e6 particles."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pic_oracle as po
+    side = 1000
+    s = dict(spec, nparticles=side)
+    n = side * side
+    pos, vel, entropy, rand = synthetic_inputs(n, s, 0x5EEDF051)
+    sink, pdf = scene_grids(s["nr"], s["nz"])
+    sim = po.OracleSim(s, dtype=np.float32)
+    sim.set(position=pos.astype(np.float64), velocity=vel.astype(np.float64), sink_mask=sink, source_pdf=pdf)
+    sim.set_random_state(entropy, rand)
+    sim.add_bz(0.01)
+    cycles = 0
+    t0 = time.perf_counter()
+    while True:
+        sim.precalc(); sim.step(); sim.density()
+        cycles += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or cycles >= 200:
+            break
+    return {
+        "value": 2.0 * n * cycles / dt, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+        "sample": "oracle/pic_oracle.c (CPU restatement of the reference's GLSL, the reference has no CPU path), "
+                  "fp32, 1 thread, grid %dx%d, %d particles, %d cycles of precalc+step+density in %.1f s; host has %d cores"
+                  % (s["nr"], s["nz"], n, cycles, dt, os.cpu_count() or 0),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--side", type=int, default=10000, help="particle texture side per GPU (count = side^2)")
+    ap.add_argument("--grid", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import fusionpic as fp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world:
+        if distributed or args.gpus != 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    spec = dict(radius=1.0, height=1.0, nr=args.grid, nz=args.grid, dt=2e-9, nparticles=args.side,
+                particle_mass=1.67e-27, particle_charge=1.602e-19)
+    n_local = args.side * args.side
+    # every rank draws its own shard of the global particle population
+    pos, vel, entropy, rand = synthetic_inputs(n_local, spec, 0x5EEDF051 + 7919 * rank)
+    if distributed:  # replicated tables must be identical on every rank
+        _, _, entropy, _ = synthetic_inputs(1, spec, 0x5EEDF051)
+    sink, pdf = scene_grids(spec["nr"], spec["nz"])
+
+    sim = fp.makeCylindricalParticlePusher(spec, device=local_rank)
+    stream = torch.cuda.Stream(device=local_rank)
+    sim.setStream(stream.cuda_stream)
+    sim.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
+    sim.setRandomState(entropy, rand)
+    del pos, vel, rand
+    sim.addBZ(0.01)
+    sim.precalc()
+
+    sums = None
+    if distributed:
+        ptr, nbytes = sim.deviceBuffer()
+
+        class _Buf:  # raw device pointer -> tensor view, no copy
+            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 3}
+        sums = torch.as_tensor(_Buf(), device=torch.device("cuda", local_rank))
+
+    def cycle():
+        sim.precalc()
+        sim.step()
+        if distributed:
+            sim.deposit()
+            with torch.cuda.stream(stream):
+                dist.all_reduce(sums)
+            sim.densityFinish()
+        else:
+            sim.density()
+
+    def fence():
+        sim.sync()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        cycle()
+    fence()
+    sim.resetStats()
+    sim.profile(True)  # HIP events on the launch stream, read after the timed region
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cycle()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = sim.stats()
+    sim.profile(False)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_total = n_local * world
+        updates = 2.0 * n_total * args.steps
+        push_ms = st["ms_push"] / max(1, st["step_launches"])
+        achieved = ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (push_ms * 1e-3) / 1e9 if push_ms > 0 else 0.0
+        out = {
+            "metric": "particle-updates/sec (push+deposit+solve)",
+            "value": updates / elapsed,
+            "unit": "particle-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "2D axisymmetric (r,z) %dx%d grid, %.0e particles per GPU, single species, reference stamp "
+                            "(11x11) deposit, uniform Bz=0.01 T, one step = precalc()+step()[2 sub-steps]+density()"
+                            % (spec["nr"], spec["nz"], n_local),
+                "particles_per_gpu": n_local, "grid": [spec["nr"], spec["nz"]],
+                "parallelism": "particle shards x%d, replicated grid, all-reduce of cell sums" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "push_kernel<float> (step(): K3+K1+K2, two sub-steps fused)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UPDATE * 2.0 * n_local,
+                "avg_launch_ms": push_ms,
+                "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
+            },
+            "kernel_ms_per_step": {
+                "push": st["ms_push"] / args.steps, "cell_sums": st["ms_deposit"] / args.steps,
+                "stamp_normalise_ema": st["ms_stamp"] / args.steps, "precalc": st["ms_precalc"] / args.steps,
+                "binning": st["ms_sort"] / args.steps, "binning_passes": st["sort_passes"],
+                "last_spilled": st["deposit_spilled"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    sim.destroy()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

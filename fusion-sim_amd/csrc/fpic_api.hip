@@ -78,10 +78,13 @@ struct fpic_handle {
     size_t work_cap = 0;
     bool binned = false;
     int deposits_since_bin = 0;
+    // Particles that missed their LDS tile in a scatter, read back with a lag of two
+    // scatters so that the host may run ahead of the GPU by at most two frames.
     unsigned long long* spilled = nullptr;      // device counter
-    unsigned long long* spilled_host = nullptr; // pinned
-    hipEvent_t spill_event = nullptr;
-    bool spill_pending = false;
+    unsigned long long* spilled_host = nullptr; // pinned, kSpillSlots entries
+    hipEvent_t spill_event[2] = {};
+    bool spill_pending[2] = {};
+    unsigned long long deposit_seq = 0;
     unsigned long long last_spill = 0;
 
     // statistics
@@ -362,7 +365,7 @@ int launch_bin(fpic_handle* h)
     h->binned = true;
     h->deposits_since_bin = 0;
     h->last_spill = 0;
-    h->spill_pending = false;
+    h->spill_pending[0] = h->spill_pending[1] = false; // counts taken before this binning say nothing now
     h->sort_passes++;
     return FPIC_OK;
 }
@@ -378,9 +381,10 @@ int launch_cell_sums(fpic_handle* h)
         arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work, h->nwork, static_cast<T*>(h->cell_sums), h->spilled);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(h->spilled_host, h->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipEventRecord(h->spill_event, h->stream));
-    h->spill_pending = true;
+    const int slot = static_cast<int>(h->deposit_seq++ & 1);
+    HIP_TRY(h, hipMemcpyAsync(h->spilled_host + slot, h->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->spill_event[slot], h->stream));
+    h->spill_pending[slot] = true;
     return FPIC_OK;
 }
 
@@ -539,7 +543,7 @@ void release(fpic_handle* h)
                      h->tile_cursor, h->nwork, h->work, h->spilled };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->spilled_host) (void)hipHostFree(h->spilled_host);
-    if (h->spill_event) (void)hipEventDestroy(h->spill_event);
+    for (hipEvent_t e : h->spill_event) if (e) (void)hipEventDestroy(e);
     for (PendingTiming& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -632,11 +636,12 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work), sizeof(BlockWork) * h->work_cap, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->spilled), sizeof(unsigned long long), acc)))
         return bail(rc);
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->spilled_host), sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&h->spill_event, hipEventDisableTiming)) != hipSuccess ||
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->spilled_host), 2 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->spill_event[0], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->spill_event[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipStreamSynchronize(h->stream)) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "handle setup failed: %s", hipGetErrorString(e)));
-    *h->spilled_host = 0;
+    h->spilled_host[0] = h->spilled_host[1] = 0;
     *out = h;
     return FPIC_OK;
 }
@@ -782,11 +787,16 @@ int fpic_deposit(fpic_handle* h)
         if (h->spec.sort_interval > 0) {
             rebin = h->deposits_since_bin >= h->spec.sort_interval;
         } else {
-            if (h->spill_pending && hipEventQuery(h->spill_event) == hipSuccess) {
-                h->last_spill = *h->spilled_host;
-                h->spill_pending = false;
+            // adaptive: the slot about to be reused holds the count of the scatter two
+            // frames back; waiting for it bounds the host's lead, it does not drain the GPU
+            const int slot = static_cast<int>(h->deposit_seq & 1);
+            if (h->spill_pending[slot]) {
+                HIP_TRY(h, hipEventSynchronize(h->spill_event[slot]));
+                h->last_spill = h->spilled_host[slot];
+                h->spill_pending[slot] = false;
             }
-            rebin = h->last_spill * 50 > h->n; // more than 2 % of the particles missed their LDS tile
+            // the count roughly doubles per frame: 0.4 % two frames ago is about 2 % now
+            rebin = h->last_spill * 256 > h->n;
         }
     }
     if (rebin)
@@ -894,7 +904,10 @@ int fpic_get_stats(fpic_handle* h, fpic_stats* out)
     if (!out) return fail(h, FPIC_ERR_INVALID_ARG, ".out <- Non-optional property is undefined!");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     timing_collect(h);
-    if (h->spill_pending) { h->last_spill = *h->spilled_host; h->spill_pending = false; }
+    if (h->deposit_seq) { // stream is idle: the newest count is there
+        const int newest = static_cast<int>((h->deposit_seq - 1) & 1);
+        if (h->spill_pending[newest]) h->last_spill = h->spilled_host[newest];
+    }
     std::memset(out, 0, sizeof *out);
     out->n_particles = h->n;
     out->particle_updates = h->particle_updates;

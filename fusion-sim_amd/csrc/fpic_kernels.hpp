@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(ParticleArrays<T> p, siz
 }
 
 // Exclusive scan of the tile counts, reset of the cursors, and the scatter's work
-// list: each real tile is cut into chunks of kDepositChunk particles.  One workgroup.
+// list: each bin is cut into chunks of kDepositChunk particles.  One workgroup.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t ntiles,
                                                         uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                         BlockWork* __restrict__ work, uint32_t* __restrict__ nwork)
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restri
     for (uint32_t t = t0; t < t0 + per && t < ntiles; ++t) {
         const uint32_t c = tile_count[t];
         sp += c;
-        if (t + 1 < ntiles) sb += (c + kDepositChunk - 1) / kDepositChunk; // the last bin holds clipped particles
+        sb += (c + kDepositChunk - 1) / kDepositChunk;
     }
     part_p[threadIdx.x] = sp;
     part_b[threadIdx.x] = sb;
@@ -740,15 +740,16 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restri
         const uint32_t c = tile_count[t];
         tile_start[t] = run_p;
         tile_cursor[t] = 0;
-        if (t + 1 < ntiles) {
-            for (uint32_t b = 0; b * kDepositChunk < c; ++b) {
-                BlockWork w;
-                w.tile = t;
-                w.begin = run_p + b * kDepositChunk;
-                w.end = run_p + ((b + 1) * kDepositChunk < c ? (b + 1) * kDepositChunk : c);
-                w.pad = 0;
-                work[run_b++] = w;
-            }
+        // The last bin holds the particles that were clipped when binned.  They are
+        // scanned too (re-injection can bring them back before the next binning); their
+        // LDS window is tile 0's, whatever lands elsewhere takes the global path.
+        for (uint32_t b = 0; b * kDepositChunk < c; ++b) {
+            BlockWork w;
+            w.tile = (t + 1 < ntiles) ? t : 0;
+            w.begin = run_p + b * kDepositChunk;
+            w.end = run_p + ((b + 1) * kDepositChunk < c ? (b + 1) * kDepositChunk : c);
+            w.pad = 0;
+            work[run_b++] = w;
         }
         run_p += c;
     }
