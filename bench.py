@@ -139,22 +139,18 @@ def main():
     sim.addBZ(0.01)
     sim.precalc()
 
-    sums = None
+    sharded = None
     if distributed:
+        from fusionpic.multi import ShardedPusher, device_tensor_view
         ptr, nbytes = sim.deviceBuffer()
-
-        class _Buf:  # raw device pointer -> tensor view, no copy
-            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 3}
-        sums = torch.as_tensor(_Buf(), device=torch.device("cuda", local_rank))
+        sums = device_tensor_view(ptr, nbytes, torch.device("cuda", local_rank))
+        sharded = ShardedPusher(sim, sums, stream=stream)  # density() = scatter, RCCL all-reduce, finish
 
     def cycle():
         sim.precalc()
         sim.step()
         if distributed:
-            sim.deposit()
-            with torch.cuda.stream(stream):
-                dist.all_reduce(sums)
-            sim.densityFinish()
+            sharded.density()
         else:
             sim.density()
 

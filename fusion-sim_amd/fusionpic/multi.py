@@ -1,0 +1,59 @@
+"""Multi-GPU host logic for the reference-parity mode.
+
+The reference never feeds the deposit back into the fields (empic.js:1471-1505 only
+draws it), so particles are independent units: each rank owns a contiguous index
+range of the particle population, the grid tables (E, B, sink, inverse CDF,
+entropy) are replicated, and the single exchange per frame is an all-reduce (sum) of
+the per-cell sums between the scatter and the stamp / normalise / EMA stage.  One
+process per GPU; on GPUs the collective is RCCL through torch.distributed's "nccl"
+backend, on CPU test ranks it is "gloo".  There is no other data-path collective.
+"""
+
+
+def shard_bounds(n_total, rank, world):
+    """Contiguous [begin, end) of particle indices owned by `rank`; sizes differ by at most 1."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("rank %r outside world of %r" % (rank, world))
+    base, rem = divmod(int(n_total), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def device_tensor_view(ptr, nbytes, device, dtype="f4"):
+    """Zero-copy torch view of a raw device allocation (fpic_device_buffer)."""
+    import torch
+    item = 4 if dtype == "f4" else 8
+
+    class _Buf:
+        __cuda_array_interface__ = {"shape": (nbytes // item,), "typestr": "<" + dtype, "data": (int(ptr), False), "version": 3}
+
+    return torch.as_tensor(_Buf(), device=device)
+
+
+class ShardedPusher:
+    """One rank's pusher plus the frame's only exchange.
+
+    `sim` offers precalc(), step(n), deposit(), densityFinish(); `sums` is a tensor that
+    aliases sim's per-cell sums (a device view on GPU ranks, a CPU tensor in tests).
+    """
+
+    def __init__(self, sim, sums, group=None, stream=None):
+        self.sim, self.sums, self.group, self.stream = sim, sums, group, stream
+
+    def precalc(self):
+        self.sim.precalc()
+
+    def step(self, ncalls=1):
+        self.sim.step(ncalls)
+
+    def density(self):
+        import torch.distributed as dist
+        self.sim.deposit()
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if self.stream is not None:
+                import torch
+                with torch.cuda.stream(self.stream):
+                    dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
+        self.sim.densityFinish()

@@ -1,0 +1,175 @@
+/*
+ * empic_native.js — drop-in for the reference's `empic` module on MI355X.
+ *
+ *   const empic = require('./empic_native.js');
+ *   const simulation = empic.makeCylindricalParticlePusher(spec);   // empic.js:30
+ *   simulation.set({position, velocity, sink_mask, source_pdf});    // empic.js:1157
+ *   simulation.addCurrentLoop(0.8, 2.0, -1e7);                      // empic.js:1352
+ *   simulation.precalc();                                           // empic.js:1413
+ *   simulation.step(); simulation.density();                        // empic.js:1436, :1471
+ *
+ * Same factory name, same method names, same argument meaning and the same
+ * synchronous `throw new Error(".prop <- ...")` on a bad spec (utilities.js:118-127)
+ * as the reference object.  The arithmetic runs in hand-written HIP kernels for
+ * gfx950 behind libfusionpic.so; this file only validates, flattens nested arrays
+ * into typed arrays, and forwards.  There is no JavaScript or CPU compute path: if
+ * the addon or a gfx950 device is missing, the factory throws.
+ *
+ * What cannot exist outside a browser is `canvas` (empic.js:60).  In its place:
+ *   readDensity(out?)   -> Float32Array 4*nr*nz, index 4*(i + j*nr), moments01_avgA
+ *   readMoments(out?)   -> moments01;  readGrid(name, out?) for any other texture
+ *   getParticles()      -> {position, velocity, rand, alive} in the caller's order
+ *   setRandomState({entropy, rand}) -> reproducible runs (the reference seeds from
+ *                          window.crypto and Math.random, empic.js:148-173)
+ * Extension keys of spec (all optional): precision 'fp32'|'fp64', device, count,
+ * compat (default true: keep quirk Q1 of empic.js:645), sort_interval.
+ */
+'use strict';
+const path = require('path');
+
+let native = null;
+function addon() {
+    if (native) return native;
+    const file = path.join(__dirname, '..', 'lib', 'fusionpic_napi.node');
+    try {
+        native = require(file);
+    } catch (e) {
+        throw new Error('fusionpic: cannot load ' + file + ' (' + e.message +
+            '); build it with `make -C fusion-sim_amd napi`. There is no CPU fallback.');
+    }
+    return native;
+}
+
+// ---- validate_object / validate_property (utilities.js:11-127), same messages
+function validate_property(test, control) {
+    if (typeof test === 'undefined') {
+        if (!Array.isArray(control) || typeof control[0] !== 'undefined') {
+            throw new Error(' <- Non-optional property is undefined!');
+        }
+    } else if (typeof test !== control) {
+        if (Array.isArray(control)) {
+            let ok = false;
+            for (let i = 0; i < control.length && !ok; i++) {
+                if (typeof control[i] === 'undefined') continue;
+                try { validate_property(test, control[i]); ok = true; } catch (e) { /* try next */ }
+            }
+            if (!ok) throw new Error(' <- Property does not match any given possible types!');
+        } else if (typeof control === 'object' && typeof test === 'object') {
+            validate_object(test, control);
+        } else {
+            throw new Error(' <- Property does not match any given possible types!');
+        }
+    }
+}
+function validate_object(test, control) {
+    for (const prop in control) {
+        try { validate_property(test[prop], control[prop]); } catch (error) { throw new Error('.' + prop + error.message); }
+    }
+}
+
+const GRID_IN = { E: 0, B: 1, sink_mask: 2, source_pdf: 3 };
+const GRID_OUT = { moments: 0, norm: 1, avg: 2, R1: 3, R2: 4, R3: 5, A: 6, B: 7, E: 8, sink: 9, inv_cdf: 10 };
+
+function isFloatArray(a) { return a instanceof Float32Array || a instanceof Float64Array; }
+
+// value[i][j][k] or value[i][j] -> Float64Array (JavaScript numbers are doubles)
+function flattenGrid(value, nr, nz, ncomp, name) {
+    if (isFloatArray(value)) {
+        if (value.length !== nr * nz * ncomp) throw new Error('.' + name + ' <- expected ' + (nr * nz * ncomp) + ' elements');
+        return value;
+    }
+    if (!Array.isArray(value) || value.length < nr) throw new Error('.' + name + ' <- expected [' + nr + '][' + nz + ']' + (ncomp > 1 ? '[3]' : ''));
+    const out = new Float64Array(nr * nz * ncomp);
+    for (let i = 0; i < nr; i++) {
+        const row = value[i];
+        for (let j = 0; j < nz; j++) {
+            if (ncomp === 1) out[i * nz + j] = row[j];
+            else for (let k = 0; k < ncomp; k++) out[(i * nz + j) * ncomp + k] = row[j][k];
+        }
+    }
+    return out;
+}
+
+function flattenParticles(value, n, name) {
+    if (isFloatArray(value)) {
+        if (value.length !== 3 * n) throw new Error('.' + name + ' <- expected ' + (3 * n) + ' elements');
+        return value;
+    }
+    if (!Array.isArray(value) || value.length < n) throw new Error('.' + name + ' <- expected [' + n + '][3]');
+    const out = new Float64Array(3 * n);
+    for (let p = 0; p < n; p++) { out[3 * p] = value[p][0]; out[3 * p + 1] = value[p][1]; out[3 * p + 2] = value[p][2]; }
+    return out;
+}
+
+exports.makeCylindricalParticlePusher = function (spec) {
+    validate_object(spec, {           // empic.js:31-41
+        radius: 'number', height: 'number', nr: 'number', nz: 'number', dt: 'number',
+        nparticles: 'number', particle_mass: 'number', particle_charge: 'number',
+        precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
+        sort_interval: [, 'number'],
+    });
+    const n = spec.count ? spec.count : spec.nparticles * spec.nparticles;   // empic.js:107-109
+    const fp64 = spec.precision === 'fp64';
+    if (spec.precision !== undefined && spec.precision !== 'fp32' && spec.precision !== 'fp64') {
+        throw new Error(".precision <- must be 'fp32' or 'fp64'");
+    }
+    const lib = addon();
+    let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass,
+        spec.particle_charge, spec.count || 0, fp64 ? 1 : 0, spec.device || 0, spec.compat === false ? 1 : 0,
+        spec.sort_interval || 0);
+    const nr = spec.nr, nz = spec.nz;
+    const Real = fp64 ? Float64Array : Float32Array;
+    const out = {};
+
+    out.set = function (value) {                                              // empic.js:1157-1350
+        if (value.E) lib.setGrid(h, GRID_IN.E, flattenGrid(value.E, nr, nz, 3, 'E'), nr, nz, 3);
+        if (value.B) lib.setGrid(h, GRID_IN.B, flattenGrid(value.B, nr, nz, 3, 'B'), nr, nz, 3);
+        if (value.position) lib.setParticles(h, flattenParticles(value.position, n, 'position'), null);
+        if (value.velocity) lib.setParticles(h, null, flattenParticles(value.velocity, n, 'velocity'));
+        if (value.sink_mask) lib.setGrid(h, GRID_IN.sink_mask, flattenGrid(value.sink_mask, nr, nz, 1, 'sink_mask'), nr, nz, 1);
+        if (value.source_pdf) lib.setGrid(h, GRID_IN.source_pdf, flattenGrid(value.source_pdf, nr, nz, 1, 'source_pdf'), nr, nz, 1);
+    };
+    out.addCurrentLoop = function (r, z, I) { lib.addCurrentLoop(h, r, z, I); };   // empic.js:1352
+    out.addCurrentZ = function (I) { lib.addCurrentZ(h, I); };                     // empic.js:1380
+    out.addBZ = function (Bz) { lib.addBZ(h, Bz); };                               // empic.js:1391
+    out.addBTheta = function (Btheta) { lib.addBTheta(h, Btheta); };               // empic.js:1402
+    out.addSpindleCuspPlasmaField = function () {                                 // empic.js:1369
+        // the reference's implementation stops at undefined symbols (spindle.js:328, :624, :643)
+        throw new Error('addSpindleCuspPlasmaField is not functional in the reference (spindle.js:328)');
+    };
+    out.precalc = function () { lib.precalc(h); };                                 // empic.js:1413
+    out.step = function (ncalls) { lib.step(h, ncalls === undefined ? 1 : ncalls); };  // empic.js:1436
+    out.density = function () { lib.density(h); };                                 // empic.js:1471
+
+    // ---- stand-ins for `canvas` and the reference's unseeded randomness
+    out.deposit = function () { lib.deposit(h); };
+    out.densityFinish = function () { lib.densityFinish(h); };
+    out.readGrid = function (name, buf) {
+        if (!(name in GRID_OUT)) throw new Error('.name <- unknown grid ' + name);
+        const cells = name === 'inv_cdf' ? 512 * 512 : nr * nz;
+        return lib.readGrid(h, GRID_OUT[name], buf || new Real(4 * cells));
+    };
+    out.readDensity = function (buf) { return out.readGrid('avg', buf); };
+    out.readMoments = function (buf) { return out.readGrid('moments', buf); };
+    out.getParticles = function (into) {
+        const r = into || { position: new Real(3 * n), velocity: new Real(3 * n), rand: new Float32Array(4 * n), alive: new Uint8Array(n) };
+        lib.getParticles(h, r.position || null, r.velocity || null, r.rand || null, r.alive || null);
+        return r;
+    };
+    out.getCells = function (buf) { return lib.getCells(h, buf || new Int32Array(n)); };
+    out.setRandomState = function (state) {
+        const f32 = function (a) { return a === undefined || a === null ? null : (a instanceof Float32Array ? a : Float32Array.from(a)); };
+        lib.setRandomState(h, f32(state.entropy), f32(state.rand));
+    };
+    out.sort = function () { lib.sort(h); };
+    out.sync = function () { lib.sync(h); };
+    out.profile = function (on) { lib.profile(h, on ? 1 : 0); };
+    out.stats = function () { return lib.getStats(h); };
+    out.resetStats = function () { lib.resetStats(h); };
+    out.destroy = function () { if (h) { lib.destroy(h); h = null; } };
+    out.nparticles = n;
+    return out;
+};
+
+exports.validate_object = validate_object;
+exports.buildArch = function () { return addon().buildArch(); };

@@ -1,0 +1,366 @@
+/*
+ * fusionpic_napi.c — Node N-API (version 8) addon over the C ABI of libfusionpic.so.
+ *
+ * The reference's host language is JavaScript; its hot path is the object returned
+ * by empic.makeCylindricalParticlePusher (empic.js:30-1529).  This addon is the thin
+ * native layer under fusion-sim_amd/js/empic_native.js, which re-creates that object
+ * with the same method names.  Every function here is one ABI call: it unpacks
+ * numbers and typed arrays, calls fpic_*, and converts a non-zero status into a
+ * synchronous JavaScript Error carrying fpic_last_error() — the way the reference
+ * reports validation and GL failures (utilities.js:118-127, :213-259).
+ *
+ * Ownership: typed arrays stay owned by JavaScript and are only read or filled
+ * during the call.  The native handle is wrapped in an external whose finaliser
+ * calls fpic_destroy (napi_add_finalizer semantics), so an unreachable pusher frees
+ * its HBM; destroy() does it eagerly.
+ */
+#include <node_api.h>
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fusionpic.h"
+
+#define NAPI_OK(env, call)                                                        \
+    do {                                                                          \
+        if ((call) != napi_ok) {                                                  \
+            napi_throw_error((env), NULL, "N-API call failed: " #call);           \
+            return NULL;                                                          \
+        }                                                                         \
+    } while (0)
+
+typedef struct {
+    fpic_handle* h;
+} box_t;
+
+static void box_finalize(napi_env env, void* data, void* hint)
+{
+    (void)env; (void)hint;
+    box_t* b = (box_t*)data;
+    if (b) {
+        if (b->h) fpic_destroy(b->h);
+        free(b);
+    }
+}
+
+static napi_value throw_fpic(napi_env env, fpic_handle* h)
+{
+    const char* msg = fpic_last_error(h);
+    napi_throw_error(env, NULL, (msg && *msg) ? msg : "libfusionpic call failed");
+    return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv, fpic_handle** h)
+{
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        napi_throw_type_error(env, NULL, "wrong number of arguments");
+        return 0;
+    }
+    if (h) {
+        box_t* b = NULL;
+        if (napi_get_value_external(env, argv[0], (void**)&b) != napi_ok || !b || !b->h) {
+            napi_throw_error(env, NULL, "pusher has been destroyed");
+            return 0;
+        }
+        *h = b->h;
+    }
+    return 1;
+}
+
+static int get_double(napi_env env, napi_value v, double* out)
+{
+    if (napi_get_value_double(env, v, out) != napi_ok) {
+        napi_throw_type_error(env, NULL, "expected a number");
+        return 0;
+    }
+    return 1;
+}
+
+/* Float32Array / Float64Array / Uint8Array / Int32Array or null/undefined. */
+static int get_typed(napi_env env, napi_value v, napi_typedarray_type* type, void** data, size_t* length)
+{
+    napi_valuetype vt;
+    *data = NULL; *length = 0;
+    if (napi_typeof(env, v, &vt) != napi_ok) return 0;
+    if (vt == napi_undefined || vt == napi_null) return 1;
+    bool is_ta = false;
+    if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) {
+        napi_throw_type_error(env, NULL, "expected a typed array");
+        return 0;
+    }
+    napi_value ab; size_t off;
+    if (napi_get_typedarray_info(env, v, type, length, data, &ab, &off) != napi_ok) {
+        napi_throw_type_error(env, NULL, "bad typed array");
+        return 0;
+    }
+    return 1;
+}
+
+static int float_dtype(napi_env env, napi_typedarray_type t, int* dtype)
+{
+    if (t == napi_float32_array) { *dtype = FPIC_F32; return 1; }
+    if (t == napi_float64_array) { *dtype = FPIC_F64; return 1; }
+    napi_throw_type_error(env, NULL, "expected Float32Array or Float64Array");
+    return 0;
+}
+
+static napi_value undefined(napi_env env)
+{
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
+/* create(radius, height, nr, nz, dt, nparticles, mass, charge, count, precision, device, physical_a, sort_interval) */
+static napi_value n_create(napi_env env, napi_callback_info info)
+{
+    napi_value argv[13];
+    if (!get_args(env, info, 13, argv, NULL)) return NULL;
+    double d[13];
+    for (int i = 0; i < 13; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
+    fpic_spec s;
+    memset(&s, 0, sizeof s);
+    s.radius = d[0]; s.height = d[1]; s.nr = (int32_t)d[2]; s.nz = (int32_t)d[3]; s.dt = d[4];
+    s.nparticles = (int32_t)d[5]; s.particle_mass = d[6]; s.particle_charge = d[7];
+    s.count = (uint64_t)d[8]; s.precision = (int32_t)d[9]; s.device = (int32_t)d[10];
+    s.physical_a = (int32_t)d[11]; s.sort_interval = (int32_t)d[12];
+    fpic_handle* h = NULL;
+    if (fpic_create(&s, &h) != FPIC_OK) return throw_fpic(env, NULL);
+    box_t* b = (box_t*)malloc(sizeof *b);
+    if (!b) { fpic_destroy(h); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    b->h = h;
+    napi_value ext;
+    if (napi_create_external(env, b, box_finalize, NULL, &ext) != napi_ok) {
+        box_finalize(env, b, NULL);
+        napi_throw_error(env, NULL, "napi_create_external failed");
+        return NULL;
+    }
+    return ext;
+}
+
+static napi_value n_destroy(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    size_t argc = 1;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    box_t* b = NULL;
+    if (argc == 1 && napi_get_value_external(env, argv[0], (void**)&b) == napi_ok && b && b->h) {
+        fpic_destroy(b->h);
+        b->h = NULL;
+    }
+    return undefined(env);
+}
+
+/* setParticles(h, positionAoS|null, velocityAoS|null) */
+static napi_value n_set_particles(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; fpic_handle* h;
+    if (!get_args(env, info, 3, argv, &h)) return NULL;
+    for (int k = 0; k < 2; ++k) {
+        napi_typedarray_type t; void* data; size_t len;
+        if (!get_typed(env, argv[1 + k], &t, &data, &len)) return NULL;
+        if (!data) continue;
+        int dtype;
+        if (!float_dtype(env, t, &dtype)) return NULL;
+        if (len % 3) { napi_throw_error(env, NULL, ".position <- length must be a multiple of 3"); return NULL; }
+        if (fpic_set_particles(h, k == 0 ? data : NULL, k == 1 ? data : NULL, len / 3, dtype) != FPIC_OK) return throw_fpic(env, h);
+    }
+    return undefined(env);
+}
+
+/* setGrid(h, which, data, nr, nz, ncomp) */
+static napi_value n_set_grid(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6]; fpic_handle* h;
+    if (!get_args(env, info, 6, argv, &h)) return NULL;
+    double which, nr, nz, nc;
+    if (!get_double(env, argv[1], &which) || !get_double(env, argv[3], &nr) || !get_double(env, argv[4], &nz) ||
+        !get_double(env, argv[5], &nc)) return NULL;
+    napi_typedarray_type t; void* data; size_t len; int dtype;
+    if (!get_typed(env, argv[2], &t, &data, &len)) return NULL;
+    if (!data) { napi_throw_type_error(env, NULL, "expected a typed array"); return NULL; }
+    if (!float_dtype(env, t, &dtype)) return NULL;
+    if (len != (size_t)(nr * nz * nc)) { napi_throw_error(env, NULL, ".grid <- wrong number of elements"); return NULL; }
+    if (fpic_set_grid(h, (int)which, data, (int)nr, (int)nz, (int)nc, dtype) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* setRandomState(h, entropy Float32Array|null, rand Float32Array|null) */
+static napi_value n_set_random_state(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; fpic_handle* h;
+    if (!get_args(env, info, 3, argv, &h)) return NULL;
+    void* ptr[2] = { NULL, NULL };
+    for (int k = 0; k < 2; ++k) {
+        napi_typedarray_type t; size_t len;
+        if (!get_typed(env, argv[1 + k], &t, &ptr[k], &len)) return NULL;
+        if (ptr[k] && t != napi_float32_array) { napi_throw_type_error(env, NULL, "expected Float32Array"); return NULL; }
+        if (ptr[k] && k == 0 && len != (size_t)4 * 1024 * 1024) { napi_throw_error(env, NULL, ".entropy <- expected 1024*1024*4 floats"); return NULL; }
+    }
+    if (fpic_set_random_state(h, (const float*)ptr[0], (const float*)ptr[1]) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+#define SIMPLE_CALL(NAME, FN)                                                \
+    static napi_value NAME(napi_env env, napi_callback_info info)            \
+    {                                                                        \
+        napi_value argv[1]; fpic_handle* h;                                  \
+        if (!get_args(env, info, 1, argv, &h)) return NULL;                  \
+        if (FN(h) != FPIC_OK) return throw_fpic(env, h);                     \
+        return undefined(env);                                               \
+    }
+SIMPLE_CALL(n_precalc, fpic_precalc)
+SIMPLE_CALL(n_density, fpic_density)
+SIMPLE_CALL(n_deposit, fpic_deposit)
+SIMPLE_CALL(n_density_finish, fpic_density_finish)
+SIMPLE_CALL(n_sort, fpic_sort)
+SIMPLE_CALL(n_sync, fpic_sync)
+SIMPLE_CALL(n_reset_stats, fpic_reset_stats)
+
+#define DOUBLE_CALL(NAME, FN)                                                \
+    static napi_value NAME(napi_env env, napi_callback_info info)            \
+    {                                                                        \
+        napi_value argv[2]; fpic_handle* h; double v;                        \
+        if (!get_args(env, info, 2, argv, &h)) return NULL;                  \
+        if (!get_double(env, argv[1], &v)) return NULL;                      \
+        if (FN(h, v) != FPIC_OK) return throw_fpic(env, h);                  \
+        return undefined(env);                                               \
+    }
+DOUBLE_CALL(n_add_current_z, fpic_add_current_z)
+DOUBLE_CALL(n_add_bz, fpic_add_bz)
+DOUBLE_CALL(n_add_btheta, fpic_add_btheta)
+
+static napi_value n_add_current_loop(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4]; fpic_handle* h; double r, z, c;
+    if (!get_args(env, info, 4, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &r) || !get_double(env, argv[2], &z) || !get_double(env, argv[3], &c)) return NULL;
+    if (fpic_add_current_loop(h, r, z, c) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+static napi_value n_step(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2]; fpic_handle* h; double n;
+    if (!get_args(env, info, 2, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &n)) return NULL;
+    if (fpic_step(h, (int)n) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+static napi_value n_profile(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2]; fpic_handle* h; double on;
+    if (!get_args(env, info, 2, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &on)) return NULL;
+    if (fpic_profile(h, (int)on) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* readGrid(h, which, out Float32Array|Float64Array) */
+static napi_value n_read_grid(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; fpic_handle* h; double which;
+    if (!get_args(env, info, 3, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &which)) return NULL;
+    napi_typedarray_type t; void* data; size_t len; int dtype;
+    if (!get_typed(env, argv[2], &t, &data, &len)) return NULL;
+    if (!data) { napi_throw_type_error(env, NULL, "expected a typed array"); return NULL; }
+    if (!float_dtype(env, t, &dtype)) return NULL;
+    if (fpic_read_grid(h, (int)which, data, dtype) != FPIC_OK) return throw_fpic(env, h);
+    return argv[2];
+}
+
+/* getParticles(h, position|null, velocity|null, rand Float32Array|null, alive Uint8Array|null) */
+static napi_value n_get_particles(napi_env env, napi_callback_info info)
+{
+    napi_value argv[5]; fpic_handle* h;
+    if (!get_args(env, info, 5, argv, &h)) return NULL;
+    napi_typedarray_type t[4]; void* p[4]; size_t len[4];
+    for (int k = 0; k < 4; ++k) if (!get_typed(env, argv[1 + k], &t[k], &p[k], &len[k])) return NULL;
+    int dtype = FPIC_F32;
+    if (p[0] && !float_dtype(env, t[0], &dtype)) return NULL;
+    if (p[1]) {
+        int d2;
+        if (!float_dtype(env, t[1], &d2)) return NULL;
+        if (p[0] && d2 != dtype) { napi_throw_type_error(env, NULL, "position and velocity must have the same element type"); return NULL; }
+        dtype = d2;
+    }
+    if (p[2] && t[2] != napi_float32_array) { napi_throw_type_error(env, NULL, "rand must be a Float32Array"); return NULL; }
+    if (p[3] && t[3] != napi_uint8_array) { napi_throw_type_error(env, NULL, "alive must be a Uint8Array"); return NULL; }
+    if (fpic_get_particles(h, p[0], p[1], (float*)p[2], (uint8_t*)p[3], dtype) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+static napi_value n_get_cells(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2]; fpic_handle* h;
+    if (!get_args(env, info, 2, argv, &h)) return NULL;
+    napi_typedarray_type t; void* p; size_t len;
+    if (!get_typed(env, argv[1], &t, &p, &len)) return NULL;
+    if (!p || t != napi_int32_array) { napi_throw_type_error(env, NULL, "expected an Int32Array"); return NULL; }
+    if (fpic_get_cells(h, (int32_t*)p) != FPIC_OK) return throw_fpic(env, h);
+    return argv[1];
+}
+
+static napi_value n_get_stats(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1]; fpic_handle* h;
+    if (!get_args(env, info, 1, argv, &h)) return NULL;
+    fpic_stats s;
+    if (fpic_get_stats(h, &s) != FPIC_OK) return throw_fpic(env, h);
+    napi_value o;
+    NAPI_OK(env, napi_create_object(env, &o));
+    struct { const char* k; double v; } f[] = {
+        { "n_particles", (double)s.n_particles }, { "particle_updates", (double)s.particle_updates },
+        { "step_launches", (double)s.step_launches }, { "deposit_launches", (double)s.deposit_launches },
+        { "sort_passes", (double)s.sort_passes }, { "deposit_spilled", (double)s.deposit_spilled },
+        { "ms_push", s.ms_push }, { "ms_deposit", s.ms_deposit }, { "ms_stamp", s.ms_stamp },
+        { "ms_precalc", s.ms_precalc }, { "ms_sort", s.ms_sort },
+        { "bytes_particle_state", (double)s.bytes_particle_state }, { "bytes_grid_state", (double)s.bytes_grid_state },
+    };
+    for (size_t i = 0; i < sizeof f / sizeof f[0]; ++i) {
+        napi_value v;
+        NAPI_OK(env, napi_create_double(env, f[i].v, &v));
+        NAPI_OK(env, napi_set_named_property(env, o, f[i].k, v));
+    }
+    return o;
+}
+
+static napi_value n_build_arch(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    napi_value s;
+    NAPI_OK(env, napi_create_string_utf8(env, fpic_build_arch(), NAPI_AUTO_LENGTH, &s));
+    return s;
+}
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    struct { const char* name; napi_callback fn; } table[] = {
+        { "create", n_create }, { "destroy", n_destroy }, { "setParticles", n_set_particles },
+        { "setGrid", n_set_grid }, { "setRandomState", n_set_random_state }, { "addCurrentLoop", n_add_current_loop },
+        { "addCurrentZ", n_add_current_z }, { "addBZ", n_add_bz }, { "addBTheta", n_add_btheta },
+        { "precalc", n_precalc }, { "step", n_step }, { "density", n_density }, { "deposit", n_deposit },
+        { "densityFinish", n_density_finish }, { "readGrid", n_read_grid }, { "getParticles", n_get_particles },
+        { "getCells", n_get_cells }, { "sort", n_sort }, { "sync", n_sync }, { "profile", n_profile },
+        { "getStats", n_get_stats }, { "resetStats", n_reset_stats }, { "buildArch", n_build_arch },
+    };
+    for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
+        napi_value fn;
+        if (napi_create_function(env, table[i].name, NAPI_AUTO_LENGTH, table[i].fn, NULL, &fn) != napi_ok ||
+            napi_set_named_property(env, exports, table[i].name, fn) != napi_ok) {
+            napi_throw_error(env, NULL, "addon initialisation failed");
+            return NULL;
+        }
+    }
+    return exports;
+}
+
+#ifndef NODE_GYP_MODULE_NAME
+#define NODE_GYP_MODULE_NAME fusionpic_napi
+#endif
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,147 @@
+"""The drop-in boundary on a machine WITHOUT a GPU: libfusionpic.so loads and exports
+every symbol include/fusionpic.h declares; spec validation speaks the reference's
+".prop <- ..." language; and the product fails loudly, with no CPU fallback, when no
+gfx950 device is present.  No compute call is made here."""
+import ctypes
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, load_json, make_spec
+
+HEADER = os.path.join(ROOT, "include", "fusionpic.h")
+LIB = os.path.join(ROOT, "fusion-sim_amd", "lib", "libfusionpic.so")
+ADDON = os.path.join(ROOT, "fusion-sim_amd", "lib", "fusionpic_napi.node")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fpic_[a-z_0-9]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def fp():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    import fusionpic
+    return fusionpic
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_header_symbols_are_all_exported(fp):
+    lib = ctypes.CDLL(LIB)
+    syms = declared_symbols()
+    assert len(syms) >= 28
+    for s in syms:
+        assert hasattr(lib, s), "libfusionpic.so does not export " + s
+    assert sorted(fp.ABI_FUNCTIONS) == syms
+    lib.fpic_build_arch.restype = ctypes.c_char_p
+    assert lib.fpic_build_arch() == b"gfx950"
+    assert lib.fpic_abi_version() == 1
+
+
+def test_header_cites_reference_lines():
+    text = open(HEADER).read()
+    for cite in ("empic.js:30-1529", "empic.js:1157-1350", "empic.js:1413-1434", "empic.js:1436-1469",
+                 "empic.js:1471-1495", "utilities.js:118-127", "utilities.js:701-711"):
+        assert cite in text
+
+
+def test_library_does_not_link_the_oracle():
+    out = subprocess.check_output(["ldd", LIB]).decode()
+    assert "pic_oracle" not in out
+    syms = subprocess.check_output(["nm", "-D", LIB]).decode()
+    assert "orc_" not in syms
+
+
+def test_spec_validation_messages_match_reference(fp):
+    v = load_json("validation.json")
+    good = make_spec(4, 4, 2)
+    bad = dict(good); del bad["radius"]
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(bad)
+    assert str(e.value) == v["missing_radius"]
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(dict(good, nr="4"))
+    assert str(e.value) == v["string_nr"]
+    bad = dict(good); del bad["particle_charge"]
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(bad)
+    assert str(e.value) == v["missing_charge"]
+
+
+def test_c_level_validation_precedes_device_probe(fp):
+    lib = fp.load_library()
+    s = fp.Spec()
+    s.radius, s.height, s.nr, s.nz, s.dt, s.nparticles = -1.0, 1.0, 4, 4, 1e-9, 2
+    s.particle_mass, s.particle_charge = 1.0, 1.0
+    h = ctypes.c_void_p()
+    assert lib.fpic_create(ctypes.byref(s), ctypes.byref(h)) == -1
+    assert lib.fpic_last_error(None).decode().startswith(".radius <- ")
+    s.radius, s.nr = 1.0, 0
+    assert lib.fpic_create(ctypes.byref(s), ctypes.byref(h)) == -1
+    assert lib.fpic_last_error(None).decode().startswith(".nr <- ")
+    assert lib.fpic_create(None, ctypes.byref(h)) == -1
+
+
+@pytest.mark.skipif(has_gpu(), reason="a GPU is present")
+def test_no_cpu_fallback_without_a_device(fp):
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(make_spec(4, 4, 2))
+    assert e.value.code == -2
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_sources_never_touch_the_oracle():
+    pkg = os.path.join(ROOT, "fusion-sim_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".js", ".c", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pic_oracle" not in text and "orc_f32" not in text and "libpic_oracle" not in text, f
+
+
+node = shutil.which("node")
+
+
+@pytest.mark.skipif(node is None, reason="node is not installed")
+def test_node_addon_loads_and_mirrors_reference_surface():
+    if not os.path.exists(ADDON):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fusion-sim_amd"), "napi"])
+    script = r"""
+const e = require(process.argv[1]);
+const out = {arch: e.buildArch(), errors: []};
+const good = {radius:1,height:2,nr:4,nz:4,dt:1e-9,nparticles:2,particle_mass:1,particle_charge:1};
+for (const bad of [Object.assign({}, good, {radius: undefined}), Object.assign({}, good, {nr: '4'})]) {
+  try { e.makeCylindricalParticlePusher(bad); out.errors.push(null); } catch (x) { out.errors.push(x.message); }
+}
+try { const s = e.makeCylindricalParticlePusher(good); out.methods = Object.keys(s).sort(); s.destroy(); }
+catch (x) { out.create_error = x.message; }
+console.log(JSON.stringify(out));
+"""
+    shim = os.path.join(ROOT, "fusion-sim_amd", "js", "empic_native.js")
+    import json
+    out = json.loads(subprocess.check_output([node, "-e", script, shim]))
+    v = load_json("validation.json")
+    assert out["arch"] == "gfx950"
+    assert out["errors"] == [v["missing_radius"], v["string_nr"]]
+    if has_gpu():
+        ref_api = set(load_json("draw_order.json")["api"]) - {"canvas"}
+        assert ref_api <= set(out["methods"])
+    else:
+        assert "no CPU fallback" in out["create_error"]

@@ -414,3 +414,73 @@ def test_large_run_properties(fp):
     np.testing.assert_allclose(m2[..., 3], m1[..., 3], rtol=1e-5)
     scale = np.abs(m1[..., :3]).max()
     assert np.abs(m2[..., :3] - 2 * m1[..., :3]).max() <= 1e-3 * scale
+
+
+# ----------------------------------------------------------------------------- through the JavaScript host
+
+def test_node_shim_end_to_end(fp, po, tmp_path):
+    """The shipped host path: Node -> empic_native.js -> N-API addon -> libfusionpic.so.
+    Same calls, same names as fusionsim.js:85-174 makes on the reference object; results
+    compared with the oracle: push bit-exact, density within 1e-3."""
+    import base64
+    import json
+    import os
+    import shutil
+    import subprocess
+    from helpers import ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    spec = make_spec(40, 80, 50, radius=1.0, height=2.0)
+    n = 2500
+    rng = np.random.default_rng(71)
+    sink = frame_sink(40, 80)
+    pdf = np.zeros((40, 80)); pdf[:5, 35:45] = 1.0                 # fusionsim.js:114-122, scaled
+    pos = np.stack([0.2 * (rng.random(n) - 0.5), 0.2 * (rng.random(n) - 0.5), 0.2 * (rng.random(n) - 0.5) + 1], axis=1)
+    vel = 0.02 * (rng.random((n, 3)) - 0.5)
+    entropy = rng.random(4 * 1024 * 1024, dtype=np.float32)
+    rand = rng.random((n, 4), dtype=np.float32)
+    B = rng.normal(0, 0.2, size=(40, 80, 3)); B[..., 2] += 0.6
+    ent_file = tmp_path / "entropy.f32"
+    entropy.tofile(ent_file)
+    (tmp_path / "in.json").write_text(json.dumps(dict(
+        spec=spec, position=pos.tolist(), velocity=vel.tolist(), sink=sink.tolist(), pdf=pdf.tolist(), B=B.tolist(),
+        rand=rand.ravel().tolist(), entropy_file=str(ent_file))))
+    script = r"""
+const fs = require('fs');
+const empic = require(process.argv[1]);
+const inp = JSON.parse(fs.readFileSync(process.argv[2]));
+const simulation = empic.makeCylindricalParticlePusher(inp.spec);
+simulation.set({position: inp.position, velocity: inp.velocity, sink_mask: inp.sink, source_pdf: inp.pdf, B: inp.B});
+simulation.setRandomState({entropy: new Float32Array(fs.readFileSync(inp.entropy_file).buffer.slice(0)), rand: inp.rand});
+simulation.addBZ(0.01);
+simulation.precalc();
+simulation.density();
+for (let frame = 0; frame < 4; frame++) { simulation.step(); simulation.density(); }
+const p = simulation.getParticles();
+const b64 = a => Buffer.from(a.buffer, a.byteOffset, a.byteLength).toString('base64');
+console.log(JSON.stringify({position: b64(p.position), velocity: b64(p.velocity), alive: b64(p.alive),
+  density: b64(simulation.readDensity()), moments: b64(simulation.readMoments()), cells: b64(simulation.getCells())}));
+simulation.destroy();
+"""
+    shim = os.path.join(ROOT, "fusion-sim_amd", "js", "empic_native.js")
+    raw = subprocess.check_output([node, "-e", script, shim, str(tmp_path / "in.json")])
+    out = json.loads(raw.decode().strip().splitlines()[-1])
+    dec = lambda k, dt: np.frombuffer(base64.b64decode(out[k]), dtype=dt)
+
+    ora = po.OracleSim(spec)
+    ora.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf, B=B)
+    ora.set_random_state(entropy, rand)
+    ora.add_bz(0.01)
+    ora.precalc()
+    ora.density()
+    for _ in range(4):
+        ora.step(); ora.density()
+    assert np.array_equal(dec("alive", np.uint8), ora.alive())
+    assert np.array_equal(dec("cells", np.int32), ora.cells())
+    assert same_bits(dec("position", np.float32).reshape(n, 3), ora.positions())
+    assert same_bits(dec("velocity", np.float32).reshape(n, 3), ora.velocities())
+    got, want = dec("density", np.float32).reshape(-1, 4), ora.avg_A.reshape(-1, 4)
+    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=2e-3)
+    got, want = dec("moments", np.float32).reshape(-1, 4), ora.moments.reshape(-1, 4)
+    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-3)
