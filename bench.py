@@ -138,6 +138,7 @@ def main():
     del pos, vel, rand
     sim.addBZ(0.01)
     sim.precalc()
+    sim.sort()  # first binning of the randomly ordered upload belongs to setup, like the upload itself
 
     sharded = None
     if distributed:
