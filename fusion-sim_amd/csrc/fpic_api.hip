@@ -341,7 +341,10 @@ int launch_push(fpic_handle* h, int nsub)
     a.nsub = nsub;
     const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
     timing_begin(h, KC_PUSH);
-    push_kernel<T><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+    if (h->binned) // the work list of the last binning is valid until the next one: the push is in place
+        push_tiles_kernel<T><<<static_cast<unsigned>(h->work_cap), kPushThreads, push_lds_bytes<T>(), h->stream>>>(a, h->ntx, h->work, h->nwork);
+    else
+        push_kernel<T><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
@@ -377,7 +380,7 @@ int launch_cell_sums(fpic_handle* h)
     timing_begin(h, KC_DEPOSIT);
     HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color [0,0,0,0] (empic.js:1476)
     HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
-    cell_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), 256, 0, h->stream>>>(
+    cell_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), kSumsThreads, kSumsLdsBytes, h->stream>>>(
         arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work, h->nwork, static_cast<T*>(h->cell_sums), h->spilled);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
@@ -626,6 +629,12 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
 
     rc = (h->prec == FPIC_F32) ? create_state<float>(h) : create_state<double>(h);
     if (rc) return bail(rc);
+    // the scatter's LDS image (72 KiB of double accumulators) exceeds the 64 KiB static limit
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_lds_bytes<float>()))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_lds_bytes<double>()))) != hipSuccess)
+        return bail(fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e)));
 
     h->work_cap = (h->n + kDepositChunk - 1) / kDepositChunk + h->ntiles;
     uint64_t* acc = &h->bytes_grid;

@@ -70,12 +70,21 @@ __device__ __forceinline__ void load4(const T* p, T (&o)[4])
     }
 }
 
+// Particle streams are read once and written once per launch: they are accessed with
+// the non-temporal hint so that they do not push the gathered tables (entropy,
+// coefficients) out of the XCD's L2.
+typedef float nat_f32x4 __attribute__((ext_vector_type(4)));
+typedef double nat_f64x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct NatVec16;
+template <> struct NatVec16<float> { using type = nat_f32x4; };
+template <> struct NatVec16<double> { using type = nat_f64x2; };
+
 template <typename T, int N>
 __device__ __forceinline__ void load_lane(const T* arr, size_t base, T (&o)[N])
 {
-    using V = typename Vec16<T>::type;
+    using V = typename NatVec16<T>::type;
     static_assert(N == Vec16<T>::N, "one 16-byte vector per lane");
-    const V v = *reinterpret_cast<const V*>(arr + base);
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(arr + base));
     if constexpr (N == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
     else { o[0] = v.x; o[1] = v.y; }
 }
@@ -83,11 +92,11 @@ __device__ __forceinline__ void load_lane(const T* arr, size_t base, T (&o)[N])
 template <typename T, int N>
 __device__ __forceinline__ void store_lane(T* arr, size_t base, const T (&o)[N])
 {
-    using V = typename Vec16<T>::type;
+    using V = typename NatVec16<T>::type;
     V v;
     if constexpr (N == 4) { v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3]; }
     else { v.x = o[0]; v.y = o[1]; }
-    *reinterpret_cast<V*>(arr + base) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(arr + base));
 }
 
 // ------------------------------------------------------------------ push (K3 + K1 + K2)
@@ -115,8 +124,85 @@ struct Particle {
 // step_position_frag on the NEW velocity (empic.js:714-719), both reading the OLD
 // random state, then the random state's own advance (empic.js:800-807).  This is the
 // order of bindings in out.step (empic.js:815-853, :890-928).
+// Where a sub-step reads the per-cell tables from.  GlobalTables: straight from HBM/L2
+// (any particle order).  WindowTables: the tile's window staged in LDS by the
+// workgroup, falling back to global memory for a particle outside the window.
 template <typename T>
-__device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a)
+struct GlobalTables {
+    const T* coef;
+    const uint8_t* sink_alive;
+    int nr;
+    __device__ __forceinline__ void coefficients(int ci, int cj, T (&R1)[4], T (&R2)[4], T (&R3)[4]) const
+    {
+        const T* cf = coef + 12 * (static_cast<size_t>(ci) + static_cast<size_t>(nr) * cj);
+        load4(cf, R1);
+        load4(cf + 4, R2);
+        load4(cf + 8, R3);
+    }
+    __device__ __forceinline__ bool keep(int ci, int cj) const
+    {
+        return sink_alive[static_cast<size_t>(ci) + static_cast<size_t>(nr) * cj] != 0;
+    }
+};
+
+constexpr int kPushHalo = 4;                           // cells staged around a tile for the push
+constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
+constexpr int kPushThreads = 512;
+template <typename T>
+constexpr size_t push_lds_bytes() { return static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1); }
+
+// LDS pointers carry their address space in the type: through a generic pointer the
+// compiler emits flat_load instead of ds_read_b128.
+#define FPIC_LDS __attribute__((address_space(3)))
+
+// (HIP's float4/double2 classes cannot live in an address space; clang's native vectors can)
+typedef float lds_f32x4 __attribute__((ext_vector_type(4)));
+typedef double lds_f64x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct LdsVec16;
+template <> struct LdsVec16<float> { using type = lds_f32x4; };
+template <> struct LdsVec16<double> { using type = lds_f64x2; };
+
+template <typename T>
+__device__ __forceinline__ void load4_lds(const FPIC_LDS T* p, T (&o)[4])
+{
+    if constexpr (sizeof(T) == 4) {
+        const lds_f32x4 v = *reinterpret_cast<const FPIC_LDS lds_f32x4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+        const lds_f64x2 a = *reinterpret_cast<const FPIC_LDS lds_f64x2*>(p);
+        const lds_f64x2 b = *reinterpret_cast<const FPIC_LDS lds_f64x2*>(p + 2);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    }
+}
+
+template <typename T>
+struct WindowTables {
+    GlobalTables<T> g;
+    const FPIC_LDS T* lcoef;          // [kPushLds*kPushLds][12]
+    const FPIC_LDS uint8_t* lsink;    // [kPushLds*kPushLds]
+    int i0, j0;
+    __device__ __forceinline__ void coefficients(int ci, int cj, T (&R1)[4], T (&R2)[4], T (&R3)[4]) const
+    {
+        const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
+        if (li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds)) {
+            const FPIC_LDS T* cf = lcoef + 12 * (lj * kPushLds + li);
+            load4_lds(cf, R1);
+            load4_lds(cf + 4, R2);
+            load4_lds(cf + 8, R3);
+        } else {
+            g.coefficients(ci, cj, R1, R2, R3);
+        }
+    }
+    __device__ __forceinline__ bool keep(int ci, int cj) const
+    {
+        const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
+        if (li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds)) return lsink[lj * kPushLds + li] != 0;
+        return g.keep(ci, cj);
+    }
+};
+
+template <typename T, typename Tables>
+__device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, const Tables& tab)
 {
     // entropy texel for the random advance depends on nothing below: issue it first
     const int et = ngp(q.c1, kEntropySide) + kEntropySide * ngp(q.c2, kEntropySide);
@@ -128,12 +214,8 @@ __device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a)
     const T dx = q.x / r, dy = q.y / r;
     const T vr = q.vx * dx + q.vy * dy;
     const T va = q.vy * dx - q.vx * dy;
-    const int cell = ngp(r, a.nr) + a.nr * ngp(q.z, a.nz);
-    const T* cf = a.coef + 12 * static_cast<size_t>(cell);
     T R1[4], R2[4], R3[4];
-    load4(cf, R1);
-    load4(cf + 4, R2);
-    load4(cf + 8, R3);
+    tab.coefficients(ngp(r, a.nr), ngp(q.z, a.nz), R1, R2, R3);
     const T cx = ((R1[0] * vr + R1[1] * va) + R1[2] * q.vz) + R1[3];
     const T cy = ((R2[0] * vr + R2[1] * va) + R2[2] * q.vz) + R2[3];
     const T cz = ((R3[0] * vr + R3[1] * va) + R3[2] * q.vz) + R3[3];
@@ -151,8 +233,7 @@ __device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a)
     const T ny = q.y + a.step_factor * nvy;
     const T nzp = q.z + a.step_factor * nvz;
     const T r2 = sqrt_(nx * nx + ny * ny);
-    const int cell2 = ngp(r2, a.nr) + a.nr * ngp(nzp, a.nz);
-    const bool keep = a.sink_alive[cell2] != 0;
+    const bool keep = tab.keep(ngp(r2, a.nr), ngp(nzp, a.nz));
     if (keep) {
         q.x = nx; q.y = ny; q.z = nzp;
     } else {
@@ -177,14 +258,12 @@ __device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a)
 // out.step (empic.js:1436-1469) fused: nsub = 2 * ncalls sub-steps per launch, state
 // held in registers between them.  Traffic per launch: one read and one write of
 // the particle state (10 T + 1 byte each way) however many sub-steps are taken.
-template <typename T>
-__global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
+// One lane owns the PPT consecutive particles starting at `base` (one 16-byte vector
+// per array); cnt < PPT only for the last lane of the population.
+template <typename T, typename Tables>
+__device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& tab, size_t base, int cnt)
 {
     constexpr int PPT = Vec16<T>::N;
-    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
-    if (base >= a.n) return;
-    const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
-
     T x[PPT], y[PPT], z[PPT], vx[PPT], vy[PPT], vz[PPT], u1[PPT], u2[PPT], c1[PPT], c2[PPT];
     uint8_t al[PPT];
     // arrays are padded to a multiple of the vector width, so the vector load is in bounds
@@ -221,7 +300,7 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
     }
     for (int s = 0; s < a.nsub; ++s) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) substep(q[k], a);
+        for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -257,6 +336,69 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
     }
 }
 
+// Flat form: any particle order, tables read from global memory.  Used until the
+// particles have been binned.
+template <typename T>
+__global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
+{
+    constexpr int PPT = Vec16<T>::N;
+    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
+    if (base >= a.n) return;
+    const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+    GlobalTables<T> tab{ a.coef, a.sink_alive, a.nr };
+    push_lane<T>(a, tab, base, cnt);
+}
+
+// Tiled form, for binned particles: one workgroup per chunk of one tile's particles
+// (the scatter's work list).  It first stages the tile's coefficient records and sink
+// bytes, plus a 4-cell halo, in LDS; a lane then reads a particle's record with three
+// ds_read_b128 instead of three divergent global loads (the L1 serves about one
+// distinct line per clock per CU, which cost 1.4 ms of the flat kernel's 4.5 ms at
+// 1e8 particles; profiles/r01_push_ablation.txt).  A particle that has drifted
+// outside the window reads global memory; results never depend on the binning.
+// Chunks are cut at arbitrary particle indices; a vector of PPT particles belongs
+// to the chunk that holds its first particle.
+template <typename T>
+__global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, int ntx, const BlockWork* __restrict__ work,
+                                                                  const uint32_t* __restrict__ nwork)
+{
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int LW = kPushLds;
+    extern __shared__ __attribute__((aligned(16))) unsigned char push_lds[];
+    FPIC_LDS T* lcoef = (FPIC_LDS T*)push_lds;
+    FPIC_LDS uint8_t* lsink = (FPIC_LDS uint8_t*)push_lds + static_cast<size_t>(LW) * LW * 12 * sizeof(T);
+    if (blockIdx.x >= *nwork) return;
+    const BlockWork w = work[blockIdx.x];
+    const int i0 = static_cast<int>(w.tile % ntx) * kTileSide - kPushHalo;
+    const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kPushHalo;
+    // stage: one 16-byte piece (a third or a sixth of a record) per lane and iteration
+    constexpr int PIECES = static_cast<int>(12 * sizeof(T) / 16);
+    for (int k = threadIdx.x; k < LW * LW * PIECES; k += kPushThreads) {
+        const int c = k / PIECES, part = k - c * PIECES;
+        const int lj = c / LW, li = c - lj * LW;
+        const int gi = i0 + li, gj = j0 + lj;
+        using V = typename LdsVec16<T>::type;
+        V v = {};
+        if (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz)
+            v = *reinterpret_cast<const V*>(a.coef + 12 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj) + part * Vec16<T>::N);
+        *reinterpret_cast<FPIC_LDS V*>(lcoef + 12 * c + part * Vec16<T>::N) = v;
+    }
+    for (int c = threadIdx.x; c < LW * LW; c += kPushThreads) {
+        const int lj = c / LW, li = c - lj * LW;
+        const int gi = i0 + li, gj = j0 + lj;
+        lsink[c] = (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz) ? a.sink_alive[static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj] : 0;
+    }
+    __syncthreads();
+    WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
+    const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
+    const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
+    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
+        const size_t base = g * PPT;
+        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+        push_lane<T>(a, tab, base, cnt);
+    }
+}
+
 // ------------------------------------------------------------------ scatter (K4), stage 1
 //
 // programMoments01 (empic.js:980-1035) draws every particle as an 11x11 sprite whose
@@ -279,30 +421,37 @@ __device__ __forceinline__ bool deposit_cell(T x, T y, T z, int nr, int nz, T& r
 }
 
 // One workgroup sums one chunk of the particles binned to one tile.  The tile and an
-// 8-cell halo live in LDS; lanes add with LDS float atomics, then the non-zero part
-// of the tile is flushed with global atomics in 256-byte contiguous pieces.  A
-// particle that has drifted beyond the halo since the last binning goes straight to
-// global memory (counted in *spilled); correctness never depends on the binning.
+// 8-cell halo live in LDS as DOUBLE accumulators: on gfx950 ds_add_f32 sustains only
+// ~0.4 lanes/clk/CU while ds_add_f64 is 3.7x and ds_add_u32 9x faster (measured,
+// profiles/r01_lds_atomics.txt), and double sums are also closer to the exact value
+// than any float ordering.  The non-zero part of the tile is then flushed with global
+// float atomics in 256-byte contiguous pieces.  A particle that has drifted beyond the
+// halo since the last binning goes straight to global memory (counted in *spilled);
+// correctness never depends on the binning.
+constexpr int kSumsThreads = 512;
+constexpr size_t kSumsLdsBytes = static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double);
+
 template <typename T>
-__global__ __launch_bounds__(256) void cell_sums_kernel(ParticleArrays<T> p, int nr, int nz, int ntx,
-                                                        const BlockWork* __restrict__ work,
-                                                        const uint32_t* __restrict__ nwork, T* __restrict__ cell_sums,
-                                                        unsigned long long* spilled)
+__global__ __launch_bounds__(kSumsThreads) void cell_sums_kernel(ParticleArrays<T> p, int nr, int nz, int ntx,
+                                                                 const BlockWork* __restrict__ work,
+                                                                 const uint32_t* __restrict__ nwork,
+                                                                 T* __restrict__ cell_sums, unsigned long long* spilled)
 {
     constexpr int PPT = Vec16<T>::N;
     constexpr int LW = kTileLds;
-    __shared__ T tile[LW * LW * 4];
+    constexpr int BS = kSumsThreads;
+    extern __shared__ double tile[];
     if (blockIdx.x >= *nwork) return;
     const BlockWork w = work[blockIdx.x];
     const int i0 = static_cast<int>(w.tile % ntx) * kTileSide - kTileHalo;
     const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kTileHalo;
-    for (int k = threadIdx.x; k < LW * LW * 4; k += 256) tile[k] = static_cast<T>(0);
+    for (int k = threadIdx.x; k < LW * LW * 4; k += BS) tile[k] = 0.0;
     __syncthreads();
 
     const size_t gw = static_cast<size_t>(nr) + 1;
     unsigned int my_spill = 0;
     const size_t first = (static_cast<size_t>(w.begin) / PPT) * PPT;
-    for (size_t base = first + static_cast<size_t>(threadIdx.x) * PPT; base < w.end; base += 256 * PPT) {
+    for (size_t base = first + static_cast<size_t>(threadIdx.x) * PPT; base < w.end; base += BS * PPT) {
         T x[PPT], y[PPT], z[PPT], vx[PPT], vy[PPT], vz[PPT];
         load_lane<T, PPT>(p.x, base, x);
         load_lane<T, PPT>(p.y, base, y);
@@ -320,17 +469,18 @@ __global__ __launch_bounds__(256) void cell_sums_kernel(ParticleArrays<T> p, int
             const T dx = x[k] / r, dy = y[k] / r;
             const T vr = vx[k] * dx + vy[k] * dy;
             const T va = vy[k] * dx - vx[k] * dy;
+            // v_color of the vertex shader, in T as the reference computes it (empic.js:1006)
             const T c0 = static_cast<T>(0.001) * vr;
             const T c1 = static_cast<T>(0.001) * va;
             const T c2 = static_cast<T>(0.001) * vz[k];
             const T c3 = static_cast<T>(0.001) * static_cast<T>(1);
             const int li = ic - i0, lj = jc - j0;
             if (li >= 0 && li < LW && lj >= 0 && lj < LW) {
-                T* t = tile + 4 * (lj * LW + li);
-                atomicAdd(t, c0);
-                atomicAdd(t + 1, c1);
-                atomicAdd(t + 2, c2);
-                atomicAdd(t + 3, c3);
+                double* t = tile + 4 * (lj * LW + li);
+                atomicAdd(t, static_cast<double>(c0));
+                atomicAdd(t + 1, static_cast<double>(c1));
+                atomicAdd(t + 2, static_cast<double>(c2));
+                atomicAdd(t + 3, static_cast<double>(c3));
             } else {
                 T* g = cell_sums + 4 * (static_cast<size_t>(ic) + gw * jc);
                 atomicAdd(g, c0);
@@ -344,14 +494,14 @@ __global__ __launch_bounds__(256) void cell_sums_kernel(ParticleArrays<T> p, int
     __syncthreads();
     // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
     // global addresses, so a wave's atomic is one 256-byte piece
-    for (int k = threadIdx.x; k < LW * LW * 4; k += 256) {
-        const T v = tile[k];
-        if (v == static_cast<T>(0)) continue;
+    for (int k = threadIdx.x; k < LW * LW * 4; k += BS) {
+        const double v = tile[k];
+        if (v == 0.0) continue;
         const int lj = k / (LW * 4);
         const int rem = k - lj * (LW * 4);
         const int gi = i0 + (rem >> 2), gj = j0 + lj;
         if (gi < 0 || gi > nr || gj < 0 || gj > nz) continue;
-        atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), v);
+        atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(v));
     }
     if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
 }
