@@ -5,6 +5,7 @@
 // There is no CPU fallback in this file or anywhere in the library: a handle
 // cannot be created without a gfx950 device.
 #include "fpic_kernels.hpp"
+#include "fpic_push.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -44,7 +45,9 @@ struct fpic_handle {
     hipStream_t stream = nullptr;
     std::string err;
 
-    // particle state, two sets (binning is out of place), cur selects the live one
+    // particle state, two sets (binning is out of place), cur selects the live one;
+    // the ten arrays of a set are consecutive pieces of one slab, n_pad elements each
+    void* slab[2] = {};
     void* part[2][10] = {};
     uint8_t* alive[2] = {};
     uint32_t* id[2] = {};
@@ -330,7 +333,9 @@ template <typename T>
 int launch_push(fpic_handle* h, int nsub)
 {
     PushArgs<T> a;
-    a.p = arrays<T>(h, h->cur);
+    a.slab = static_cast<T*>(h->slab[h->cur]);
+    a.stride = h->n_pad;
+    a.alive = h->alive[h->cur];
     a.coef = static_cast<const T*>(h->coef);
     a.sink_alive = h->sink_alive;
     a.inv_cdf_xy = static_cast<const T*>(h->inv_cdf_xy);
@@ -481,8 +486,8 @@ template <typename T>
 int create_state(fpic_handle* h)
 {
     for (int s = 0; s < 2; ++s) {
-        for (int a = 0; a < 10; ++a)
-            if (int rc = dev_alloc(h, &h->part[s][a], h->n_pad * sizeof(T), &h->bytes_particles)) return rc;
+        if (int rc = dev_alloc(h, &h->slab[s], 10 * h->n_pad * sizeof(T), &h->bytes_particles)) return rc;
+        for (int a = 0; a < 10; ++a) h->part[s][a] = static_cast<T*>(h->slab[s]) + a * h->n_pad;
         if (int rc = dev_alloc(h, reinterpret_cast<void**>(&h->alive[s]), h->n_pad, &h->bytes_particles)) return rc;
         if (int rc = dev_alloc(h, reinterpret_cast<void**>(&h->id[s]), h->n_pad * sizeof(uint32_t), &h->bytes_particles)) return rc;
     }
@@ -537,7 +542,7 @@ void release(fpic_handle* h)
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (int s = 0; s < 2; ++s) {
-        for (int a = 0; a < 10; ++a) if (h->part[s][a]) (void)hipFree(h->part[s][a]);
+        if (h->slab[s]) (void)hipFree(h->slab[s]);
         if (h->alive[s]) (void)hipFree(h->alive[s]);
         if (h->id[s]) (void)hipFree(h->id[s]);
     }

@@ -51,10 +51,11 @@ struct BlockWork {
 template <typename T>
 __device__ __forceinline__ int ngp(T u, int W)
 {
+    // branch-free: fmax drops a NaN (-> 0), the upper clamp at W-1 equals floor's result
+    // for every t in [W-1, W) and clamps everything above (W-1 is exact in T for W <= 2^24)
     const T t = u * static_cast<T>(W);
-    if (!(t >= static_cast<T>(0))) return 0;
-    if (t >= static_cast<T>(W)) return W - 1;
-    return static_cast<int>(t);
+    if constexpr (sizeof(T) == 4) return static_cast<int>(fminf(fmaxf(t, 0.0f), static_cast<float>(W - 1)));
+    else return static_cast<int>(fmin(fmax(t, 0.0), static_cast<double>(W - 1)));
 }
 
 template <typename T>
@@ -97,306 +98,6 @@ __device__ __forceinline__ void store_lane(T* arr, size_t base, const T (&o)[N])
     if constexpr (N == 4) { v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3]; }
     else { v.x = o[0]; v.y = o[1]; }
     __builtin_nontemporal_store(v, reinterpret_cast<V*>(arr + base));
-}
-
-// ------------------------------------------------------------------ push (K3 + K1 + K2)
-
-template <typename T>
-struct PushArgs {
-    ParticleArrays<T> p;
-    const T* coef;
-    const uint8_t* sink_alive;
-    const T* inv_cdf_xy;
-    const T* entropy;
-    int nr, nz;
-    T step_factor;
-    unsigned long long n;
-    int nsub;
-};
-
-template <typename T>
-struct Particle {
-    T x, y, z, vx, vy, vz, u1, u2, c1, c2;
-    bool alive;
-};
-
-// One leap-frog sub-step of one particle: step_velocity_frag (empic.js:749-773), then
-// step_position_frag on the NEW velocity (empic.js:714-719), both reading the OLD
-// random state, then the random state's own advance (empic.js:800-807).  This is the
-// order of bindings in out.step (empic.js:815-853, :890-928).
-// Where a sub-step reads the per-cell tables from.  GlobalTables: straight from HBM/L2
-// (any particle order).  WindowTables: the tile's window staged in LDS by the
-// workgroup, falling back to global memory for a particle outside the window.
-template <typename T>
-struct GlobalTables {
-    const T* coef;
-    const uint8_t* sink_alive;
-    int nr;
-    __device__ __forceinline__ void coefficients(int ci, int cj, T (&R1)[4], T (&R2)[4], T (&R3)[4]) const
-    {
-        const T* cf = coef + 12 * (static_cast<size_t>(ci) + static_cast<size_t>(nr) * cj);
-        load4(cf, R1);
-        load4(cf + 4, R2);
-        load4(cf + 8, R3);
-    }
-    __device__ __forceinline__ bool keep(int ci, int cj) const
-    {
-        return sink_alive[static_cast<size_t>(ci) + static_cast<size_t>(nr) * cj] != 0;
-    }
-};
-
-constexpr int kPushHalo = 4;                           // cells staged around a tile for the push
-constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
-constexpr int kPushThreads = 512;
-template <typename T>
-constexpr size_t push_lds_bytes() { return static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1); }
-
-// LDS pointers carry their address space in the type: through a generic pointer the
-// compiler emits flat_load instead of ds_read_b128.
-#define FPIC_LDS __attribute__((address_space(3)))
-
-// (HIP's float4/double2 classes cannot live in an address space; clang's native vectors can)
-typedef float lds_f32x4 __attribute__((ext_vector_type(4)));
-typedef double lds_f64x2 __attribute__((ext_vector_type(2)));
-template <typename T> struct LdsVec16;
-template <> struct LdsVec16<float> { using type = lds_f32x4; };
-template <> struct LdsVec16<double> { using type = lds_f64x2; };
-
-template <typename T>
-__device__ __forceinline__ void load4_lds(const FPIC_LDS T* p, T (&o)[4])
-{
-    if constexpr (sizeof(T) == 4) {
-        const lds_f32x4 v = *reinterpret_cast<const FPIC_LDS lds_f32x4*>(p);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    } else {
-        const lds_f64x2 a = *reinterpret_cast<const FPIC_LDS lds_f64x2*>(p);
-        const lds_f64x2 b = *reinterpret_cast<const FPIC_LDS lds_f64x2*>(p + 2);
-        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
-    }
-}
-
-template <typename T>
-struct WindowTables {
-    GlobalTables<T> g;
-    const FPIC_LDS T* lcoef;          // [kPushLds*kPushLds][12]
-    const FPIC_LDS uint8_t* lsink;    // [kPushLds*kPushLds]
-    int i0, j0;
-    __device__ __forceinline__ void coefficients(int ci, int cj, T (&R1)[4], T (&R2)[4], T (&R3)[4]) const
-    {
-        const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
-        if (li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds)) {
-            const FPIC_LDS T* cf = lcoef + 12 * (lj * kPushLds + li);
-            load4_lds(cf, R1);
-            load4_lds(cf + 4, R2);
-            load4_lds(cf + 8, R3);
-        } else {
-            g.coefficients(ci, cj, R1, R2, R3);
-        }
-    }
-    __device__ __forceinline__ bool keep(int ci, int cj) const
-    {
-        const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
-        if (li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds)) return lsink[lj * kPushLds + li] != 0;
-        return g.keep(ci, cj);
-    }
-};
-
-template <typename T, typename Tables>
-__device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, const Tables& tab)
-{
-    // entropy texel for the random advance depends on nothing below: issue it first
-    const int et = ngp(q.c1, kEntropySide) + kEntropySide * ngp(q.c2, kEntropySide);
-    T s[4];
-    load4(a.entropy + 4 * static_cast<size_t>(et), s);
-
-    // K1: velocity in local cylindrical components, v' = R v + A at the nearest cell
-    const T r = sqrt_(q.x * q.x + q.y * q.y);
-    const T dx = q.x / r, dy = q.y / r;
-    const T vr = q.vx * dx + q.vy * dy;
-    const T va = q.vy * dx - q.vx * dy;
-    T R1[4], R2[4], R3[4];
-    tab.coefficients(ngp(r, a.nr), ngp(q.z, a.nz), R1, R2, R3);
-    const T cx = ((R1[0] * vr + R1[1] * va) + R1[2] * q.vz) + R1[3];
-    const T cy = ((R2[0] * vr + R2[1] * va) + R2[2] * q.vz) + R2[3];
-    const T cz = ((R3[0] * vr + R3[1] * va) + R3[2] * q.vz) + R3[3];
-    T nvx = cx * dx - cy * dy;
-    T nvy = cx * dy + cy * dx;
-    T nvz = cz;
-    if (!q.alive) { // re-injected on the previous sub-step (empic.js:772, quirk Q4)
-        nvx = static_cast<T>(0.001) * (static_cast<T>(2) * q.u1 - static_cast<T>(1));
-        nvy = static_cast<T>(0.001) * (static_cast<T>(2) * q.u2 - static_cast<T>(1));
-        nvz = static_cast<T>(0.001) * (static_cast<T>(2) * q.c1 - static_cast<T>(1));
-    }
-
-    // K2: drift, boundary test, re-injection from the inverse-CDF table
-    const T nx = q.x + a.step_factor * nvx;
-    const T ny = q.y + a.step_factor * nvy;
-    const T nzp = q.z + a.step_factor * nvz;
-    const T r2 = sqrt_(nx * nx + ny * ny);
-    const bool keep = tab.keep(ngp(r2, a.nr), ngp(nzp, a.nz));
-    if (keep) {
-        q.x = nx; q.y = ny; q.z = nzp;
-    } else {
-        const int t = ngp(q.u1, kCdfSide) + kCdfSide * ngp(q.u2, kCdfSide);
-        q.x = a.inv_cdf_xy[2 * static_cast<size_t>(t)];
-        q.y = static_cast<T>(0);
-        q.z = a.inv_cdf_xy[2 * static_cast<size_t>(t) + 1];
-    }
-    q.alive = keep;
-    q.vx = nvx; q.vy = nvy; q.vz = nvz;
-
-    // K3: additive walk on (u1,u2), logistic map on (c1,c2) (quirk Q5: m == 1 stays 1)
-    const T x0 = static_cast<T>(0.999) * q.c1 + static_cast<T>(0.001) * s[2];
-    const T x1 = static_cast<T>(0.999) * q.c2 + static_cast<T>(0.001) * s[3];
-    const T m0 = q.u1 + s[0], m1 = q.u2 + s[1];
-    q.u1 = (m0 > static_cast<T>(1)) ? m0 - static_cast<T>(1) : m0;
-    q.u2 = (m1 > static_cast<T>(1)) ? m1 - static_cast<T>(1) : m1;
-    q.c1 = static_cast<T>(4) * x0 * (static_cast<T>(1) - x0);
-    q.c2 = static_cast<T>(4) * x1 * (static_cast<T>(1) - x1);
-}
-
-// out.step (empic.js:1436-1469) fused: nsub = 2 * ncalls sub-steps per launch, state
-// held in registers between them.  Traffic per launch: one read and one write of
-// the particle state (10 T + 1 byte each way) however many sub-steps are taken.
-// One lane owns the PPT consecutive particles starting at `base` (one 16-byte vector
-// per array); cnt < PPT only for the last lane of the population.
-template <typename T, typename Tables>
-__device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& tab, size_t base, int cnt)
-{
-    constexpr int PPT = Vec16<T>::N;
-    T x[PPT], y[PPT], z[PPT], vx[PPT], vy[PPT], vz[PPT], u1[PPT], u2[PPT], c1[PPT], c2[PPT];
-    uint8_t al[PPT];
-    // arrays are padded to a multiple of the vector width, so the vector load is in bounds
-    load_lane<T, PPT>(a.p.x, base, x);
-    load_lane<T, PPT>(a.p.y, base, y);
-    load_lane<T, PPT>(a.p.z, base, z);
-    load_lane<T, PPT>(a.p.vx, base, vx);
-    load_lane<T, PPT>(a.p.vy, base, vy);
-    load_lane<T, PPT>(a.p.vz, base, vz);
-    load_lane<T, PPT>(a.p.u1, base, u1);
-    load_lane<T, PPT>(a.p.u2, base, u2);
-    load_lane<T, PPT>(a.p.c1, base, c1);
-    load_lane<T, PPT>(a.p.c2, base, c2);
-    if constexpr (PPT == 4) {
-        const uchar4 v = *reinterpret_cast<const uchar4*>(a.p.alive + base);
-        al[0] = v.x; al[1] = v.y; al[2] = v.z; al[3] = v.w;
-    } else {
-        const uchar2 v = *reinterpret_cast<const uchar2*>(a.p.alive + base);
-        al[0] = v.x; al[1] = v.y;
-    }
-
-    Particle<T> q[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        q[k].x = x[k]; q[k].y = y[k]; q[k].z = z[k];
-        q[k].vx = vx[k]; q[k].vy = vy[k]; q[k].vz = vz[k];
-        q[k].u1 = u1[k]; q[k].u2 = u2[k]; q[k].c1 = c1[k]; q[k].c2 = c2[k];
-        q[k].alive = al[k] != 0;
-        if (k >= cnt) { // padding lanes: keep every gather in range, results are discarded
-            q[k].x = static_cast<T>(0.5); q[k].y = static_cast<T>(0); q[k].z = static_cast<T>(0.5);
-            q[k].vx = q[k].vy = q[k].vz = static_cast<T>(0);
-            q[k].u1 = q[k].u2 = q[k].c1 = q[k].c2 = static_cast<T>(0.5);
-        }
-    }
-    for (int s = 0; s < a.nsub; ++s) {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
-    }
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        x[k] = q[k].x; y[k] = q[k].y; z[k] = q[k].z;
-        vx[k] = q[k].vx; vy[k] = q[k].vy; vz[k] = q[k].vz;
-        u1[k] = q[k].u1; u2[k] = q[k].u2; c1[k] = q[k].c1; c2[k] = q[k].c2;
-        al[k] = q[k].alive ? 1 : 0;
-    }
-    if (cnt == PPT) {
-        store_lane<T, PPT>(a.p.x, base, x);
-        store_lane<T, PPT>(a.p.y, base, y);
-        store_lane<T, PPT>(a.p.z, base, z);
-        store_lane<T, PPT>(a.p.vx, base, vx);
-        store_lane<T, PPT>(a.p.vy, base, vy);
-        store_lane<T, PPT>(a.p.vz, base, vz);
-        store_lane<T, PPT>(a.p.u1, base, u1);
-        store_lane<T, PPT>(a.p.u2, base, u2);
-        store_lane<T, PPT>(a.p.c1, base, c1);
-        store_lane<T, PPT>(a.p.c2, base, c2);
-        if constexpr (PPT == 4) {
-            *reinterpret_cast<uchar4*>(a.p.alive + base) = make_uchar4(al[0], al[1], al[2], al[3]);
-        } else {
-            *reinterpret_cast<uchar2*>(a.p.alive + base) = make_uchar2(al[0], al[1]);
-        }
-    } else {
-        for (int k = 0; k < cnt; ++k) {
-            a.p.x[base + k] = x[k]; a.p.y[base + k] = y[k]; a.p.z[base + k] = z[k];
-            a.p.vx[base + k] = vx[k]; a.p.vy[base + k] = vy[k]; a.p.vz[base + k] = vz[k];
-            a.p.u1[base + k] = u1[k]; a.p.u2[base + k] = u2[k];
-            a.p.c1[base + k] = c1[k]; a.p.c2[base + k] = c2[k];
-            a.p.alive[base + k] = al[k];
-        }
-    }
-}
-
-// Flat form: any particle order, tables read from global memory.  Used until the
-// particles have been binned.
-template <typename T>
-__global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
-{
-    constexpr int PPT = Vec16<T>::N;
-    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
-    if (base >= a.n) return;
-    const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
-    GlobalTables<T> tab{ a.coef, a.sink_alive, a.nr };
-    push_lane<T>(a, tab, base, cnt);
-}
-
-// Tiled form, for binned particles: one workgroup per chunk of one tile's particles
-// (the scatter's work list).  It first stages the tile's coefficient records and sink
-// bytes, plus a 4-cell halo, in LDS; a lane then reads a particle's record with three
-// ds_read_b128 instead of three divergent global loads (the L1 serves about one
-// distinct line per clock per CU, which cost 1.4 ms of the flat kernel's 4.5 ms at
-// 1e8 particles; profiles/r01_push_ablation.txt).  A particle that has drifted
-// outside the window reads global memory; results never depend on the binning.
-// Chunks are cut at arbitrary particle indices; a vector of PPT particles belongs
-// to the chunk that holds its first particle.
-template <typename T>
-__global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, int ntx, const BlockWork* __restrict__ work,
-                                                                  const uint32_t* __restrict__ nwork)
-{
-    constexpr int PPT = Vec16<T>::N;
-    constexpr int LW = kPushLds;
-    extern __shared__ __attribute__((aligned(16))) unsigned char push_lds[];
-    FPIC_LDS T* lcoef = (FPIC_LDS T*)push_lds;
-    FPIC_LDS uint8_t* lsink = (FPIC_LDS uint8_t*)push_lds + static_cast<size_t>(LW) * LW * 12 * sizeof(T);
-    if (blockIdx.x >= *nwork) return;
-    const BlockWork w = work[blockIdx.x];
-    const int i0 = static_cast<int>(w.tile % ntx) * kTileSide - kPushHalo;
-    const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kPushHalo;
-    // stage: one 16-byte piece (a third or a sixth of a record) per lane and iteration
-    constexpr int PIECES = static_cast<int>(12 * sizeof(T) / 16);
-    for (int k = threadIdx.x; k < LW * LW * PIECES; k += kPushThreads) {
-        const int c = k / PIECES, part = k - c * PIECES;
-        const int lj = c / LW, li = c - lj * LW;
-        const int gi = i0 + li, gj = j0 + lj;
-        using V = typename LdsVec16<T>::type;
-        V v = {};
-        if (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz)
-            v = *reinterpret_cast<const V*>(a.coef + 12 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj) + part * Vec16<T>::N);
-        *reinterpret_cast<FPIC_LDS V*>(lcoef + 12 * c + part * Vec16<T>::N) = v;
-    }
-    for (int c = threadIdx.x; c < LW * LW; c += kPushThreads) {
-        const int lj = c / LW, li = c - lj * LW;
-        const int gi = i0 + li, gj = j0 + lj;
-        lsink[c] = (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz) ? a.sink_alive[static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj] : 0;
-    }
-    __syncthreads();
-    WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
-    const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
-    const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
-    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
-        const size_t base = g * PPT;
-        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
-        push_lane<T>(a, tab, base, cnt);
-    }
 }
 
 // ------------------------------------------------------------------ scatter (K4), stage 1

@@ -1,0 +1,308 @@
+// fpic_push.hpp — the particle push: out.step (empic.js:1436-1469) as one kernel.
+//
+// One launch takes nsub = 2*ncalls leap-frog sub-steps.  A sub-step of one particle is
+// step_velocity_frag (empic.js:749-773), then step_position_frag on the NEW velocity
+// (empic.js:714-719), both reading the OLD random state, then the random state's own
+// advance (empic.js:800-807) — the order of bindings in out.step (empic.js:815-853,
+// :890-928).  The particle's state stays in registers between sub-steps, so the
+// traffic per launch is one read and one write of 10 T + 1 byte per particle however
+// many sub-steps are taken.
+//
+// Expression order follows the shader text (-ffp-contract=off, correctly rounded sqrt
+// and divide): float results are bit-identical to the CPU oracle.  The radius and
+// the nearest cell found by the boundary test of one sub-step ARE the radius and cell
+// the next sub-step's velocity pass would recompute from the same position, so they
+// are carried over instead (one sqrt and two NGP evaluations per sub-step instead
+// of two and four).
+#pragma once
+
+#include "fpic_kernels.hpp"
+
+namespace fpic {
+
+template <typename T>
+struct PushArgs {
+    T* slab;               // 10 arrays x,y,z,vx,vy,vz,u1,u2,c1,c2, each `stride` elements
+    size_t stride;
+    uint8_t* alive;
+    const T* coef;
+    const uint8_t* sink_alive;
+    const T* inv_cdf_xy;
+    const T* entropy;
+    int nr, nz;
+    T step_factor;
+    unsigned long long n;
+    int nsub;              // even: two sub-steps per step() call
+};
+
+template <typename T>
+struct Particle {
+    T x, y, z, vx, vy, vz, u1, u2, c1, c2;
+    T r;        // sqrt(x*x + y*y) of the current position
+    int ci, cj; // NGP cell of (r, z)
+    bool alive;
+};
+
+// Where a sub-step reads the per-cell tables from.  GlobalTables: straight from
+// L2/HBM (any particle order).  WindowTables: the tile's window staged in LDS by the
+// workgroup, with global memory behind it for a particle outside the window.
+template <typename T>
+struct GlobalTables {
+    const T* coef;
+    const uint8_t* sink_alive;
+    int nr;
+    __device__ __forceinline__ void coefficients(int ci, int cj, T (&R1)[4], T (&R2)[4], T (&R3)[4]) const
+    {
+        const T* cf = coef + 12u * (static_cast<unsigned>(ci) + static_cast<unsigned>(nr) * static_cast<unsigned>(cj));
+        load4(cf, R1);
+        load4(cf + 4, R2);
+        load4(cf + 8, R3);
+    }
+    __device__ __forceinline__ bool keep(int ci, int cj) const
+    {
+        return sink_alive[static_cast<unsigned>(ci) + static_cast<unsigned>(nr) * static_cast<unsigned>(cj)] != 0;
+    }
+};
+
+constexpr int kPushHalo = 4;                           // cells staged around a tile for the push
+constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
+constexpr int kPushThreads = 512;
+template <typename T>
+constexpr size_t push_lds_bytes() { return static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1); }
+
+// LDS pointers carry their address space in the type: through a generic pointer the
+// compiler emits flat_load instead of ds_read_b128.  (HIP's float4/double2 classes
+// cannot live in an address space; clang's native vectors can.)
+#define FPIC_LDS __attribute__((address_space(3)))
+template <typename T>
+__device__ __forceinline__ void load4_lds(const FPIC_LDS T* p, T (&o)[4])
+{
+    using V = typename NatVec16<T>::type;
+    if constexpr (sizeof(T) == 4) {
+        const V v = *reinterpret_cast<const FPIC_LDS V*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+        const V a = *reinterpret_cast<const FPIC_LDS V*>(p);
+        const V b = *reinterpret_cast<const FPIC_LDS V*>(p + 2);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    }
+}
+
+template <typename T>
+struct WindowTables {
+    GlobalTables<T> g;
+    const FPIC_LDS T* lcoef;          // [kPushLds*kPushLds][12]
+    const FPIC_LDS uint8_t* lsink;    // [kPushLds*kPushLds]
+    int i0, j0;
+    // The LDS read is unconditional (index 0 stands in for a cell outside the window);
+    // only lanes outside the window, rare between binnings, run the global loads.
+    __device__ __forceinline__ void coefficients(int ci, int cj, T (&R1)[4], T (&R2)[4], T (&R3)[4]) const
+    {
+        const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
+        const bool in = li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds);
+        const FPIC_LDS T* cf = lcoef + 12u * (in ? lj * kPushLds + li : 0u);
+        load4_lds(cf, R1);
+        load4_lds(cf + 4, R2);
+        load4_lds(cf + 8, R3);
+        if (!in) g.coefficients(ci, cj, R1, R2, R3);
+    }
+    __device__ __forceinline__ bool keep(int ci, int cj) const
+    {
+        const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
+        const bool in = li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds);
+        bool k = lsink[in ? lj * kPushLds + li : 0u] != 0;
+        if (!in) k = g.keep(ci, cj);
+        return k;
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void locate(Particle<T>& q, int nr, int nz)
+{
+    q.r = sqrt_(q.x * q.x + q.y * q.y);
+    q.ci = ngp(q.r, nr);
+    q.cj = ngp(q.z, nz);
+}
+
+template <typename T, typename Tables>
+__device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, const Tables& tab)
+{
+    // K3's entropy texel depends on nothing below: issue it first
+    const unsigned et = static_cast<unsigned>(ngp(q.c1, kEntropySide)) + static_cast<unsigned>(kEntropySide) * static_cast<unsigned>(ngp(q.c2, kEntropySide));
+    T s[4];
+    load4(a.entropy + 4u * et, s);
+
+    // K1: velocity in local cylindrical components, v' = R v + A at the nearest cell
+    const T dx = q.x / q.r, dy = q.y / q.r;
+    const T vr = q.vx * dx + q.vy * dy;
+    const T va = q.vy * dx - q.vx * dy;
+    T R1[4], R2[4], R3[4];
+    tab.coefficients(q.ci, q.cj, R1, R2, R3);
+    const T cx = ((R1[0] * vr + R1[1] * va) + R1[2] * q.vz) + R1[3];
+    const T cy = ((R2[0] * vr + R2[1] * va) + R2[2] * q.vz) + R2[3];
+    const T cz = ((R3[0] * vr + R3[1] * va) + R3[2] * q.vz) + R3[3];
+    T nvx = cx * dx - cy * dy;
+    T nvy = cx * dy + cy * dx;
+    T nvz = cz;
+    if (!q.alive) { // re-injected on the previous sub-step (empic.js:772, quirk Q4)
+        nvx = static_cast<T>(0.001) * (static_cast<T>(2) * q.u1 - static_cast<T>(1));
+        nvy = static_cast<T>(0.001) * (static_cast<T>(2) * q.u2 - static_cast<T>(1));
+        nvz = static_cast<T>(0.001) * (static_cast<T>(2) * q.c1 - static_cast<T>(1));
+    }
+    q.vx = nvx; q.vy = nvy; q.vz = nvz;
+
+    // K2: drift, boundary test at the new position's nearest cell
+    q.x = q.x + a.step_factor * nvx;
+    q.y = q.y + a.step_factor * nvy;
+    q.z = q.z + a.step_factor * nvz;
+    locate(q, a.nr, a.nz);
+    q.alive = tab.keep(q.ci, q.cj);
+    if (!q.alive) { // lost: re-inject from the inverse-CDF table on the plane y = 0 (empic.js:719)
+        const unsigned t = static_cast<unsigned>(ngp(q.u1, kCdfSide)) + static_cast<unsigned>(kCdfSide) * static_cast<unsigned>(ngp(q.u2, kCdfSide));
+        q.x = a.inv_cdf_xy[2u * t];
+        q.y = static_cast<T>(0);
+        q.z = a.inv_cdf_xy[2u * t + 1];
+        locate(q, a.nr, a.nz);
+    }
+
+    // K3: additive walk on (u1,u2), logistic map on (c1,c2) (quirk Q5: m == 1 stays 1)
+    const T x0 = static_cast<T>(0.999) * q.c1 + static_cast<T>(0.001) * s[2];
+    const T x1 = static_cast<T>(0.999) * q.c2 + static_cast<T>(0.001) * s[3];
+    const T m0 = q.u1 + s[0], m1 = q.u2 + s[1];
+    q.u1 = (m0 > static_cast<T>(1)) ? m0 - static_cast<T>(1) : m0;
+    q.u2 = (m1 > static_cast<T>(1)) ? m1 - static_cast<T>(1) : m1;
+    q.c1 = static_cast<T>(4) * x0 * (static_cast<T>(1) - x0);
+    q.c2 = static_cast<T>(4) * x1 * (static_cast<T>(1) - x1);
+}
+
+// One lane owns the PPT consecutive particles starting at `base` (one 16-byte vector
+// per array); cnt < PPT only for the last lane of the population.
+template <typename T, typename Tables>
+__device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& tab, size_t base, int cnt)
+{
+    constexpr int PPT = Vec16<T>::N;
+    T v[10][PPT];
+    uint8_t al[PPT];
+    // arrays are padded to a multiple of the vector width, so the vector load is in bounds
+#pragma unroll
+    for (int f = 0; f < 10; ++f) load_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+    if constexpr (PPT == 4) {
+        const uchar4 b = *reinterpret_cast<const uchar4*>(a.alive + base);
+        al[0] = b.x; al[1] = b.y; al[2] = b.z; al[3] = b.w;
+    } else {
+        const uchar2 b = *reinterpret_cast<const uchar2*>(a.alive + base);
+        al[0] = b.x; al[1] = b.y;
+    }
+
+    Particle<T> q[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        q[k].x = v[0][k]; q[k].y = v[1][k]; q[k].z = v[2][k];
+        q[k].vx = v[3][k]; q[k].vy = v[4][k]; q[k].vz = v[5][k];
+        q[k].u1 = v[6][k]; q[k].u2 = v[7][k]; q[k].c1 = v[8][k]; q[k].c2 = v[9][k];
+        q[k].alive = al[k] != 0;
+        if (k >= cnt) { // padding lanes: keep every gather in range, results are discarded
+            q[k].x = static_cast<T>(0.5); q[k].y = static_cast<T>(0); q[k].z = static_cast<T>(0.5);
+            q[k].vx = q[k].vy = q[k].vz = static_cast<T>(0);
+            q[k].u1 = q[k].u2 = q[k].c1 = q[k].c2 = static_cast<T>(0.5);
+        }
+        locate(q[k], a.nr, a.nz);
+    }
+    for (int s = 0; s < a.nsub; s += 2) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        v[0][k] = q[k].x; v[1][k] = q[k].y; v[2][k] = q[k].z;
+        v[3][k] = q[k].vx; v[4][k] = q[k].vy; v[5][k] = q[k].vz;
+        v[6][k] = q[k].u1; v[7][k] = q[k].u2; v[8][k] = q[k].c1; v[9][k] = q[k].c2;
+        al[k] = q[k].alive ? 1 : 0;
+    }
+    if (cnt == PPT) {
+#pragma unroll
+        for (int f = 0; f < 10; ++f) store_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+        if constexpr (PPT == 4) {
+            *reinterpret_cast<uchar4*>(a.alive + base) = make_uchar4(al[0], al[1], al[2], al[3]);
+        } else {
+            *reinterpret_cast<uchar2*>(a.alive + base) = make_uchar2(al[0], al[1]);
+        }
+    } else {
+        // fully unrolled: a runtime index into v[][] would move the whole array to scratch
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (k < cnt) {
+#pragma unroll
+                for (int f = 0; f < 10; ++f) a.slab[f * a.stride + base + k] = v[f][k];
+                a.alive[base + k] = al[k];
+            }
+        }
+    }
+}
+
+// Flat form: any particle order, tables read from global memory.  Used until the
+// particles have been binned.
+template <typename T>
+__global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
+{
+    constexpr int PPT = Vec16<T>::N;
+    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
+    if (base >= a.n) return;
+    const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+    GlobalTables<T> tab{ a.coef, a.sink_alive, a.nr };
+    push_lane<T>(a, tab, base, cnt);
+}
+
+// Tiled form, for binned particles: one workgroup per chunk of one tile's particles
+// (the scatter's work list).  It first stages the tile's coefficient records and sink
+// bytes, plus a 4-cell halo, in LDS; a lane then reads a particle's record with three
+// ds_read_b128 instead of three divergent global loads (the L1 serves about one
+// distinct line per clock per CU, which cost 1.4 ms of the flat kernel's 4.5 ms at
+// 1e8 particles; profiles/r01_push_ablation.txt).  A particle that has drifted
+// outside the window reads global memory; results never depend on the binning.
+// Chunks are cut at arbitrary particle indices; a vector of PPT particles belongs
+// to the chunk that holds its first particle.
+template <typename T>
+__global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, int ntx, const BlockWork* __restrict__ work,
+                                                                  const uint32_t* __restrict__ nwork)
+{
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int LW = kPushLds;
+    extern __shared__ __attribute__((aligned(16))) unsigned char push_lds[];
+    FPIC_LDS T* lcoef = (FPIC_LDS T*)push_lds;
+    FPIC_LDS uint8_t* lsink = (FPIC_LDS uint8_t*)push_lds + static_cast<size_t>(LW) * LW * 12 * sizeof(T);
+    if (blockIdx.x >= *nwork) return;
+    const BlockWork w = work[blockIdx.x];
+    const int i0 = static_cast<int>(w.tile % ntx) * kTileSide - kPushHalo;
+    const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kPushHalo;
+    // stage: one 16-byte piece (a third or a sixth of a record) per lane and iteration
+    constexpr int PIECES = static_cast<int>(12 * sizeof(T) / 16);
+    using V = typename NatVec16<T>::type;
+    for (int k = threadIdx.x; k < LW * LW * PIECES; k += kPushThreads) {
+        const int c = k / PIECES, part = k - c * PIECES;
+        const int lj = c / LW, li = c - lj * LW;
+        const int gi = i0 + li, gj = j0 + lj;
+        V val = {};
+        if (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz)
+            val = *reinterpret_cast<const V*>(a.coef + 12 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj) + part * Vec16<T>::N);
+        *reinterpret_cast<FPIC_LDS V*>(lcoef + 12 * c + part * Vec16<T>::N) = val;
+    }
+    for (int c = threadIdx.x; c < LW * LW; c += kPushThreads) {
+        const int lj = c / LW, li = c - lj * LW;
+        const int gi = i0 + li, gj = j0 + lj;
+        lsink[c] = (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz) ? a.sink_alive[static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj] : 0;
+    }
+    __syncthreads();
+    WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
+    const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
+    const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
+    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
+        const size_t base = g * PPT;
+        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+        push_lane<T>(a, tab, base, cnt);
+    }
+}
+
+} // namespace fpic

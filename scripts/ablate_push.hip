@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics \
 //         -I fusion-sim_amd/csrc scripts/ablate_push.hip -o /tmp/ablate_push && /tmp/ablate_push
 #include "fpic_kernels.hpp"
+#include "fpic_push.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -10,16 +11,25 @@
 
 using namespace fpic;
 
+struct ProbeArgs {
+    ParticleArrays<float> p;
+    const float* coef; const uint8_t* sink_alive; const float* inv_cdf_xy; const float* entropy;
+    int nr, nz; float step_factor; unsigned long long n; int nsub;
+};
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-enum { NO_ENTROPY = 1, NO_COEF = 2, NO_SINK = 4, FAST_MATH = 8, NO_STORE = 16, NO_RAND_IO = 32 };
+enum { NO_ENTROPY = 1, NO_COEF = 2, NO_SINK = 4, FAST_MATH = 8, NO_STORE = 16, NO_RAND_IO = 32, ENTROPY_1MB = 64, ENTROPY_16KB = 128, ENTROPY_4MB = 256 };
 
 template <int M>
-__device__ __forceinline__ void substep_v(Particle<float>& q, const PushArgs<float>& a)
+__device__ __forceinline__ void substep_v(Particle<float>& q, const ProbeArgs& a)
 {
     float s[4] = { 0.3f, 0.7f, 0.2f, 0.9f };
     if (!(M & NO_ENTROPY)) {
-        const int et = ngp(q.c1, kEntropySide) + kEntropySide * ngp(q.c2, kEntropySide);
+        int et = ngp(q.c1, kEntropySide) + kEntropySide * ngp(q.c2, kEntropySide);
+        if (M & ENTROPY_1MB) et &= 0xFFFF;      // timing only: 64K texels = 1 MB footprint
+        if (M & ENTROPY_4MB) et &= 0x3FFFF;     // 4 MB
+        if (M & ENTROPY_16KB) et &= 0x3FF;      // 16 KB
         load4(a.entropy + 4 * static_cast<size_t>(et), s);
     }
     float r, dx, dy;
@@ -62,7 +72,7 @@ __device__ __forceinline__ void substep_v(Particle<float>& q, const PushArgs<flo
 }
 
 template <int M, int BS>
-__global__ __launch_bounds__(BS) void push_v(PushArgs<float> a)
+__global__ __launch_bounds__(BS) void push_v(ProbeArgs a)
 {
     constexpr int PPT = 4;
     const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
@@ -142,7 +152,7 @@ __global__ void fill_k(float* p, size_t n, float lo, float hi)
 }
 
 template <int M, int BS>
-float run(PushArgs<float> a, int reps, ParticleArrays<float> p, int sorted, int grid)
+float run(ProbeArgs a, int reps, ParticleArrays<float> p, int sorted, int grid)
 {
     init_k<<<(a.n + 255) / 256, 256>>>(p, a.n, sorted, grid);
     hipEvent_t e0, e1;
@@ -176,7 +186,7 @@ int main(int argc, char** argv)
     fill_k<<<(512 * 512 * 2 + 255) / 256, 256>>>(inv, 512 * 512 * 2, 0.1f, 0.9f);
     fill_k<<<(1024 * 1024 * 4 + 255) / 256, 256>>>(ent, 1024 * 1024 * 4, 0.f, 1.f);
     CK(hipMemset(sink, 1, nc));
-    PushArgs<float> a;
+    ProbeArgs a;
     a.p = p; a.coef = coef; a.sink_alive = sink; a.inv_cdf_xy = inv; a.entropy = ent;
     a.nr = grid; a.nz = grid; a.step_factor = 0.5996f; a.n = n; a.nsub = 2;
     const int reps = 5;
@@ -191,6 +201,10 @@ int main(int argc, char** argv)
         printf("no gathers + fast math     %.3f ms\n", run<NO_ENTROPY | NO_COEF | NO_SINK | FAST_MATH, 256>(a, reps, p, sorted, grid));
         printf("no stores                  %.3f ms\n", run<NO_STORE, 256>(a, reps, p, sorted, grid));
         printf("no rand I/O (6 streams)    %.3f ms\n", run<NO_RAND_IO, 256>(a, reps, p, sorted, grid));
+        printf("no coef/sink (~LDS-staged) %.3f ms\n", run<NO_COEF | NO_SINK, 256>(a, reps, p, sorted, grid));
+        printf(" + entropy footprint 4 MB  %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_4MB, 256>(a, reps, p, sorted, grid));
+        printf(" + entropy footprint 1 MB  %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_1MB, 256>(a, reps, p, sorted, grid));
+        printf(" + entropy footprint 16 KB %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_16KB, 256>(a, reps, p, sorted, grid));
         printf("full, block 128            %.3f ms\n", run<0, 128>(a, reps, p, sorted, grid));
         printf("full, block 512            %.3f ms\n", run<0, 512>(a, reps, p, sorted, grid));
     }
