@@ -81,6 +81,7 @@ struct fpic_handle {
     size_t work_cap = 0;
     bool binned = false;
     int deposits_since_bin = 0;
+    bool sums_fresh = false; // cell_sums already holds the sums of the current particle state (fused push)
     // Particles that missed their LDS tile in a scatter, read back with a lag of two
     // scatters so that the host may run ahead of the GPU by at most two frames.
     unsigned long long* spilled = nullptr;      // device counter
@@ -329,6 +330,16 @@ int launch_precalc(fpic_handle* h)
     return FPIC_OK;
 }
 
+// queue the read-back of the scatter's spill counter into the next of the two lagged slots
+int record_spill(fpic_handle* h)
+{
+    const int slot = static_cast<int>(h->deposit_seq++ & 1);
+    HIP_TRY(h, hipMemcpyAsync(h->spilled_host + slot, h->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->spill_event[slot], h->stream));
+    h->spill_pending[slot] = true;
+    return FPIC_OK;
+}
+
 template <typename T>
 int launch_push(fpic_handle* h, int nsub)
 {
@@ -345,13 +356,30 @@ int launch_push(fpic_handle* h, int nsub)
     a.n = h->n;
     a.nsub = nsub;
     const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
+    // float state, binned, fusion not switched off: the push also forms the per-cell sums
+    const bool fuse = sizeof(T) == 4 && h->binned && !h->spec.unfused_deposit;
+    h->sums_fresh = false;
     timing_begin(h, KC_PUSH);
-    if (h->binned) // the work list of the last binning is valid until the next one: the push is in place
-        push_tiles_kernel<T><<<static_cast<unsigned>(h->work_cap), kPushThreads, push_lds_bytes<T>(), h->stream>>>(a, h->ntx, h->work, h->nwork);
-    else
+    if (fuse) {
+        if constexpr (sizeof(T) == 4) {
+            const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
+            HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
+            HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
+            push_tiles_kernel<T, true><<<static_cast<unsigned>(h->work_cap), kPushThreads, push_tiles_lds_bytes<T, true>(), h->stream>>>(
+                a, h->ntx, h->work, h->nwork, static_cast<T*>(h->cell_sums), h->spilled);
+        }
+    } else if (h->binned) { // the work list of the last binning is valid until the next one: the push is in place
+        push_tiles_kernel<T, false><<<static_cast<unsigned>(h->work_cap), kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(
+            a, h->ntx, h->work, h->nwork, nullptr, nullptr);
+    } else {
         push_kernel<T><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+    }
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
+    if (fuse) {
+        if (int rc = record_spill(h)) return rc;
+        h->sums_fresh = true;
+    }
     return FPIC_OK;
 }
 
@@ -389,11 +417,7 @@ int launch_cell_sums(fpic_handle* h)
         arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work, h->nwork, static_cast<T*>(h->cell_sums), h->spilled);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
-    const int slot = static_cast<int>(h->deposit_seq++ & 1);
-    HIP_TRY(h, hipMemcpyAsync(h->spilled_host + slot, h->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipEventRecord(h->spill_event[slot], h->stream));
-    h->spill_pending[slot] = true;
-    return FPIC_OK;
+    return record_spill(h);
 }
 
 template <typename T>
@@ -637,8 +661,9 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     // the scatter's LDS image (72 KiB of double accumulators) exceeds the 64 KiB static limit
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_lds_bytes<float>()))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_lds_bytes<double>()))) != hipSuccess)
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, false>()))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, true>()))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<double, false>()))) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e)));
 
     h->work_cap = (h->n + kDepositChunk - 1) / kDepositChunk + h->ntiles;
@@ -687,6 +712,7 @@ int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos,
                                    : upload_vec3<double, double>(h, static_cast<const double*>(src), first, fr, fz, al);
     }
     if (pos_aos) h->binned = false; // positions changed under the bins
+    if (pos_aos || vel_aos) h->sums_fresh = false;
     return rc;
 }
 
@@ -815,8 +841,10 @@ int fpic_deposit(fpic_handle* h)
     }
     if (rebin)
         if (int rc = fpic_sort(h)) return rc;
+    h->deposits_since_bin++;
+    if (h->sums_fresh) return FPIC_OK; // the last step() already summed this very state (fused push)
     const int rc = h->prec == FPIC_F32 ? launch_cell_sums<float>(h) : launch_cell_sums<double>(h);
-    if (rc == FPIC_OK) { h->deposit_launches++; h->deposits_since_bin++; }
+    if (rc == FPIC_OK) { h->deposit_launches++; h->sums_fresh = true; }
     return rc;
 }
 

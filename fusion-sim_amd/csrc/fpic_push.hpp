@@ -175,10 +175,56 @@ __device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, co
     q.c2 = static_cast<T>(4) * x1 * (static_cast<T>(1) - x1);
 }
 
+// What happens to a particle's final state besides being stored.  NoSums: nothing.
+// WindowSums: the scatter's stage 1 (programMoments01's vertex colour summed per
+// nearest cell, see fpic_kernels.hpp) fused into the push: the workgroup owns the
+// tile, the state is in registers and sqrt(x*x+y*y) has just been computed, so the
+// separate pass that re-reads 24 B per particle disappears.  Accumulators are double
+// in LDS (ds_add_f64; ds_add_f32 is 3.7x slower on gfx950).
+struct NoSums {
+    template <typename T>
+    __device__ __forceinline__ void add(const Particle<T>&, int, int) const {}
+};
+
+template <typename T>
+struct WindowSums {
+    FPIC_LDS double* lsums;   // [kTileLds*kTileLds][4]
+    int i0, j0;               // window origin (tile origin - kTileHalo)
+    T* cell_sums;             // global (nr+1) x (nz+1) x 4
+    unsigned* spilled;        // lane-local count of particles outside the window
+    __device__ __forceinline__ void add(const Particle<T>& q, int nr, int nz) const
+    {
+        // clip test and cell of the point sprite (deposit_cell), on the carried radius
+        if (!(q.r >= static_cast<T>(0) && q.r <= static_cast<T>(1) && q.z >= static_cast<T>(0) && q.z <= static_cast<T>(1))) return;
+        const int ic = static_cast<int>(q.r * static_cast<T>(nr));
+        const int jc = static_cast<int>(q.z * static_cast<T>(nz));
+        const T dx = q.x / q.r, dy = q.y / q.r;
+        const T c0 = static_cast<T>(0.001) * (q.vx * dx + q.vy * dy);
+        const T c1 = static_cast<T>(0.001) * (q.vy * dx - q.vx * dy);
+        const T c2 = static_cast<T>(0.001) * q.vz;
+        const T c3 = static_cast<T>(0.001) * static_cast<T>(1);
+        const unsigned li = static_cast<unsigned>(ic - i0), lj = static_cast<unsigned>(jc - j0);
+        if (li < static_cast<unsigned>(kTileLds) && lj < static_cast<unsigned>(kTileLds)) {
+            FPIC_LDS double* t = lsums + 4u * (lj * kTileLds + li);
+            __hip_atomic_fetch_add(t, static_cast<double>(c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(t + 1, static_cast<double>(c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(t + 2, static_cast<double>(c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(t + 3, static_cast<double>(c3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            T* g = cell_sums + 4 * (static_cast<size_t>(ic) + (static_cast<size_t>(nr) + 1) * jc);
+            atomicAdd(g, c0);
+            atomicAdd(g + 1, c1);
+            atomicAdd(g + 2, c2);
+            atomicAdd(g + 3, c3);
+            ++*spilled;
+        }
+    }
+};
+
 // One lane owns the PPT consecutive particles starting at `base` (one 16-byte vector
 // per array); cnt < PPT only for the last lane of the population.
-template <typename T, typename Tables>
-__device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& tab, size_t base, int cnt)
+template <typename T, typename Tables, typename Sums>
+__device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& tab, const Sums& sums, size_t base, int cnt)
 {
     constexpr int PPT = Vec16<T>::N;
     T v[10][PPT];
@@ -214,6 +260,9 @@ __device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& ta
 #pragma unroll
         for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
     }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (k < cnt) sums.add(q[k], a.nr, a.nz);
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         v[0][k] = q[k].x; v[1][k] = q[k].y; v[2][k] = q[k].z;
@@ -252,11 +301,11 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
     if (base >= a.n) return;
     const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
     GlobalTables<T> tab{ a.coef, a.sink_alive, a.nr };
-    push_lane<T>(a, tab, base, cnt);
+    push_lane<T>(a, tab, NoSums{}, base, cnt);
 }
 
 // Tiled form, for binned particles: one workgroup per chunk of one tile's particles
-// (the scatter's work list).  It first stages the tile's coefficient records and sink
+// (the binning's work list).  It first stages the tile's coefficient records and sink
 // bytes, plus a 4-cell halo, in LDS; a lane then reads a particle's record with three
 // ds_read_b128 instead of three divergent global loads (the L1 serves about one
 // distinct line per clock per CU, which cost 1.4 ms of the flat kernel's 4.5 ms at
@@ -264,19 +313,33 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
 // outside the window reads global memory; results never depend on the binning.
 // Chunks are cut at arbitrary particle indices; a vector of PPT particles belongs
 // to the chunk that holds its first particle.
+// FUSE_SUMS adds the scatter's stage 1 (WindowSums): a second LDS window, tile + 8-cell
+// halo of double accumulators, zeroed before and flushed with global float atomics in
+// 256-byte pieces after the chunk.  LDS: 76.8 + 1.6 (+ 73.7) KB for float.
 template <typename T>
+constexpr size_t push_sums_offset() { return (static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1) + 15) / 16 * 16; }
+template <typename T, bool FUSE_SUMS>
+constexpr size_t push_tiles_lds_bytes()
+{
+    return FUSE_SUMS ? push_sums_offset<T>() + static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double) : push_lds_bytes<T>();
+}
+
+template <typename T, bool FUSE_SUMS>
 __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, int ntx, const BlockWork* __restrict__ work,
-                                                                  const uint32_t* __restrict__ nwork)
+                                                                  const uint32_t* __restrict__ nwork, T* __restrict__ cell_sums,
+                                                                  unsigned long long* spilled)
 {
     constexpr int PPT = Vec16<T>::N;
     constexpr int LW = kPushLds;
+    constexpr int SW = kTileLds;
     extern __shared__ __attribute__((aligned(16))) unsigned char push_lds[];
     FPIC_LDS T* lcoef = (FPIC_LDS T*)push_lds;
     FPIC_LDS uint8_t* lsink = (FPIC_LDS uint8_t*)push_lds + static_cast<size_t>(LW) * LW * 12 * sizeof(T);
+    FPIC_LDS double* lsums = (FPIC_LDS double*)((FPIC_LDS unsigned char*)push_lds + push_sums_offset<T>());
     if (blockIdx.x >= *nwork) return;
     const BlockWork w = work[blockIdx.x];
-    const int i0 = static_cast<int>(w.tile % ntx) * kTileSide - kPushHalo;
-    const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kPushHalo;
+    const int ti0 = static_cast<int>(w.tile % ntx) * kTileSide, tj0 = static_cast<int>(w.tile / ntx) * kTileSide;
+    const int i0 = ti0 - kPushHalo, j0 = tj0 - kPushHalo;
     // stage: one 16-byte piece (a third or a sixth of a record) per lane and iteration
     constexpr int PIECES = static_cast<int>(12 * sizeof(T) / 16);
     using V = typename NatVec16<T>::type;
@@ -294,14 +357,36 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         const int gi = i0 + li, gj = j0 + lj;
         lsink[c] = (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz) ? a.sink_alive[static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj] : 0;
     }
+    if constexpr (FUSE_SUMS)
+        for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) lsums[k] = 0.0;
     __syncthreads();
     WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
+    unsigned my_spill = 0;
     const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
     const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
     for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
         const size_t base = g * PPT;
         const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
-        push_lane<T>(a, tab, base, cnt);
+        if constexpr (FUSE_SUMS)
+            push_lane<T>(a, tab, WindowSums<T>{ lsums, ti0 - kTileHalo, tj0 - kTileHalo, cell_sums, &my_spill }, base, cnt);
+        else
+            push_lane<T>(a, tab, NoSums{}, base, cnt);
+    }
+    if constexpr (FUSE_SUMS) {
+        __syncthreads();
+        // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
+        // global addresses, so a wave's atomic is one 256-byte piece
+        const size_t gw = static_cast<size_t>(a.nr) + 1;
+        for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) {
+            const double val = lsums[k];
+            if (val == 0.0) continue;
+            const int lj = k / (SW * 4);
+            const int rem = k - lj * (SW * 4);
+            const int gi = ti0 - kTileHalo + (rem >> 2), gj = tj0 - kTileHalo + lj;
+            if (gi < 0 || gi > a.nr || gj < 0 || gj > a.nz) continue;
+            atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(val));
+        }
+        if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
     }
 }
 

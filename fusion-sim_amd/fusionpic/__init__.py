@@ -47,7 +47,7 @@ class Spec(ctypes.Structure):
         ("dt", ctypes.c_double), ("nparticles", ctypes.c_int32), ("particle_mass", ctypes.c_double),
         ("particle_charge", ctypes.c_double), ("count", ctypes.c_uint64), ("precision", ctypes.c_int32),
         ("device", ctypes.c_int32), ("physical_a", ctypes.c_int32), ("sort_interval", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 8),
+        ("unfused_deposit", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7),
     ]
 
 
@@ -136,7 +136,8 @@ def _as_float_array(a):
 class CylindricalParticlePusher:
     """Object returned by makeCylindricalParticlePusher (empic.js:1528)."""
 
-    def __init__(self, spec, precision="fp32", device=0, count=0, compat=True, sort_interval=0, library=None):
+    def __init__(self, spec, precision="fp32", device=0, count=0, compat=True, sort_interval=0, fuse_deposit=True,
+                 library=None):
         _validate_spec(spec)
         self._lib = library or load_library()
         self.spec = dict(spec)
@@ -148,6 +149,7 @@ class CylindricalParticlePusher:
         s.device = int(device)
         s.physical_a = 0 if compat else 1
         s.sort_interval = int(sort_interval)
+        s.unfused_deposit = 0 if fuse_deposit else 1
         self.precision = s.precision
         self.nr, self.nz = int(spec["nr"]), int(spec["nz"])
         self.n = int(count) if count else int(spec["nparticles"]) ** 2

@@ -106,7 +106,10 @@ typedef struct fpic_spec {
     int32_t physical_a;     /* 0: reference's K9 formula incl. quirk Q1 (empic.js:645);
                                1: h(E.B)B vector form */
     int32_t sort_interval;  /* re-bin particles every k density() calls; 0 = adaptive */
-    int32_t reserved[8];
+    int32_t unfused_deposit;/* 1: step() does not also form the per-cell sums of density()'s
+                               scatter (by default it does: the frame loop of fusionsim.js:172-174
+                               always calls density() after step()) */
+    int32_t reserved[7];
 } fpic_spec;
 
 typedef struct fpic_handle fpic_handle;
