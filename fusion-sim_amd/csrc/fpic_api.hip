@@ -74,14 +74,19 @@ struct fpic_handle {
     int ntx = 0, ntz = 0;
     uint32_t ntiles = 0; // real tiles + 1 bin for clipped particles
     uint32_t* tile_count = nullptr;
-    uint32_t* tile_start = nullptr;
+    // two bin tables: [wl] describes the live particle order, [wl ^ 1] is laid out by the
+    // next binning (which may be the next push, see scatter_pending)
+    uint32_t* tile_start2[2] = {};
+    uint32_t* nwork2[2] = {};
+    BlockWork* work2[2] = {};
+    int wl = 0;
     uint32_t* tile_cursor = nullptr;
-    uint32_t* nwork = nullptr;
-    BlockWork* work = nullptr;
     size_t work_cap = 0;
     bool binned = false;
     int deposits_since_bin = 0;
-    bool sums_fresh = false; // cell_sums already holds the sums of the current particle state (fused push)
+    bool sums_fresh = false;      // cell_sums already holds the sums of the current particle state (fused push)
+    bool census_fresh = false;    // tile_count holds the census of the current particle state (fused push)
+    bool scatter_pending = false; // tables [wl ^ 1] are laid out from that census: the next push re-bins
     // Particles that missed their LDS tile in a scatter, read back with a lag of two
     // scatters so that the host may run ahead of the GPU by at most two frames.
     unsigned long long* spilled = nullptr;      // device counter
@@ -357,28 +362,48 @@ int launch_push(fpic_handle* h, int nsub)
     a.nsub = nsub;
     const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
     // float state, binned, fusion not switched off: the push also forms the per-cell sums
+    // and the tile census, and on a re-binning launch writes the sorted order itself
     const bool fuse = sizeof(T) == 4 && h->binned && !h->spec.unfused_deposit;
-    h->sums_fresh = false;
+    const bool scatter = fuse && h->scatter_pending;
+    TileArgs<T> t{};
+    t.ntx = h->ntx; t.ntz = h->ntz; t.ntiles = h->ntiles;
+    t.work = h->work2[h->wl]; t.nwork = h->nwork2[h->wl];
+    t.cell_sums = static_cast<T*>(h->cell_sums); t.spilled = h->spilled; t.tile_count = h->tile_count;
+    t.id = h->id[h->cur];
+    t.dst_slab = static_cast<T*>(h->slab[h->cur ^ 1]); t.dst_alive = h->alive[h->cur ^ 1]; t.dst_id = h->id[h->cur ^ 1];
+    t.dst_tile_start = h->tile_start2[h->wl ^ 1]; t.dst_tile_cursor = h->tile_cursor;
+    h->sums_fresh = h->census_fresh = false;
+    h->scatter_pending = false;
+    const unsigned grid = static_cast<unsigned>(h->work_cap);
     timing_begin(h, KC_PUSH);
     if (fuse) {
         if constexpr (sizeof(T) == 4) {
             const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
             HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
             HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
-            push_tiles_kernel<T, true><<<static_cast<unsigned>(h->work_cap), kPushThreads, push_tiles_lds_bytes<T, true>(), h->stream>>>(
-                a, h->ntx, h->work, h->nwork, static_cast<T*>(h->cell_sums), h->spilled);
+            HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
+            if (scatter) push_tiles_kernel<T, true, true><<<grid, kPushThreads, push_tiles_lds_bytes<T, true>(), h->stream>>>(a, t);
+            else push_tiles_kernel<T, true, false><<<grid, kPushThreads, push_tiles_lds_bytes<T, true>(), h->stream>>>(a, t);
         }
     } else if (h->binned) { // the work list of the last binning is valid until the next one: the push is in place
-        push_tiles_kernel<T, false><<<static_cast<unsigned>(h->work_cap), kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(
-            a, h->ntx, h->work, h->nwork, nullptr, nullptr);
+        push_tiles_kernel<T, false, false><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
     } else {
         push_kernel<T><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
     }
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     if (fuse) {
-        if (int rc = record_spill(h)) return rc;
-        h->sums_fresh = true;
+        h->sums_fresh = h->census_fresh = true;
+        if (scatter) { // this launch was the binning: the other set and the other tables are live now
+            h->cur ^= 1;
+            h->wl ^= 1;
+            h->deposits_since_bin = 0;
+            h->last_spill = 0;
+            h->spill_pending[0] = h->spill_pending[1] = false; // its own count was taken against the old windows
+            h->sort_passes++;
+        } else if (int rc = record_spill(h)) {
+            return rc;
+        }
     }
     return FPIC_OK;
 }
@@ -392,12 +417,16 @@ int launch_bin(fpic_handle* h)
     timing_begin(h, KC_SORT);
     HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
     bin_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_count);
-    bin_scan_kernel<<<1, 1024, 0, h->stream>>>(h->tile_count, h->ntiles, h->tile_start, h->tile_cursor, h->work, h->nwork);
-    bin_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_start,
+    const int nw = h->wl ^ 1;
+    bin_scan_kernel<<<1, 1024, 0, h->stream>>>(h->tile_count, h->ntiles, h->tile_start2[nw], h->tile_cursor, h->work2[nw], h->nwork2[nw]);
+    bin_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_start2[nw],
                                                        h->tile_cursor);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
+    h->wl = nw;
+    h->census_fresh = false; // tile_count now describes this binning, not a fused push
+    h->scatter_pending = false;
     h->binned = true;
     h->deposits_since_bin = 0;
     h->last_spill = 0;
@@ -414,7 +443,7 @@ int launch_cell_sums(fpic_handle* h)
     HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color [0,0,0,0] (empic.js:1476)
     HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
     cell_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), kSumsThreads, kSumsLdsBytes, h->stream>>>(
-        arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work, h->nwork, static_cast<T*>(h->cell_sums), h->spilled);
+        arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work2[h->wl], h->nwork2[h->wl], static_cast<T*>(h->cell_sums), h->spilled);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     return record_spill(h);
@@ -571,8 +600,8 @@ void release(fpic_handle* h)
         if (h->id[s]) (void)hipFree(h->id[s]);
     }
     void* bufs[] = { h->E, h->B, h->sink, h->sink_alive, h->inv_cdf_xy, h->entropy, h->coef, h->cell_sums, h->moments,
-                     h->norm, h->avg, h->stamp, h->shape_half, h->shape_tenth, h->tile_count, h->tile_start,
-                     h->tile_cursor, h->nwork, h->work, h->spilled };
+                     h->norm, h->avg, h->stamp, h->shape_half, h->shape_tenth, h->tile_count, h->tile_start2[0],
+                     h->tile_start2[1], h->tile_cursor, h->nwork2[0], h->nwork2[1], h->work2[0], h->work2[1], h->spilled };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->spilled_host) (void)hipHostFree(h->spilled_host);
     for (hipEvent_t e : h->spill_event) if (e) (void)hipEventDestroy(e);
@@ -661,18 +690,22 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     // the scatter's LDS image (72 KiB of double accumulators) exceeds the 64 KiB static limit
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, false>()))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, true>()))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<double, false>()))) != hipSuccess)
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, false>()))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, true>()))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, true>()))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<double, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<double, false>()))) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e)));
 
     h->work_cap = (h->n + kDepositChunk - 1) / kDepositChunk + h->ntiles;
     uint64_t* acc = &h->bytes_grid;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_count), sizeof(uint32_t) * h->ntiles, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_start), sizeof(uint32_t) * (h->ntiles + 1), acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_start2[0]), sizeof(uint32_t) * (h->ntiles + 1), acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_start2[1]), sizeof(uint32_t) * (h->ntiles + 1), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_cursor), sizeof(uint32_t) * h->ntiles, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->nwork), sizeof(uint32_t), acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work), sizeof(BlockWork) * h->work_cap, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->nwork2[0]), sizeof(uint32_t), acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->nwork2[1]), sizeof(uint32_t), acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work2[0]), sizeof(BlockWork) * h->work_cap, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work2[1]), sizeof(BlockWork) * h->work_cap, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->spilled), sizeof(unsigned long long), acc)))
         return bail(rc);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->spilled_host), 2 * sizeof(unsigned long long))) != hipSuccess ||
@@ -711,7 +744,10 @@ int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos,
             rc = dtype == FPIC_F32 ? upload_vec3<double, float>(h, static_cast<const float*>(src), first, fr, fz, al)
                                    : upload_vec3<double, double>(h, static_cast<const double*>(src), first, fr, fz, al);
     }
-    if (pos_aos) h->binned = false; // positions changed under the bins
+    if (pos_aos) { // positions changed under the bins
+        h->binned = false;
+        h->census_fresh = h->scatter_pending = false;
+    }
     if (pos_aos || vel_aos) h->sums_fresh = false;
     return rc;
 }
@@ -839,8 +875,21 @@ int fpic_deposit(fpic_handle* h)
             rebin = h->last_spill * 256 > h->n;
         }
     }
-    if (rebin)
-        if (int rc = fpic_sort(h)) return rc;
+    if (rebin) {
+        if (h->prec == FPIC_F32 && h->binned && h->census_fresh && !h->spec.unfused_deposit) {
+            // The last push counted the particles per tile as it stored them.  Lay the
+            // next order out from that census now; the next push writes it (no extra pass).
+            const int nw = h->wl ^ 1;
+            timing_begin(h, KC_SORT);
+            bin_scan_kernel<<<1, 1024, 0, h->stream>>>(h->tile_count, h->ntiles, h->tile_start2[nw], h->tile_cursor, h->work2[nw], h->nwork2[nw]);
+            timing_end(h);
+            HIP_TRY(h, hipGetLastError());
+            h->scatter_pending = true;
+            h->last_spill = 0; // decided; do not decide again on the same stale count
+        } else if (int rc = fpic_sort(h)) {
+            return rc;
+        }
+    }
     h->deposits_since_bin++;
     if (h->sums_fresh) return FPIC_OK; // the last step() already summed this very state (fused push)
     const int rc = h->prec == FPIC_F32 ? launch_cell_sums<float>(h) : launch_cell_sums<double>(h);

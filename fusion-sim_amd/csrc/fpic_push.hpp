@@ -14,6 +14,13 @@
 // the next sub-step's velocity pass would recompute from the same position, so they
 // are carried over instead (one sqrt and two NGP evaluations per sub-step instead
 // of two and four).
+//
+// Three things ride on the tiled form of the kernel because the workgroup already owns
+// a tile's particles and holds their final state in registers:
+//   * the scatter's stage 1 (per-cell sums of density()'s point sprites),
+//   * a census of the particles per tile (input of the next re-binning),
+//   * the re-binning itself: on a re-binning launch the state is written to its
+//     sorted place in the other particle set instead of in place.
 #pragma once
 
 #include "fpic_kernels.hpp"
@@ -33,6 +40,25 @@ struct PushArgs {
     T step_factor;
     unsigned long long n;
     int nsub;              // even: two sub-steps per step() call
+};
+
+// Extra arguments of the tiled form.
+template <typename T>
+struct TileArgs {
+    int ntx, ntz;
+    uint32_t ntiles;                   // real tiles + 1 bin for clipped particles
+    const BlockWork* work;             // chunks of the CURRENT particle order
+    const uint32_t* nwork;
+    T* cell_sums;                      // FUSE: (nr+1) x (nz+1) x 4, zeroed by the host
+    unsigned long long* spilled;       // FUSE: particles summed outside their LDS window
+    uint32_t* tile_count;              // FUSE: census of final states per tile, zeroed by the host
+    // SCATTER (re-binning launch): the other particle set and its bin table
+    const uint32_t* id;
+    T* dst_slab;
+    uint8_t* dst_alive;
+    uint32_t* dst_id;
+    const uint32_t* dst_tile_start;
+    uint32_t* dst_tile_cursor;
 };
 
 template <typename T>
@@ -67,8 +93,8 @@ struct GlobalTables {
 constexpr int kPushHalo = 4;                           // cells staged around a tile for the push
 constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
 constexpr int kPushThreads = 512;
-template <typename T>
-constexpr size_t push_lds_bytes() { return static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1); }
+constexpr int kNbr = 5;                                // tile neighbourhood tracked in LDS when binning
+constexpr int kNbrSlots = kNbr * kNbr + 1;             // + the bin of clipped particles
 
 // LDS pointers carry their address space in the type: through a generic pointer the
 // compiler emits flat_load instead of ds_read_b128.  (HIP's float4/double2 classes
@@ -175,12 +201,47 @@ __device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, co
     q.c2 = static_cast<T>(4) * x1 * (static_cast<T>(1) - x1);
 }
 
+// Point-sprite cell of a state (deposit_cell on the carried radius): false = clipped.
+template <typename T>
+__device__ __forceinline__ bool sprite_cell(const Particle<T>& q, int nr, int nz, int& ic, int& jc)
+{
+    if (!(q.r >= static_cast<T>(0) && q.r <= static_cast<T>(1) && q.z >= static_cast<T>(0) && q.z <= static_cast<T>(1))) return false;
+    ic = static_cast<int>(q.r * static_cast<T>(nr));
+    jc = static_cast<int>(q.z * static_cast<T>(nz));
+    return true;
+}
+
+// A workgroup tracks the 5x5 tiles around its own tile (+ the clipped bin) in LDS; a
+// particle further away than that goes to the global tables directly.
+struct TileNeighbourhood {
+    int ti, tj, ntx, ntz;
+    uint32_t clipped_bin;
+    // slot in the LDS tables, or -1 for a tile outside the neighbourhood; key = global bin
+    __device__ __forceinline__ int slot(bool visible, int ic, int jc, uint32_t& key) const
+    {
+        if (!visible) { key = clipped_bin; return kNbr * kNbr; }
+        const int tx = ic / kTileSide, ty = jc / kTileSide;
+        key = static_cast<uint32_t>(tx) + static_cast<uint32_t>(ntx) * static_cast<uint32_t>(ty);
+        const unsigned dx = static_cast<unsigned>(tx - ti + kNbr / 2), dy = static_cast<unsigned>(ty - tj + kNbr / 2);
+        return (dx < static_cast<unsigned>(kNbr) && dy < static_cast<unsigned>(kNbr)) ? static_cast<int>(dy * kNbr + dx) : -1;
+    }
+    // global bin of an LDS slot, or ~0u when the slot lies outside the tile grid
+    __device__ __forceinline__ uint32_t bin_of_slot(int s) const
+    {
+        if (s == kNbr * kNbr) return clipped_bin;
+        const int tx = ti + s % kNbr - kNbr / 2, ty = tj + s / kNbr - kNbr / 2;
+        if (tx < 0 || tx >= ntx || ty < 0 || ty >= ntz) return ~0u;
+        return static_cast<uint32_t>(tx) + static_cast<uint32_t>(ntx) * static_cast<uint32_t>(ty);
+    }
+};
+
 // What happens to a particle's final state besides being stored.  NoSums: nothing.
 // WindowSums: the scatter's stage 1 (programMoments01's vertex colour summed per
 // nearest cell, see fpic_kernels.hpp) fused into the push: the workgroup owns the
 // tile, the state is in registers and sqrt(x*x+y*y) has just been computed, so the
 // separate pass that re-reads 24 B per particle disappears.  Accumulators are double
-// in LDS (ds_add_f64; ds_add_f32 is 3.7x slower on gfx950).
+// in LDS (ds_add_f64; ds_add_f32 is 3.7x slower on gfx950).  It also counts the
+// final states per tile: the census the next re-binning is laid out from.
 struct NoSums {
     template <typename T>
     __device__ __forceinline__ void add(const Particle<T>&, int, int) const {}
@@ -188,16 +249,22 @@ struct NoSums {
 
 template <typename T>
 struct WindowSums {
-    FPIC_LDS double* lsums;   // [kTileLds*kTileLds][4]
-    int i0, j0;               // window origin (tile origin - kTileHalo)
-    T* cell_sums;             // global (nr+1) x (nz+1) x 4
-    unsigned* spilled;        // lane-local count of particles outside the window
+    FPIC_LDS double* lsums;      // [kTileLds*kTileLds][4]
+    FPIC_LDS uint32_t* lcensus;  // [kNbrSlots]
+    int i0, j0;                  // window origin (tile origin - kTileHalo)
+    TileNeighbourhood nb;
+    T* cell_sums;                // global (nr+1) x (nz+1) x 4
+    uint32_t* tile_count;        // global census
+    unsigned* spilled;           // lane-local count of particles outside the window
     __device__ __forceinline__ void add(const Particle<T>& q, int nr, int nz) const
     {
-        // clip test and cell of the point sprite (deposit_cell), on the carried radius
-        if (!(q.r >= static_cast<T>(0) && q.r <= static_cast<T>(1) && q.z >= static_cast<T>(0) && q.z <= static_cast<T>(1))) return;
-        const int ic = static_cast<int>(q.r * static_cast<T>(nr));
-        const int jc = static_cast<int>(q.z * static_cast<T>(nz));
+        int ic = 0, jc = 0;
+        const bool visible = sprite_cell(q, nr, nz, ic, jc);
+        uint32_t key;
+        const int s = nb.slot(visible, ic, jc, key);
+        if (s >= 0) __hip_atomic_fetch_add(lcensus + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else atomicAdd(tile_count + key, 1u);
+        if (!visible) return;
         const T dx = q.x / q.r, dy = q.y / q.r;
         const T c0 = static_cast<T>(0.001) * (q.vx * dx + q.vy * dy);
         const T c1 = static_cast<T>(0.001) * (q.vy * dx - q.vx * dy);
@@ -223,8 +290,8 @@ struct WindowSums {
 
 // One lane owns the PPT consecutive particles starting at `base` (one 16-byte vector
 // per array); cnt < PPT only for the last lane of the population.
-template <typename T, typename Tables, typename Sums>
-__device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& tab, const Sums& sums, size_t base, int cnt)
+template <typename T>
+__device__ __forceinline__ void load_state(const PushArgs<T>& a, size_t base, int cnt, Particle<T> (&q)[Vec16<T>::N])
 {
     constexpr int PPT = Vec16<T>::N;
     T v[10][PPT];
@@ -239,8 +306,6 @@ __device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& ta
         const uchar2 b = *reinterpret_cast<const uchar2*>(a.alive + base);
         al[0] = b.x; al[1] = b.y;
     }
-
-    Particle<T> q[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         q[k].x = v[0][k]; q[k].y = v[1][k]; q[k].z = v[2][k];
@@ -254,6 +319,13 @@ __device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& ta
         }
         locate(q[k], a.nr, a.nz);
     }
+}
+
+template <typename T, typename Tables, typename Sums>
+__device__ __forceinline__ void advance_state(const PushArgs<T>& a, const Tables& tab, const Sums& sums, int cnt,
+                                              Particle<T> (&q)[Vec16<T>::N])
+{
+    constexpr int PPT = Vec16<T>::N;
     for (int s = 0; s < a.nsub; s += 2) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
@@ -263,6 +335,15 @@ __device__ __forceinline__ void push_lane(const PushArgs<T>& a, const Tables& ta
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
         if (k < cnt) sums.add(q[k], a.nr, a.nz);
+}
+
+// in place, one 16-byte vector per array
+template <typename T>
+__device__ __forceinline__ void store_state(const PushArgs<T>& a, size_t base, int cnt, const Particle<T> (&q)[Vec16<T>::N])
+{
+    constexpr int PPT = Vec16<T>::N;
+    T v[10][PPT];
+    uint8_t al[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         v[0][k] = q[k].x; v[1][k] = q[k].y; v[2][k] = q[k].z;
@@ -301,7 +382,10 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
     if (base >= a.n) return;
     const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
     GlobalTables<T> tab{ a.coef, a.sink_alive, a.nr };
-    push_lane<T>(a, tab, NoSums{}, base, cnt);
+    Particle<T> q[PPT];
+    load_state<T>(a, base, cnt, q);
+    advance_state<T>(a, tab, NoSums{}, cnt, q);
+    store_state<T>(a, base, cnt, q);
 }
 
 // Tiled form, for binned particles: one workgroup per chunk of one tile's particles
@@ -313,22 +397,33 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
 // outside the window reads global memory; results never depend on the binning.
 // Chunks are cut at arbitrary particle indices; a vector of PPT particles belongs
 // to the chunk that holds its first particle.
-// FUSE_SUMS adds the scatter's stage 1 (WindowSums): a second LDS window, tile + 8-cell
-// halo of double accumulators, zeroed before and flushed with global float atomics in
-// 256-byte pieces after the chunk.  LDS: 76.8 + 1.6 (+ 73.7) KB for float.
+//
+// FUSE adds the scatter's stage 1 and the tile census (WindowSums): a second LDS
+// window, tile + 8-cell halo of double accumulators, zeroed before and flushed with
+// global float atomics in 256-byte pieces after the chunk.
+//
+// SCATTER (needs FUSE) makes this launch the re-binning as well.  The bin of a
+// particle is the tile of the state it is LOADED with — exactly what the previous
+// launch's census counted, from which the host has laid out dst_tile_start.  Per
+// sweep of the chunk the workgroup ranks its particles per bin in LDS, reserves one
+// range per bin with a single global atomic, and stores each final state at
+// start + range + rank in the other particle set.  Consecutive lanes get
+// consecutive ranks, so the 4-byte stores of a wave coalesce.
 template <typename T>
 constexpr size_t push_sums_offset() { return (static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1) + 15) / 16 * 16; }
-template <typename T, bool FUSE_SUMS>
+template <typename T, bool FUSE>
 constexpr size_t push_tiles_lds_bytes()
 {
-    return FUSE_SUMS ? push_sums_offset<T>() + static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double) : push_lds_bytes<T>();
+    // coefficient window | sink bytes | double sums window | census | per-wave ranks | per-wave ranges
+    return FUSE ? push_sums_offset<T>() + static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double) +
+                      (1 + 2 * (kPushThreads / 64)) * kNbrSlots * sizeof(uint32_t) + 16
+                : push_sums_offset<T>();
 }
 
-template <typename T, bool FUSE_SUMS>
-__global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, int ntx, const BlockWork* __restrict__ work,
-                                                                  const uint32_t* __restrict__ nwork, T* __restrict__ cell_sums,
-                                                                  unsigned long long* spilled)
+template <typename T, bool FUSE, bool SCATTER>
+__global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, TileArgs<T> t)
 {
+    static_assert(FUSE || !SCATTER, "the re-binning launch relies on the census of the fused form");
     constexpr int PPT = Vec16<T>::N;
     constexpr int LW = kPushLds;
     constexpr int SW = kTileLds;
@@ -336,9 +431,13 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
     FPIC_LDS T* lcoef = (FPIC_LDS T*)push_lds;
     FPIC_LDS uint8_t* lsink = (FPIC_LDS uint8_t*)push_lds + static_cast<size_t>(LW) * LW * 12 * sizeof(T);
     FPIC_LDS double* lsums = (FPIC_LDS double*)((FPIC_LDS unsigned char*)push_lds + push_sums_offset<T>());
-    if (blockIdx.x >= *nwork) return;
-    const BlockWork w = work[blockIdx.x];
-    const int ti0 = static_cast<int>(w.tile % ntx) * kTileSide, tj0 = static_cast<int>(w.tile / ntx) * kTileSide;
+    FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lsums + SW * SW * 4);
+    FPIC_LDS uint32_t* lrank = lcensus + kNbrSlots;
+    FPIC_LDS uint32_t* lrange = lrank + (kPushThreads / 64) * kNbrSlots;
+    if (blockIdx.x >= *t.nwork) return;
+    const BlockWork w = t.work[blockIdx.x];
+    const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>(w.tile / t.ntx);
+    const int ti0 = ti * kTileSide, tj0 = tj * kTileSide;
     const int i0 = ti0 - kPushHalo, j0 = tj0 - kPushHalo;
     // stage: one 16-byte piece (a third or a sixth of a record) per lane and iteration
     constexpr int PIECES = static_cast<int>(12 * sizeof(T) / 16);
@@ -357,22 +456,98 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         const int gi = i0 + li, gj = j0 + lj;
         lsink[c] = (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz) ? a.sink_alive[static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj] : 0;
     }
-    if constexpr (FUSE_SUMS)
+    if constexpr (FUSE) {
         for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) lsums[k] = 0.0;
+        for (int k = threadIdx.x; k < (1 + 2 * (kPushThreads / 64)) * kNbrSlots; k += kPushThreads) lcensus[k] = 0;
+    }
     __syncthreads();
-    WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
+    const WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
+    const TileNeighbourhood nb{ ti, tj, t.ntx, t.ntz, t.ntiles - 1 };
     unsigned my_spill = 0;
     const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
     const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
-    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
-        const size_t base = g * PPT;
-        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
-        if constexpr (FUSE_SUMS)
-            push_lane<T>(a, tab, WindowSums<T>{ lsums, ti0 - kTileHalo, tj0 - kTileHalo, cell_sums, &my_spill }, base, cnt);
-        else
-            push_lane<T>(a, tab, NoSums{}, base, cnt);
+
+    if constexpr (!SCATTER) {
+        for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
+            const size_t base = g * PPT;
+            const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+            Particle<T> q[PPT];
+            load_state<T>(a, base, cnt, q);
+            if constexpr (FUSE)
+                advance_state<T>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+            else
+                advance_state<T>(a, tab, NoSums{}, cnt, q);
+            store_state<T>(a, base, cnt, q);
+        }
+    } else {
+        // Ranks and ranges are kept per WAVE (its own 26 counters in LDS): the lanes of a
+        // wave run in lockstep, so the three phases below need no workgroup barrier and the
+        // waves of the (single resident) workgroup keep overlapping loads with arithmetic.
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        FPIC_LDS uint32_t* wrank = lrank + wave * kNbrSlots;
+        FPIC_LDS uint32_t* wrange = lrange + wave * kNbrSlots;
+        for (size_t g0 = g_begin + static_cast<size_t>(wave) * 64; g0 < g_end; g0 += kPushThreads) {
+            const size_t g = g0 + lane;
+            const bool active = g < g_end;
+            const size_t base = g * PPT;
+            const int cnt = !active ? 0 : ((base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base));
+            Particle<T> q[PPT];
+            uint32_t dest[PPT], pid[PPT];
+            int slot[PPT];
+            if (active) {
+                load_state<T>(a, base, cnt, q);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    dest[k] = 0; pid[k] = 0; slot[k] = -2;
+                    if (k < cnt) {
+                        pid[k] = t.id[base + k];
+                        int ic = 0, jc = 0;
+                        const bool visible = sprite_cell(q[k], a.nr, a.nz, ic, jc);
+                        uint32_t key;
+                        slot[k] = nb.slot(visible, ic, jc, key);
+                        if (slot[k] >= 0) dest[k] = __hip_atomic_fetch_add(wrank + slot[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else dest[k] = t.dst_tile_start[key] + atomicAdd(t.dst_tile_cursor + key, 1u);
+                    }
+                }
+            }
+            // same wave, LDS operations complete in order: fence the compiler, not the hardware
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kNbrSlots) {
+                const uint32_t c = wrank[lane];
+                uint32_t start = 0;
+                if (c) {
+                    const uint32_t bin = nb.bin_of_slot(lane);
+                    start = t.dst_tile_start[bin] + atomicAdd(t.dst_tile_cursor + bin, c);
+                }
+                wrange[lane] = start;
+                wrank[lane] = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k)
+                    if (slot[k] >= 0) dest[k] += wrange[slot[k]];
+                advance_state<T>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    if (k < cnt) {
+                        const size_t d = dest[k];
+                        t.dst_slab[0 * a.stride + d] = q[k].x; t.dst_slab[1 * a.stride + d] = q[k].y; t.dst_slab[2 * a.stride + d] = q[k].z;
+                        t.dst_slab[3 * a.stride + d] = q[k].vx; t.dst_slab[4 * a.stride + d] = q[k].vy; t.dst_slab[5 * a.stride + d] = q[k].vz;
+                        t.dst_slab[6 * a.stride + d] = q[k].u1; t.dst_slab[7 * a.stride + d] = q[k].u2;
+                        t.dst_slab[8 * a.stride + d] = q[k].c1; t.dst_slab[9 * a.stride + d] = q[k].c2;
+                        t.dst_alive[d] = q[k].alive ? 1 : 0;
+                        t.dst_id[d] = pid[k];
+                    }
+                }
+            }
+            // lrank was reset by the reserving lanes before the second barrier: the next sweep may start
+        }
     }
-    if constexpr (FUSE_SUMS) {
+
+    if constexpr (FUSE) {
         __syncthreads();
         // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
         // global addresses, so a wave's atomic is one 256-byte piece
@@ -384,9 +559,14 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             const int rem = k - lj * (SW * 4);
             const int gi = ti0 - kTileHalo + (rem >> 2), gj = tj0 - kTileHalo + lj;
             if (gi < 0 || gi > a.nr || gj < 0 || gj > a.nz) continue;
-            atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(val));
+            atomicAdd(t.cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(val));
         }
-        if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
+        if (threadIdx.x < kNbrSlots) {
+            const uint32_t c = lcensus[threadIdx.x];
+            const uint32_t bin = nb.bin_of_slot(threadIdx.x);
+            if (c && bin != ~0u) atomicAdd(t.tile_count + bin, c);
+        }
+        if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));
     }
 }
 
