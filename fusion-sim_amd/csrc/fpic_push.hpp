@@ -95,6 +95,10 @@ constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
 constexpr int kPushThreads = 512;
 constexpr int kNbr = 5;                                // tile neighbourhood tracked in LDS when binning
 constexpr int kNbrSlots = kNbr * kNbr + 1;             // + the bin of clipped particles
+constexpr int kOwnSlot = (kNbr * kNbr) / 2;            // the workgroup's own tile
+constexpr int kStageWords = 260;                       // 256 particles of a wave + 3 words of alignment shift, 16-byte multiple
+typedef uint32_t nat_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t unaligned_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // LDS pointers carry their address space in the type: through a generic pointer the
 // compiler emits flat_load instead of ds_read_b128.  (HIP's float4/double2 classes
@@ -411,13 +415,17 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
 // consecutive ranks, so the 4-byte stores of a wave coalesce.
 template <typename T>
 constexpr size_t push_sums_offset() { return (static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1) + 15) / 16 * 16; }
+template <typename T>
+constexpr size_t push_stage_offset() // per-wave 1 KiB transposition buffers of the re-binning stores
+{
+    return (push_sums_offset<T>() + static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double) +
+            (1 + 2 * (kPushThreads / 64)) * kNbrSlots * sizeof(uint32_t) + 15) / 16 * 16;
+}
 template <typename T, bool FUSE>
 constexpr size_t push_tiles_lds_bytes()
 {
     // coefficient window | sink bytes | double sums window | census | per-wave ranks | per-wave ranges
-    return FUSE ? push_sums_offset<T>() + static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double) +
-                      (1 + 2 * (kPushThreads / 64)) * kNbrSlots * sizeof(uint32_t) + 16
-                : push_sums_offset<T>();
+    return FUSE ? push_stage_offset<T>() + (kPushThreads / 64) * kStageWords * sizeof(uint32_t) : push_sums_offset<T>();
 }
 
 template <typename T, bool FUSE, bool SCATTER>
@@ -434,6 +442,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
     FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lsums + SW * SW * 4);
     FPIC_LDS uint32_t* lrank = lcensus + kNbrSlots;
     FPIC_LDS uint32_t* lrange = lrank + (kPushThreads / 64) * kNbrSlots;
+    FPIC_LDS uint32_t* lstage = (FPIC_LDS uint32_t*)((FPIC_LDS unsigned char*)push_lds + push_stage_offset<T>());
     if (blockIdx.x >= *t.nwork) return;
     const BlockWork w = t.work[blockIdx.x];
     const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>(w.tile / t.ntx);
@@ -486,6 +495,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         FPIC_LDS uint32_t* wrank = lrank + wave * kNbrSlots;
         FPIC_LDS uint32_t* wrange = lrange + wave * kNbrSlots;
+        FPIC_LDS uint32_t* wstage = lstage + wave * kStageWords;
         for (size_t g0 = g_begin + static_cast<size_t>(wave) * 64; g0 < g_end; g0 += kPushThreads) {
             const size_t g = g0 + lane;
             const bool active = g < g_end;
@@ -513,32 +523,79 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             // same wave, LDS operations complete in order: fence the compiler, not the hardware
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // one returning global atomic per occupied bin; its result is first used after the
+            // sub-steps below, which hide its latency
+            uint32_t my_count = 0, my_start = 0;
             if (lane < kNbrSlots) {
-                const uint32_t c = wrank[lane];
-                uint32_t start = 0;
-                if (c) {
+                my_count = wrank[lane];
+                if (my_count) {
                     const uint32_t bin = nb.bin_of_slot(lane);
-                    start = t.dst_tile_start[bin] + atomicAdd(t.dst_tile_cursor + bin, c);
+                    my_start = t.dst_tile_start[bin] + atomicAdd(t.dst_tile_cursor + bin, my_count);
                 }
-                wrange[lane] = start;
                 wrank[lane] = 0;
             }
+            if (active)
+                advance_state<T>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+            if (lane < kNbrSlots) wrange[lane] = my_start;
+            // the wave's particles that stay in the workgroup's own tile (nearly all of them)
+            // occupy one contiguous range [own_start, own_start + own_count) of every array
+            const uint32_t own_count = __shfl(my_count, kOwnSlot);
+            const uint32_t own_start = __shfl(my_start, kOwnSlot);
+            const uint32_t shift = own_start & 3u; // staging is shifted so that 16-byte stores are aligned
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (active) {
+            bool own[PPT];
 #pragma unroll
-                for (int k = 0; k < PPT; ++k)
+            for (int k = 0; k < PPT; ++k) {
+                own[k] = false;
+                if (k < cnt) {
                     if (slot[k] >= 0) dest[k] += wrange[slot[k]];
-                advance_state<T>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+                    own[k] = slot[k] == kOwnSlot;
+                }
+            }
+            // Stores.
+            // (1) Each array's words of the own-tile particles are transposed through the wave's
+            //     LDS buffer into destination order and leave as one aligned 16-byte store per
+            //     lane; the up to three words in front of the first and behind the last whole
+            //     vector go out in one masked store from lanes 0-5.
+            const uint32_t end = shift + own_count;                       // staging indices [shift, end)
+            const uint32_t vstart = (shift + 3u) & ~3u, vend = end & ~3u; // whole vectors cover [vstart, vend)
+            const uint32_t first = 4u * lane;
+            const bool whole = first >= vstart && first + 4u <= vend;
+            uint32_t edge = ~0u; // staging index this lane stores singly, if any
+            if (lane < 3) { const uint32_t i = shift + lane; if (i < (vstart < end ? vstart : end)) edge = i; }
+            else if (lane < 6) { const uint32_t i = (vend > vstart ? vend : vstart) + (lane - 3); if (i < end) edge = i; }
+#pragma unroll
+            for (int f = 0; f < 11; ++f) {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    if (k < cnt) {
-                        const size_t d = dest[k];
+                    if (own[k]) {
+                        const T v = f == 0 ? q[k].x : f == 1 ? q[k].y : f == 2 ? q[k].z : f == 3 ? q[k].vx : f == 4 ? q[k].vy
+                                  : f == 5 ? q[k].vz : f == 6 ? q[k].u1 : f == 7 ? q[k].u2 : f == 8 ? q[k].c1 : q[k].c2;
+                        wstage[shift + dest[k] - own_start] = f < 10 ? __builtin_bit_cast(uint32_t, v) : pid[k];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // word i of the staging buffer belongs at element own_start - shift + i
+                uint32_t* out = (f < 10 ? reinterpret_cast<uint32_t*>(t.dst_slab + f * a.stride) : t.dst_id) + (own_start - shift);
+                if (whole) *reinterpret_cast<nat_u32x4*>(out + first) = *reinterpret_cast<const FPIC_LDS nat_u32x4*>(wstage + first);
+                if (edge != ~0u) out[edge] = wstage[edge];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // (2) alive bytes, and the particles that changed tile since the last binning (about
+            //     a quarter of them after four frames at the bench's temperature): stored singly
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                if (k < cnt) {
+                    const size_t d = dest[k];
+                    t.dst_alive[d] = q[k].alive ? 1 : 0;
+                    if (!own[k]) {
                         t.dst_slab[0 * a.stride + d] = q[k].x; t.dst_slab[1 * a.stride + d] = q[k].y; t.dst_slab[2 * a.stride + d] = q[k].z;
                         t.dst_slab[3 * a.stride + d] = q[k].vx; t.dst_slab[4 * a.stride + d] = q[k].vy; t.dst_slab[5 * a.stride + d] = q[k].vz;
                         t.dst_slab[6 * a.stride + d] = q[k].u1; t.dst_slab[7 * a.stride + d] = q[k].u2;
                         t.dst_slab[8 * a.stride + d] = q[k].c1; t.dst_slab[9 * a.stride + d] = q[k].c2;
-                        t.dst_alive[d] = q[k].alive ? 1 : 0;
                         t.dst_id[d] = pid[k];
                     }
                 }
