@@ -87,12 +87,46 @@ def cpu_baseline(spec, seconds_target=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds_target or cycles >= 200:
             break
-    return {
+    out = {
         "value": 2.0 * n * cycles / dt, "unit": "particle-updates/s", "cores": 1, "kind": "port",
         "sample": "oracle/pic_oracle.c (CPU restatement of the reference's GLSL, the reference has no CPU path), "
                   "fp32, 1 thread, grid %dx%d, %d particles, %d cycles of precalc+step+density in %.1f s; host has %d cores"
                   % (s["nr"], s["nz"], n, cycles, dt, os.cpu_count() or 0),
     }
+    out["js_twin"] = js_twin_baseline(s["nr"])
+    return out
+
+
+def js_twin_baseline(grid, seconds_target=8.0):
+    """The same restatement in plain JavaScript under node (oracle/pic_oracle.js): the
+    closest analogue of a "JS engine on CPU" — the reference itself has none."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None:
+        return {"value": None, "note": "node unavailable on this box"}
+    try:
+        raw = subprocess.check_output([node, os.path.join(ROOT, "oracle", "pic_oracle.js"), "time", "316", str(grid),
+                                       str(seconds_target)], timeout=300)
+        j = json.loads(raw.decode().strip().splitlines()[-1])
+        return {"value": j["value"], "unit": "particle-updates/s", "cores": 1, "kind": "port",
+                "sample": "oracle/pic_oracle.js under node %s, fp32 via Math.fround, grid %dx%d, %d particles, %d cycles in %.1f s"
+                          % (j["node"], grid, grid, j["particles"], j["cycles"], j["seconds"])}
+    except Exception as e:  # the baseline is a report, never a reason to fail the bench
+        return {"value": None, "note": "node run failed: %s" % e}
+
+
+def measured_traffic():
+    """HBM bytes per push launch from the committed PMC passes (scripts/pmc_bench.sh,
+    profiles/*_traffic.json): rocprofv3 cannot run inside the timed process."""
+    best = None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            best = json.load(open(f))
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -202,20 +236,28 @@ def main():
                 "parallelism": "particle shards x%d, replicated grid, all-reduce of cell sums" % world,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "push_kernel<float> (step(): K3+K1+K2, two sub-steps fused)",
+                "bound": "hbm",
+                "kernel": "push_tiles_kernel<float, fuse, rebin> (step(): K3+K1+K2 x2 sub-steps, with the scatter's "
+                          "per-cell sums, the tile census and every ~4th launch the re-binning fused in)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UPDATE * 2.0 * n_local,
                 "avg_launch_ms": push_ms,
+                "launches_timed": st["step_launches"],
                 "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
             },
             "kernel_ms_per_step": {
-                "push": st["ms_push"] / args.steps, "cell_sums": st["ms_deposit"] / args.steps,
+                "push_incl_fused_scatter_and_rebinning": st["ms_push"] / args.steps,
+                "separate_cell_sums": st["ms_deposit"] / args.steps,
                 "stamp_normalise_ema": st["ms_stamp"] / args.steps, "precalc": st["ms_precalc"] / args.steps,
-                "binning": st["ms_sort"] / args.steps, "binning_passes": st["sort_passes"],
+                "bin_table_scan": st["ms_sort"] / args.steps, "rebinning_launches": st["sort_passes"],
                 "last_spilled": st["deposit_spilled"],
             },
         }
+        tr = measured_traffic()
+        if tr and world == 1:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
