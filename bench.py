@@ -145,7 +145,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # under torch.distributed.run the collective path is taken even for a world of one, so a
+    # 1-GPU box can rehearse exactly what the N-GPU launch executes
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
     if args.gpus != world:
         if distributed or args.gpus != 1:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"

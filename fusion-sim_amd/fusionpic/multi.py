@@ -49,7 +49,7 @@ class ShardedPusher:
     def density(self):
         import torch.distributed as dist
         self.sim.deposit()
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_initialized():  # also with a world of one: the same calls as the N-GPU launch
             if self.stream is not None:
                 import torch
                 with torch.cuda.stream(self.stream):
