@@ -137,6 +137,10 @@ def main():
     ap.add_argument("--side", type=int, default=10000, help="particle texture side per GPU (count = side^2)")
     ap.add_argument("--grid", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rng", choices=["reference", "counter"], default="reference",
+                    help="reference = the reference's entropy-table generator (the drop-in, the headline); "
+                         "counter = the Philox extension mode (SURVEY.md 8(d))")
+    ap.add_argument("--no-extensions", action="store_true", help="skip the extra counter-RNG measurement at N=1")
     args = ap.parse_args()
 
     import torch
@@ -166,13 +170,18 @@ def main():
         _, _, entropy, _ = synthetic_inputs(1, spec, 0x5EEDF051)
     sink, pdf = scene_grids(spec["nr"], spec["nz"])
 
-    sim = fp.makeCylindricalParticlePusher(spec, device=local_rank)
     stream = torch.cuda.Stream(device=local_rank)
-    sim.setStream(stream.cuda_stream)
-    sim.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
-    sim.setRandomState(entropy, rand)
-    del pos, vel, rand
-    sim.addBZ(0.01)
+
+    def build(rng_mode):
+        s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051)
+        s_.setStream(stream.cuda_stream)
+        s_.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
+        if rng_mode == "reference":
+            s_.setRandomState(entropy, rand)
+        s_.addBZ(0.01)
+        return s_
+
+    sim = build(args.rng)
     sim.precalc()
     sim.sort()  # first binning of the randomly ordered upload belongs to setup, like the upload itself
 
@@ -260,12 +269,42 @@ def main():
         if tr and world == 1:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_source"] = tr.get("source")
+        if args.rng == "counter":
+            out["config"]["workload"] += "; EXTENSION: counter-based RNG (Philox4x32-10) instead of the reference's entropy-table generator"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
 
     sim.destroy()
+    if rank == 0 and world == 1 and not distributed and args.rng == "reference" and not args.no_extensions:
+        # Extension, reported beside the headline and never as it: same scene, same frame, with
+        # the counter-based generator (no entropy table, no per-particle random state).
+        ext = build("counter")
+        ext.precalc(); ext.sort()
+        for _ in range(args.warmup):
+            ext.precalc(); ext.step(); ext.density()
+        ext.sync(); torch.cuda.synchronize()
+        ext.resetStats(); ext.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ext.precalc(); ext.step(); ext.density()
+        ext.sync(); torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        es = ext.stats()
+        pm = es["ms_push"] / max(1, es["step_launches"])
+        out["extensions"] = {"counter_rng": {
+            "what": "spec.rng_mode = 1: Philox4x32-10(particle id, sub-step) replaces the reference's entropy-table walk; "
+                    "parity is bit-exact against the oracle's counter mode, not against the reference's random stream",
+            "value": 2.0 * n_local * args.steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / args.steps,
+            "push_avg_launch_ms": pm, "rebinning_launches": es["sort_passes"],
+            "roofline_achieved_GBs": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9,
+            "roofline_frac": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "streamed_bytes_per_launch": 50.0 * n_local,
+        }}
+        ext.destroy()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
     if distributed:
         dist.destroy_process_group()
 

@@ -84,6 +84,7 @@ struct fpic_handle {
     size_t work_cap = 0;
     bool binned = false;
     int deposits_since_bin = 0;
+    unsigned long long t_substep = 0; // counter-based RNG mode: global index of the next sub-step
     bool sums_fresh = false;      // cell_sums already holds the sums of the current particle state (fused push)
     bool census_fresh = false;    // tile_count holds the census of the current particle state (fused push)
     bool scatter_pending = false; // tables [wl ^ 1] are laid out from that census: the next push re-bins
@@ -188,6 +189,17 @@ void timing_end(fpic_handle* h)
     if (!h->profiling) return;
     (void)hipEventRecord(h->pending.back().b, h->stream);
     if (h->pending.size() > 2048) timing_collect(h);
+}
+
+// counter-based RNG mode: the random vector of caller's particle i at sub-step t
+__global__ __launch_bounds__(256) void counter_rand_readback_kernel(float* aos4, size_t chunk_begin, size_t chunk_n, uint32_t k0,
+                                                                     uint32_t k1, unsigned long long t)
+{
+    const size_t o = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (o >= chunk_n) return;
+    float u[4];
+    counter_rand<float>(static_cast<uint32_t>(chunk_begin + o), t, k0, k1, u);
+    aos4[4 * o] = u[0]; aos4[4 * o + 1] = u[1]; aos4[4 * o + 2] = u[2]; aos4[4 * o + 3] = u[3];
 }
 
 // default random state when the host never injects one: the reference seeds from
@@ -298,6 +310,8 @@ int download_misc(fpic_handle* h, float* rand, uint8_t* alive, int32_t* cells)
         const size_t m = std::min(chunk, h->n - b);
         get_rand_kernel<T><<<blocks_for(h->n), 256, 0, h->stream>>>(arrays<T>(h, h->cur), h->n, b, m, srand, salive, scells,
                                                                   h->nr, h->nz);
+        if (srand && h->spec.rng_mode == 1) // no stored state: what the next sub-step would draw for each particle
+            counter_rand_readback_kernel<<<blocks_for(m), 256, 0, h->stream>>>(srand, b, m, h->spec.rng_seed_lo, h->spec.rng_seed_hi, h->t_substep);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && rand) e = hipMemcpyAsync(rand + 4 * b, srand, m * 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess && alive) e = hipMemcpyAsync(alive + b, salive, m, hipMemcpyDeviceToHost, h->stream);
@@ -360,6 +374,10 @@ int launch_push(fpic_handle* h, int nsub)
     a.step_factor = static_cast<T>(h->k.step_factor); // uniform1f(u_step_factor) (empic.js:852)
     a.n = h->n;
     a.nsub = nsub;
+    a.id = h->id[h->cur];
+    a.seed_lo = h->spec.rng_seed_lo; a.seed_hi = h->spec.rng_seed_hi;
+    a.t0 = h->t_substep;
+    const bool ctr = h->spec.rng_mode == 1;
     const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
     // float state, binned, fusion not switched off: the push also forms the per-cell sums
     // and the tile census, and on a re-binning launch writes the sorted order itself
@@ -382,14 +400,20 @@ int launch_push(fpic_handle* h, int nsub)
             HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
             HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
             HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
-            if (scatter) push_tiles_kernel<T, true, true><<<grid, kPushThreads, push_tiles_lds_bytes<T, true>(), h->stream>>>(a, t);
-            else push_tiles_kernel<T, true, false><<<grid, kPushThreads, push_tiles_lds_bytes<T, true>(), h->stream>>>(a, t);
+            constexpr size_t lds = push_tiles_lds_bytes<T, true>();
+            if (scatter && ctr) push_tiles_kernel<T, true, true, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            else if (scatter) push_tiles_kernel<T, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            else if (ctr) push_tiles_kernel<T, true, false, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            else push_tiles_kernel<T, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
         }
     } else if (h->binned) { // the work list of the last binning is valid until the next one: the push is in place
-        push_tiles_kernel<T, false, false><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
+        if (ctr) push_tiles_kernel<T, false, false, true><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
+        else push_tiles_kernel<T, false, false, false><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
     } else {
-        push_kernel<T><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+        if (ctr) push_kernel<T, true><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+        else push_kernel<T, false><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
     }
+    h->t_substep += static_cast<unsigned long long>(nsub);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     if (fuse) {
@@ -611,6 +635,12 @@ void release(fpic_handle* h)
     delete h;
 }
 
+template <typename K>
+hipError_t set_lds(K kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
 // The reference validates with typeof === 'number' (utilities.js:118-127); over a C
 // struct the equivalent failure is a non-finite or out-of-domain value.
 int validate_spec(const fpic_spec* s)
@@ -627,6 +657,7 @@ int validate_spec(const fpic_spec* s)
     if (s->nz < 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".nz <- must be a positive integer");
     if (s->count == 0 && s->nparticles < 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".nparticles <- must be a positive integer");
     if (s->precision != FPIC_F32 && s->precision != FPIC_F64) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".precision <- must be 0 (f32) or 1 (f64)");
+    if (s->rng_mode != 0 && s->rng_mode != 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".rng_mode <- must be 0 (reference) or 1 (counter)");
     return FPIC_OK;
 }
 
@@ -690,10 +721,14 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     // the scatter's LDS image (72 KiB of double accumulators) exceeds the 64 KiB static limit
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, false>()))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, true>()))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<float, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<float, true>()))) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(push_tiles_kernel<double, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(push_tiles_lds_bytes<double, false>()))) != hipSuccess)
+        (e = set_lds(push_tiles_kernel<float, false, false, false>, push_tiles_lds_bytes<float, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, false, false, true>, push_tiles_lds_bytes<float, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, false, false>, push_tiles_lds_bytes<float, true>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, false, true>, push_tiles_lds_bytes<float, true>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, true, false>, push_tiles_lds_bytes<float, true>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, true, true>, push_tiles_lds_bytes<float, true>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<double, false, false, false>, push_tiles_lds_bytes<double, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<double, false, false, true>, push_tiles_lds_bytes<double, false>())) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e)));
 
     h->work_cap = (h->n + kDepositChunk - 1) / kDepositChunk + h->ntiles;
@@ -792,6 +827,8 @@ int fpic_set_grid(fpic_handle* h, int which, const void* data, int nr, int nz, i
 int fpic_set_random_state(fpic_handle* h, const float* entropy, const float* rand)
 {
     CHECK_HANDLE(h);
+    if (h->spec.rng_mode == 1 && (entropy || rand))
+        return fail(h, FPIC_ERR_STATE, ".rng_mode <- the counter-based generator has no entropy table or per-particle state; use rng_seed and fpic_set_substep_counter");
     if (entropy) {
         const size_t ne = static_cast<size_t>(4) * kEntropySide * kEntropySide;
         float* stage = nullptr;
@@ -847,6 +884,20 @@ int fpic_step(fpic_handle* h, int ncalls)
         h->particle_updates += static_cast<uint64_t>(2) * ncalls * h->n;
     }
     return rc;
+}
+
+int fpic_get_substep_counter(fpic_handle* h, uint64_t* t)
+{
+    CHECK_HANDLE(h);
+    if (t) *t = h->t_substep;
+    return FPIC_OK;
+}
+
+int fpic_set_substep_counter(fpic_handle* h, uint64_t t)
+{
+    CHECK_HANDLE(h);
+    h->t_substep = t;
+    return FPIC_OK;
 }
 
 int fpic_sort(fpic_handle* h)

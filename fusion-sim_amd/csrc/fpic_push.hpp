@@ -40,7 +40,34 @@ struct PushArgs {
     T step_factor;
     unsigned long long n;
     int nsub;              // even: two sub-steps per step() call
+    // counter-based RNG extension (CTR kernels): nothing random is stored per particle
+    const uint32_t* id;    // the caller's particle index = the generator's stream
+    uint32_t seed_lo, seed_hi;
+    unsigned long long t0; // global index of this launch's first sub-step
 };
+
+// Philox4x32-10 (Salmon et al., SC'11; Random123 constants).  Extension mode only:
+// the random vector of particle `id` at sub-step `t` is the block with counter
+// (id, t_lo, t_hi, 0x5EED) under key = seed, each word mapped to (w >> 8) * 2^-24.
+// It stands where the reference reads its rand texel (empic.js:717, :772); the
+// reference's own generator is the entropy-table walk of K3.
+template <typename T>
+__device__ __forceinline__ void counter_rand(uint32_t id, unsigned long long t, uint32_t k0, uint32_t k1, T (&u)[4])
+{
+    uint32_t c0 = id, c1 = static_cast<uint32_t>(t), c2 = static_cast<uint32_t>(t >> 32), c3 = 0x5EEDu;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0, n1 = static_cast<uint32_t>(p1);
+        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1, n3 = static_cast<uint32_t>(p0);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u[0] = static_cast<T>(c0 >> 8) * static_cast<T>(1.0 / 16777216.0);
+    u[1] = static_cast<T>(c1 >> 8) * static_cast<T>(1.0 / 16777216.0);
+    u[2] = static_cast<T>(c2 >> 8) * static_cast<T>(1.0 / 16777216.0);
+    u[3] = static_cast<T>(c3 >> 8) * static_cast<T>(1.0 / 16777216.0);
+}
 
 // Extra arguments of the tiled form.
 template <typename T>
@@ -67,6 +94,7 @@ struct Particle {
     T r;        // sqrt(x*x + y*y) of the current position
     int ci, cj; // NGP cell of (r, z)
     bool alive;
+    uint32_t at; // index of the particle in the arrays (CTR: where its id is found when needed)
 };
 
 // Where a sub-step reads the per-cell tables from.  GlobalTables: straight from
@@ -154,13 +182,17 @@ __device__ __forceinline__ void locate(Particle<T>& q, int nr, int nz)
     q.cj = ngp(q.z, nz);
 }
 
-template <typename T, typename Tables>
-__device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, const Tables& tab)
+// CTR = false: the reference's generator (per-particle state u1,u2,c1,c2 advanced by K3).
+// CTR = true: the counter-based extension; tsub is the global index of this sub-step.
+template <typename T, bool CTR, typename Tables>
+__device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, const Tables& tab, unsigned long long tsub)
 {
-    // K3's entropy texel depends on nothing below: issue it first
-    const unsigned et = static_cast<unsigned>(ngp(q.c1, kEntropySide)) + static_cast<unsigned>(kEntropySide) * static_cast<unsigned>(ngp(q.c2, kEntropySide));
-    T s[4];
-    load4(a.entropy + 4u * et, s);
+    T s[4] = { 0, 0, 0, 0 };
+    if constexpr (!CTR) {
+        // K3's entropy texel depends on nothing below: issue it first
+        const unsigned et = static_cast<unsigned>(ngp(q.c1, kEntropySide)) + static_cast<unsigned>(kEntropySide) * static_cast<unsigned>(ngp(q.c2, kEntropySide));
+        load4(a.entropy + 4u * et, s);
+    }
 
     // K1: velocity in local cylindrical components, v' = R v + A at the nearest cell
     const T dx = q.x / q.r, dy = q.y / q.r;
@@ -175,9 +207,11 @@ __device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, co
     T nvy = cx * dy + cy * dx;
     T nvz = cz;
     if (!q.alive) { // re-injected on the previous sub-step (empic.js:772, quirk Q4)
-        nvx = static_cast<T>(0.001) * (static_cast<T>(2) * q.u1 - static_cast<T>(1));
-        nvy = static_cast<T>(0.001) * (static_cast<T>(2) * q.u2 - static_cast<T>(1));
-        nvz = static_cast<T>(0.001) * (static_cast<T>(2) * q.c1 - static_cast<T>(1));
+        T u[4] = { q.u1, q.u2, q.c1, q.c2 };
+        if constexpr (CTR) counter_rand<T>(a.id[q.at], tsub, a.seed_lo, a.seed_hi, u);
+        nvx = static_cast<T>(0.001) * (static_cast<T>(2) * u[0] - static_cast<T>(1));
+        nvy = static_cast<T>(0.001) * (static_cast<T>(2) * u[1] - static_cast<T>(1));
+        nvz = static_cast<T>(0.001) * (static_cast<T>(2) * u[2] - static_cast<T>(1));
     }
     q.vx = nvx; q.vy = nvy; q.vz = nvz;
 
@@ -188,21 +222,25 @@ __device__ __forceinline__ void substep(Particle<T>& q, const PushArgs<T>& a, co
     locate(q, a.nr, a.nz);
     q.alive = tab.keep(q.ci, q.cj);
     if (!q.alive) { // lost: re-inject from the inverse-CDF table on the plane y = 0 (empic.js:719)
-        const unsigned t = static_cast<unsigned>(ngp(q.u1, kCdfSide)) + static_cast<unsigned>(kCdfSide) * static_cast<unsigned>(ngp(q.u2, kCdfSide));
+        T u[4] = { q.u1, q.u2, q.c1, q.c2 };
+        if constexpr (CTR) counter_rand<T>(a.id[q.at], tsub, a.seed_lo, a.seed_hi, u);
+        const unsigned t = static_cast<unsigned>(ngp(u[0], kCdfSide)) + static_cast<unsigned>(kCdfSide) * static_cast<unsigned>(ngp(u[1], kCdfSide));
         q.x = a.inv_cdf_xy[2u * t];
         q.y = static_cast<T>(0);
         q.z = a.inv_cdf_xy[2u * t + 1];
         locate(q, a.nr, a.nz);
     }
 
-    // K3: additive walk on (u1,u2), logistic map on (c1,c2) (quirk Q5: m == 1 stays 1)
-    const T x0 = static_cast<T>(0.999) * q.c1 + static_cast<T>(0.001) * s[2];
-    const T x1 = static_cast<T>(0.999) * q.c2 + static_cast<T>(0.001) * s[3];
-    const T m0 = q.u1 + s[0], m1 = q.u2 + s[1];
-    q.u1 = (m0 > static_cast<T>(1)) ? m0 - static_cast<T>(1) : m0;
-    q.u2 = (m1 > static_cast<T>(1)) ? m1 - static_cast<T>(1) : m1;
-    q.c1 = static_cast<T>(4) * x0 * (static_cast<T>(1) - x0);
-    q.c2 = static_cast<T>(4) * x1 * (static_cast<T>(1) - x1);
+    if constexpr (!CTR) {
+        // K3: additive walk on (u1,u2), logistic map on (c1,c2) (quirk Q5: m == 1 stays 1)
+        const T x0 = static_cast<T>(0.999) * q.c1 + static_cast<T>(0.001) * s[2];
+        const T x1 = static_cast<T>(0.999) * q.c2 + static_cast<T>(0.001) * s[3];
+        const T m0 = q.u1 + s[0], m1 = q.u2 + s[1];
+        q.u1 = (m0 > static_cast<T>(1)) ? m0 - static_cast<T>(1) : m0;
+        q.u2 = (m1 > static_cast<T>(1)) ? m1 - static_cast<T>(1) : m1;
+        q.c1 = static_cast<T>(4) * x0 * (static_cast<T>(1) - x0);
+        q.c2 = static_cast<T>(4) * x1 * (static_cast<T>(1) - x1);
+    }
 }
 
 // Point-sprite cell of a state (deposit_cell on the carried radius): false = clipped.
@@ -273,20 +311,21 @@ struct WindowSums {
         const T c0 = static_cast<T>(0.001) * (q.vx * dx + q.vy * dy);
         const T c1 = static_cast<T>(0.001) * (q.vy * dx - q.vx * dy);
         const T c2 = static_cast<T>(0.001) * q.vz;
-        const T c3 = static_cast<T>(0.001) * static_cast<T>(1);
         const unsigned li = static_cast<unsigned>(ic - i0), lj = static_cast<unsigned>(jc - j0);
         if (li < static_cast<unsigned>(kTileLds) && lj < static_cast<unsigned>(kTileLds)) {
             FPIC_LDS double* t = lsums + 4u * (lj * kTileLds + li);
             __hip_atomic_fetch_add(t, static_cast<double>(c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(t + 1, static_cast<double>(c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(t + 2, static_cast<double>(c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(t + 3, static_cast<double>(c3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the count channel is an exact integer in the slot's low word (ds_add_u32 is the fast
+            // LDS atomic); the flush turns n into n * 0.001 once
+            __hip_atomic_fetch_add((FPIC_LDS uint32_t*)(t + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             T* g = cell_sums + 4 * (static_cast<size_t>(ic) + (static_cast<size_t>(nr) + 1) * jc);
             atomicAdd(g, c0);
             atomicAdd(g + 1, c1);
             atomicAdd(g + 2, c2);
-            atomicAdd(g + 3, c3);
+            atomicAdd(g + 3, static_cast<T>(0.001) * static_cast<T>(1));
             ++*spilled;
         }
     }
@@ -294,15 +333,16 @@ struct WindowSums {
 
 // One lane owns the PPT consecutive particles starting at `base` (one 16-byte vector
 // per array); cnt < PPT only for the last lane of the population.
-template <typename T>
+template <typename T, bool CTR>
 __device__ __forceinline__ void load_state(const PushArgs<T>& a, size_t base, int cnt, Particle<T> (&q)[Vec16<T>::N])
 {
     constexpr int PPT = Vec16<T>::N;
-    T v[10][PPT];
+    constexpr int NF = CTR ? 6 : 10; // the counter-based mode keeps no random state
+    T v[10][PPT] = {};
     uint8_t al[PPT];
     // arrays are padded to a multiple of the vector width, so the vector load is in bounds
 #pragma unroll
-    for (int f = 0; f < 10; ++f) load_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+    for (int f = 0; f < NF; ++f) load_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
     if constexpr (PPT == 4) {
         const uchar4 b = *reinterpret_cast<const uchar4*>(a.alive + base);
         al[0] = b.x; al[1] = b.y; al[2] = b.z; al[3] = b.w;
@@ -316,6 +356,7 @@ __device__ __forceinline__ void load_state(const PushArgs<T>& a, size_t base, in
         q[k].vx = v[3][k]; q[k].vy = v[4][k]; q[k].vz = v[5][k];
         q[k].u1 = v[6][k]; q[k].u2 = v[7][k]; q[k].c1 = v[8][k]; q[k].c2 = v[9][k];
         q[k].alive = al[k] != 0;
+        q[k].at = static_cast<uint32_t>(base + k);
         if (k >= cnt) { // padding lanes: keep every gather in range, results are discarded
             q[k].x = static_cast<T>(0.5); q[k].y = static_cast<T>(0); q[k].z = static_cast<T>(0.5);
             q[k].vx = q[k].vy = q[k].vz = static_cast<T>(0);
@@ -325,16 +366,16 @@ __device__ __forceinline__ void load_state(const PushArgs<T>& a, size_t base, in
     }
 }
 
-template <typename T, typename Tables, typename Sums>
+template <typename T, bool CTR, typename Tables, typename Sums>
 __device__ __forceinline__ void advance_state(const PushArgs<T>& a, const Tables& tab, const Sums& sums, int cnt,
                                               Particle<T> (&q)[Vec16<T>::N])
 {
     constexpr int PPT = Vec16<T>::N;
     for (int s = 0; s < a.nsub; s += 2) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
+        for (int k = 0; k < PPT; ++k) substep<T, CTR>(q[k], a, tab, a.t0 + s);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) substep(q[k], a, tab);
+        for (int k = 0; k < PPT; ++k) substep<T, CTR>(q[k], a, tab, a.t0 + s + 1);
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
@@ -342,10 +383,11 @@ __device__ __forceinline__ void advance_state(const PushArgs<T>& a, const Tables
 }
 
 // in place, one 16-byte vector per array
-template <typename T>
+template <typename T, bool CTR>
 __device__ __forceinline__ void store_state(const PushArgs<T>& a, size_t base, int cnt, const Particle<T> (&q)[Vec16<T>::N])
 {
     constexpr int PPT = Vec16<T>::N;
+    constexpr int NF = CTR ? 6 : 10;
     T v[10][PPT];
     uint8_t al[PPT];
 #pragma unroll
@@ -357,7 +399,7 @@ __device__ __forceinline__ void store_state(const PushArgs<T>& a, size_t base, i
     }
     if (cnt == PPT) {
 #pragma unroll
-        for (int f = 0; f < 10; ++f) store_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+        for (int f = 0; f < NF; ++f) store_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
         if constexpr (PPT == 4) {
             *reinterpret_cast<uchar4*>(a.alive + base) = make_uchar4(al[0], al[1], al[2], al[3]);
         } else {
@@ -369,7 +411,7 @@ __device__ __forceinline__ void store_state(const PushArgs<T>& a, size_t base, i
         for (int k = 0; k < PPT; ++k) {
             if (k < cnt) {
 #pragma unroll
-                for (int f = 0; f < 10; ++f) a.slab[f * a.stride + base + k] = v[f][k];
+                for (int f = 0; f < NF; ++f) a.slab[f * a.stride + base + k] = v[f][k];
                 a.alive[base + k] = al[k];
             }
         }
@@ -378,7 +420,7 @@ __device__ __forceinline__ void store_state(const PushArgs<T>& a, size_t base, i
 
 // Flat form: any particle order, tables read from global memory.  Used until the
 // particles have been binned.
-template <typename T>
+template <typename T, bool CTR>
 __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
 {
     constexpr int PPT = Vec16<T>::N;
@@ -387,9 +429,9 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
     const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
     GlobalTables<T> tab{ a.coef, a.sink_alive, a.nr };
     Particle<T> q[PPT];
-    load_state<T>(a, base, cnt, q);
-    advance_state<T>(a, tab, NoSums{}, cnt, q);
-    store_state<T>(a, base, cnt, q);
+    load_state<T, CTR>(a, base, cnt, q);
+    advance_state<T, CTR>(a, tab, NoSums{}, cnt, q);
+    store_state<T, CTR>(a, base, cnt, q);
 }
 
 // Tiled form, for binned particles: one workgroup per chunk of one tile's particles
@@ -428,7 +470,7 @@ constexpr size_t push_tiles_lds_bytes()
     return FUSE ? push_stage_offset<T>() + (kPushThreads / 64) * kStageWords * sizeof(uint32_t) : push_sums_offset<T>();
 }
 
-template <typename T, bool FUSE, bool SCATTER>
+template <typename T, bool FUSE, bool SCATTER, bool CTR>
 __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, TileArgs<T> t)
 {
     static_assert(FUSE || !SCATTER, "the re-binning launch relies on the census of the fused form");
@@ -481,12 +523,12 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             const size_t base = g * PPT;
             const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
             Particle<T> q[PPT];
-            load_state<T>(a, base, cnt, q);
+            load_state<T, CTR>(a, base, cnt, q);
             if constexpr (FUSE)
-                advance_state<T>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+                advance_state<T, CTR>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
             else
-                advance_state<T>(a, tab, NoSums{}, cnt, q);
-            store_state<T>(a, base, cnt, q);
+                advance_state<T, CTR>(a, tab, NoSums{}, cnt, q);
+            store_state<T, CTR>(a, base, cnt, q);
         }
     } else {
         // Ranks and ranges are kept per WAVE (its own 26 counters in LDS): the lanes of a
@@ -505,7 +547,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             uint32_t dest[PPT], pid[PPT];
             int slot[PPT];
             if (active) {
-                load_state<T>(a, base, cnt, q);
+                load_state<T, CTR>(a, base, cnt, q);
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     dest[k] = 0; pid[k] = 0; slot[k] = -2;
@@ -535,7 +577,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
                 wrank[lane] = 0;
             }
             if (active)
-                advance_state<T>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+                advance_state<T, CTR>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
             if (lane < kNbrSlots) wrange[lane] = my_start;
             // the wave's particles that stay in the workgroup's own tile (nearly all of them)
             // occupy one contiguous range [own_start, own_start + own_count) of every array
@@ -567,6 +609,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             else if (lane < 6) { const uint32_t i = (vend > vstart ? vend : vstart) + (lane - 3); if (i < end) edge = i; }
 #pragma unroll
             for (int f = 0; f < 11; ++f) {
+                if (CTR && f >= 6 && f < 10) continue; // no random state to move
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     if (own[k]) {
@@ -594,8 +637,10 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
                     if (!own[k]) {
                         t.dst_slab[0 * a.stride + d] = q[k].x; t.dst_slab[1 * a.stride + d] = q[k].y; t.dst_slab[2 * a.stride + d] = q[k].z;
                         t.dst_slab[3 * a.stride + d] = q[k].vx; t.dst_slab[4 * a.stride + d] = q[k].vy; t.dst_slab[5 * a.stride + d] = q[k].vz;
-                        t.dst_slab[6 * a.stride + d] = q[k].u1; t.dst_slab[7 * a.stride + d] = q[k].u2;
-                        t.dst_slab[8 * a.stride + d] = q[k].c1; t.dst_slab[9 * a.stride + d] = q[k].c2;
+                        if constexpr (!CTR) {
+                            t.dst_slab[6 * a.stride + d] = q[k].u1; t.dst_slab[7 * a.stride + d] = q[k].u2;
+                            t.dst_slab[8 * a.stride + d] = q[k].c1; t.dst_slab[9 * a.stride + d] = q[k].c2;
+                        }
                         t.dst_id[d] = pid[k];
                     }
                 }
@@ -610,10 +655,12 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         // global addresses, so a wave's atomic is one 256-byte piece
         const size_t gw = static_cast<size_t>(a.nr) + 1;
         for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) {
-            const double val = lsums[k];
-            if (val == 0.0) continue;
             const int lj = k / (SW * 4);
             const int rem = k - lj * (SW * 4);
+            double val = lsums[k];
+            if ((rem & 3) == 3) // integer count -> the sum of that many 0.001's (exact in double)
+                val = static_cast<double>(*(FPIC_LDS uint32_t*)(lsums + k)) * static_cast<double>(static_cast<T>(0.001) * static_cast<T>(1));
+            if (val == 0.0) continue;
             const int gi = ti0 - kTileHalo + (rem >> 2), gj = tj0 - kTileHalo + lj;
             if (gi < 0 || gi > a.nr || gj < 0 || gj > a.nz) continue;
             atomicAdd(t.cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(val));

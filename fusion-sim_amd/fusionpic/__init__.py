@@ -32,6 +32,7 @@ ABI_FUNCTIONS = [
     "fpic_add_btheta", "fpic_precalc", "fpic_step", "fpic_density", "fpic_deposit", "fpic_density_finish",
     "fpic_read_grid", "fpic_get_particles", "fpic_get_cells", "fpic_device_buffer", "fpic_set_stream",
     "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
+    "fpic_get_substep_counter", "fpic_set_substep_counter",
 ]
 
 
@@ -47,7 +48,8 @@ class Spec(ctypes.Structure):
         ("dt", ctypes.c_double), ("nparticles", ctypes.c_int32), ("particle_mass", ctypes.c_double),
         ("particle_charge", ctypes.c_double), ("count", ctypes.c_uint64), ("precision", ctypes.c_int32),
         ("device", ctypes.c_int32), ("physical_a", ctypes.c_int32), ("sort_interval", ctypes.c_int32),
-        ("unfused_deposit", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7),
+        ("unfused_deposit", ctypes.c_int32), ("rng_mode", ctypes.c_int32), ("rng_seed_lo", ctypes.c_uint32),
+        ("rng_seed_hi", ctypes.c_uint32), ("reserved", ctypes.c_int32 * 4),
     ]
 
 
@@ -101,6 +103,8 @@ def load_library(path=None):
     lib.fpic_set_stream.argtypes = [vp, vp]
     lib.fpic_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.fpic_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    lib.fpic_get_substep_counter.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.fpic_set_substep_counter.argtypes = [vp, ctypes.c_uint64]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -137,7 +141,7 @@ class CylindricalParticlePusher:
     """Object returned by makeCylindricalParticlePusher (empic.js:1528)."""
 
     def __init__(self, spec, precision="fp32", device=0, count=0, compat=True, sort_interval=0, fuse_deposit=True,
-                 library=None):
+                 rng="reference", seed=0, library=None):
         _validate_spec(spec)
         self._lib = library or load_library()
         self.spec = dict(spec)
@@ -150,6 +154,8 @@ class CylindricalParticlePusher:
         s.physical_a = 0 if compat else 1
         s.sort_interval = int(sort_interval)
         s.unfused_deposit = 0 if fuse_deposit else 1
+        s.rng_mode = {"reference": 0, "counter": 1}[rng]
+        s.rng_seed_lo, s.rng_seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
         self.precision = s.precision
         self.nr, self.nz = int(spec["nr"]), int(spec["nz"])
         self.n = int(count) if count else int(spec["nparticles"]) ** 2
@@ -291,6 +297,14 @@ class CylindricalParticlePusher:
 
     def setStream(self, stream_ptr):
         self._check(self._lib.fpic_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def substepCounter(self):
+        t = ctypes.c_uint64()
+        self._check(self._lib.fpic_get_substep_counter(self._h, ctypes.byref(t)))
+        return t.value
+
+    def setSubstepCounter(self, t):
+        self._check(self._lib.fpic_set_substep_counter(self._h, int(t)))
 
     def sort(self):
         self._check(self._lib.fpic_sort(self._h))

@@ -109,7 +109,12 @@ typedef struct fpic_spec {
     int32_t unfused_deposit;/* 1: step() does not also form the per-cell sums of density()'s
                                scatter (by default it does: the frame loop of fusionsim.js:172-174
                                always calls density() after step()) */
-    int32_t reserved[7];
+    int32_t rng_mode;       /* 0: the reference's generator (entropy-table walk K3, per-particle state,
+                               empic.js:783-820).  1: counter-based extension: the random
+                               vector of particle i at sub-step t is Philox4x32-10(counter (i, t, 0x5EED),
+                               key rng_seed); no per-particle random state, no entropy table */
+    uint32_t rng_seed_lo, rng_seed_hi;
+    int32_t reserved[4];
 } fpic_spec;
 
 typedef struct fpic_handle fpic_handle;
@@ -202,6 +207,11 @@ int fpic_get_cells(fpic_handle* h, int32_t* cells);
 int fpic_device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
 int fpic_set_stream(fpic_handle* h, void* hip_stream);
 int fpic_get_stream(fpic_handle* h, void** hip_stream);
+
+/* Counter-based RNG mode only: the global sub-step index (starts at 0, +2 per step() call);
+ * settable so that a run can be resumed. */
+int fpic_get_substep_counter(fpic_handle* h, uint64_t* t);
+int fpic_set_substep_counter(fpic_handle* h, uint64_t t);
 
 /* Force a re-bin of the particle arrays by cell tile now (normally automatic). */
 int fpic_sort(fpic_handle* h);

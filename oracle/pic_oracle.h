@@ -51,6 +51,9 @@ void orc_stamp(float out[121]);
  * throw "function out of range". */
 int orc_inv_cdf(const double* pdf, int nr, int nz, float* out);
 
+/* Philox4x32-10 block: counter (c0..c3), key (k0,k1) -> 4 words (RNG extension mode). */
+void orc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]);
+
 #define ORC_DECL(REAL, P)                                                                              \
     void P##step_rand(const REAL* rand_in, const REAL* entropy, REAL* rand_out, size_t n);             \
     void P##step_velocity(const REAL* pos, const REAL* vel, const REAL* rnd, const REAL* R1,           \
@@ -79,7 +82,11 @@ int orc_inv_cdf(const double* pdf, int nr, int nz, float* out);
     void P##loop_shape(REAL u_R, int nr, int nz, REAL* out);                                           \
     void P##add_current_loop(REAL* B, const REAL* shape_half, const REAL* shape_tenth, int nr, int nz, \
                              REAL u_R, REAL u_Z, REAL u_I);                                            \
-    void P##add_uniform(REAL* B, int nr, int nz, int kind, REAL value);
+    void P##add_uniform(REAL* B, int nr, int nz, int kind, REAL value);                                \
+    void P##step_counter(REAL* pos_A, REAL* vel_A, REAL* pos_B, REAL* vel_B, const REAL* R1,           \
+                         const REAL* R2, const REAL* R3, const REAL* A, const REAL* sink,              \
+                         const REAL* inv_cdf, int nr, int nz, REAL step_factor, size_t n, int ncalls,  \
+                         uint64_t seed, uint64_t t0);
 
 ORC_DECL(float, orc_f32_)
 ORC_DECL(double, orc_f64_)

@@ -83,7 +83,9 @@ def inv_cdf(pdf):
 class OracleSim:
     """CPU twin of empic.makeCylindricalParticlePusher(spec) (empic.js:30)."""
 
-    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None):
+    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None, rng="reference", seed=0):
+        # rng="counter": the Philox extension mode (no per-particle random state), sub-step counter self.t
+        self.rng, self.seed, self.t = rng, int(seed), 0
         self.spec = dict(spec)
         self.dtype = np.dtype(dtype)
         self.prefix, self.creal = _real(dtype)
@@ -184,6 +186,13 @@ class OracleSim:
 
     # ---- out.step (empic.js:1436-1469)
     def step(self, ncalls=1):
+        if self.rng == "counter":
+            self._f("step_counter")(_p(self.pos_A), _p(self.vel_A), _p(self.pos_B), _p(self.vel_B), _p(self.R1), _p(self.R2),
+                                    _p(self.R3), _p(self.A), _p(self.sink), _p(self.inv_cdf), self.nr, self.nz,
+                                    self._c(self.step_factor), ctypes.c_size_t(self.n), int(ncalls),
+                                    ctypes.c_uint64(self.seed), ctypes.c_uint64(self.t))
+            self.t += 2 * int(ncalls)
+            return
         self._f("step")(_p(self.pos_A), _p(self.vel_A), _p(self.rand_A), _p(self.pos_B), _p(self.vel_B), _p(self.rand_B),
                         _p(self.entropy), _p(self.R1), _p(self.R2), _p(self.R3), _p(self.A), _p(self.sink),
                         _p(self.inv_cdf), self.nr, self.nz, self._c(self.step_factor), ctypes.c_size_t(self.n),

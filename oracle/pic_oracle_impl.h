@@ -366,3 +366,34 @@ void FN(add_uniform)(REAL* B, int nr, int nz, int kind, REAL value)
             o[3] += (REAL)1;
         }
 }
+
+/* ---- counter-based RNG mode (an EXTENSION, SURVEY.md 8(d): "RNG: counter-based
+ * Philox-4x32-10 ... stream = particle id"; the reference's own generator is the
+ * entropy-table walk above).  The random vector of particle `id` at sub-step `t` is
+ * Philox4x32-10(counter = (id, t_lo, t_hi, 0x5EED), key = seed), each word mapped to
+ * (w >> 8) * 2^-24.  It plays the role of the rand texel in both passes of a sub-step:
+ * .xyz re-seeds the velocity of a just re-injected particle (empic.js:772), .xy picks
+ * the re-injection point (empic.js:717-719).  Nothing is stored per particle. */
+void FN(step_counter)(REAL* pos_A, REAL* vel_A, REAL* pos_B, REAL* vel_B,
+                      const REAL* R1, const REAL* R2, const REAL* R3, const REAL* A,
+                      const REAL* sink, const REAL* inv_cdf, int nr, int nz, REAL step_factor,
+                      size_t n, int ncalls, uint64_t seed, uint64_t t0)
+{
+    REAL* rnd = (REAL*)malloc(sizeof(REAL) * 4 * n);
+    uint64_t t = t0;
+    for (int k = 0; k < 2 * ncalls; ++k, ++t) {
+        for (size_t p = 0; p < n; ++p) {
+            uint32_t w[4];
+            orc_philox4x32_10((uint32_t)p, (uint32_t)t, (uint32_t)(t >> 32), 0x5EEDu, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            for (int c = 0; c < 4; ++c) rnd[4 * p + c] = (REAL)(w[c] >> 8) * (REAL)(1.0 / 16777216.0);
+        }
+        if ((k & 1) == 0) {
+            FN(step_velocity)(pos_A, vel_A, rnd, R1, R2, R3, A, nr, nz, vel_B, n);
+            FN(step_position)(pos_A, vel_B, rnd, sink, inv_cdf, nr, nz, step_factor, pos_B, n);
+        } else {
+            FN(step_velocity)(pos_B, vel_B, rnd, R1, R2, R3, A, nr, nz, vel_A, n);
+            FN(step_position)(pos_B, vel_A, rnd, sink, inv_cdf, nr, nz, step_factor, pos_A, n);
+        }
+    }
+    free(rnd);
+}
