@@ -635,6 +635,139 @@ void release(fpic_handle* h)
     delete h;
 }
 
+
+// ---------------------------------------------------------------- checkpoint
+// Flat binary file: header, then every particle array in the CALLER's order (x y z vx vy vz
+// u1 u2 c1 c2 as T, alive as bytes), then the grid tables that cannot be rebuilt (E, B, sink,
+// inverse CDF, entropy, running average).  The reference keeps its state only in GPU textures
+// and never reads it back (utilities.js:701-711 exists but is unused): this is the read-back /
+// resume path a host needs.
+struct CheckpointHeader {
+    char magic[8];          // "FPICCKP1"
+    uint32_t version;       // 1
+    uint32_t precision;     // fpic_dtype of every T below
+    uint64_t n;
+    int32_t nr, nz;
+    uint64_t t_substep;
+    int32_t rng_mode;
+    uint32_t reserved;
+    fpic_spec spec;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_caller_order_kernel(const T* __restrict__ src, const uint32_t* __restrict__ id, size_t n,
+                                                              size_t chunk_begin, size_t chunk_n, T* __restrict__ out)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t i = id[s];
+    if (i >= chunk_begin && i < chunk_begin + chunk_n) out[i - chunk_begin] = src[s];
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t* id, size_t n)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) id[i] = static_cast<uint32_t>(i);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sink_mask_kernel(const T* __restrict__ sink_rgba, uint8_t* __restrict__ mask, size_t ncell)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < ncell) mask[c] = sink_rgba[4 * c] > static_cast<T>(0.5) ? 1 : 0;
+}
+
+struct FileCloser {
+    FILE* f;
+    ~FileCloser() { if (f) std::fclose(f); }
+};
+
+// one particle array (T or bytes), caller order, through a bounded staging buffer
+template <typename E>
+int save_array(fpic_handle* h, FILE* f, const E* dev_array, std::vector<unsigned char>& host)
+{
+    const size_t chunk = 16u << 20;
+    E* stage = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, h->n) * sizeof(E)));
+    int rc = FPIC_OK;
+    for (size_t b = 0; b < h->n && rc == FPIC_OK; b += chunk) {
+        const size_t m = std::min(chunk, h->n - b);
+        host.resize(m * sizeof(E));
+        to_caller_order_kernel<E><<<blocks_for(h->n), 256, 0, h->stream>>>(dev_array, h->id[h->cur], h->n, b, m, stage);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(host.data(), stage, m * sizeof(E), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, FPIC_ERR_HIP, "checkpoint read-back failed: %s", hipGetErrorString(e));
+        else if (std::fwrite(host.data(), sizeof(E), m, f) != m) rc = fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
+int save_block(fpic_handle* h, FILE* f, const void* dev, size_t bytes, std::vector<unsigned char>& host)
+{
+    host.resize(bytes);
+    HIP_TRY(h, hipMemcpyAsync(host.data(), dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (std::fwrite(host.data(), 1, bytes, f) != bytes) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+    return FPIC_OK;
+}
+
+int load_block(fpic_handle* h, FILE* f, void* dev, size_t bytes, std::vector<unsigned char>& host)
+{
+    const size_t chunk = 256u << 20;
+    for (size_t b = 0; b < bytes; b += chunk) {
+        const size_t m = std::min(chunk, bytes - b);
+        host.resize(m);
+        if (std::fread(host.data(), 1, m, f) != m) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
+        HIP_TRY(h, hipMemcpyAsync(static_cast<unsigned char*>(dev) + b, host.data(), m, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return FPIC_OK;
+}
+
+template <typename T>
+int save_state(fpic_handle* h, FILE* f)
+{
+    std::vector<unsigned char> host;
+    for (int a = 0; a < 10; ++a)
+        if (int rc = save_array<T>(h, f, static_cast<const T*>(h->part[h->cur][a]), host)) return rc;
+    if (int rc = save_array<uint8_t>(h, f, h->alive[h->cur], host)) return rc;
+    const size_t rgba = h->ncell * 4 * sizeof(T);
+    struct { const void* p; size_t bytes; } grids[] = {
+        { h->E, rgba }, { h->B, rgba }, { h->sink, rgba },
+        { h->inv_cdf_xy, static_cast<size_t>(kCdfSide) * kCdfSide * 2 * sizeof(T) },
+        { h->entropy, static_cast<size_t>(kEntropySide) * kEntropySide * 4 * sizeof(T) },
+        { h->avg, rgba },
+    };
+    for (auto& g : grids)
+        if (int rc = save_block(h, f, g.p, g.bytes, host)) return rc;
+    return FPIC_OK;
+}
+
+template <typename T>
+int load_state(fpic_handle* h, FILE* f)
+{
+    std::vector<unsigned char> host;
+    // the file is in the caller's order: it becomes the memory order, ids restart at identity
+    for (int a = 0; a < 10; ++a)
+        if (int rc = load_block(h, f, h->part[h->cur][a], h->n * sizeof(T), host)) return rc;
+    if (int rc = load_block(h, f, h->alive[h->cur], h->n, host)) return rc;
+    iota_kernel<<<blocks_for(h->n), 256, 0, h->stream>>>(h->id[h->cur], h->n);
+    const size_t rgba = h->ncell * 4 * sizeof(T);
+    struct { void* p; size_t bytes; } grids[] = {
+        { h->E, rgba }, { h->B, rgba }, { h->sink, rgba },
+        { h->inv_cdf_xy, static_cast<size_t>(kCdfSide) * kCdfSide * 2 * sizeof(T) },
+        { h->entropy, static_cast<size_t>(kEntropySide) * kEntropySide * 4 * sizeof(T) },
+        { h->avg, rgba },
+    };
+    for (auto& g : grids)
+        if (int rc = load_block(h, f, g.p, g.bytes, host)) return rc;
+    sink_mask_kernel<T><<<blocks_for(h->ncell), 256, 0, h->stream>>>(static_cast<const T*>(h->sink), h->sink_alive, h->ncell);
+    HIP_TRY(h, hipGetLastError());
+    return launch_precalc<T>(h); // the coefficient records follow from E and B
+}
+
 template <typename K>
 hipError_t set_lds(K kernel, size_t bytes)
 {
@@ -1022,6 +1155,46 @@ int fpic_get_stream(fpic_handle* h, void** hip_stream)
 {
     CHECK_HANDLE(h);
     if (hip_stream) *hip_stream = h->stream;
+    return FPIC_OK;
+}
+
+int fpic_save_checkpoint(fpic_handle* h, const char* path)
+{
+    CHECK_HANDLE(h);
+    if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    FileCloser fc{ std::fopen(path, "wb") };
+    if (!fc.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
+    CheckpointHeader hd{};
+    std::memcpy(hd.magic, "FPICCKP1", 8);
+    hd.version = 1; hd.precision = static_cast<uint32_t>(h->prec); hd.n = h->n; hd.nr = h->nr; hd.nz = h->nz;
+    hd.t_substep = h->t_substep; hd.rng_mode = h->spec.rng_mode; hd.spec = h->spec;
+    if (std::fwrite(&hd, sizeof hd, 1, fc.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+    return h->prec == FPIC_F32 ? save_state<float>(h, fc.f) : save_state<double>(h, fc.f);
+}
+
+int fpic_load_checkpoint(fpic_handle* h, const char* path)
+{
+    CHECK_HANDLE(h);
+    if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
+    FileCloser fc{ std::fopen(path, "rb") };
+    if (!fc.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
+    CheckpointHeader hd{};
+    if (std::fread(&hd, sizeof hd, 1, fc.f) != 1 || std::memcmp(hd.magic, "FPICCKP1", 8) != 0 || hd.version != 1)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a fusionpic checkpoint (version 1)", path);
+    if (hd.n != h->n || hd.nr != h->nr || hd.nz != h->nz || static_cast<int>(hd.precision) != h->prec || hd.rng_mode != h->spec.rng_mode)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint holds %llu particles on %d x %d, precision %u, rng %d; the pusher was made for %zu on %d x %d, precision %d, rng %d",
+                    static_cast<unsigned long long>(hd.n), hd.nr, hd.nz, hd.precision, hd.rng_mode, h->n, h->nr, h->nz, h->prec, h->spec.rng_mode);
+    if (hd.spec.radius != h->spec.radius || hd.spec.height != h->spec.height || hd.spec.dt != h->spec.dt ||
+        hd.spec.particle_mass != h->spec.particle_mass || hd.spec.particle_charge != h->spec.particle_charge)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint was written with different radius/height/dt/mass/charge");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int rc = h->prec == FPIC_F32 ? load_state<float>(h, fc.f) : load_state<double>(h, fc.f);
+    if (rc) return rc;
+    h->t_substep = hd.t_substep;
+    h->binned = false;
+    h->sums_fresh = h->census_fresh = h->scatter_pending = false;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FPIC_OK;
 }
 

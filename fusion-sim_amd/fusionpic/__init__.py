@@ -32,7 +32,7 @@ ABI_FUNCTIONS = [
     "fpic_add_btheta", "fpic_precalc", "fpic_step", "fpic_density", "fpic_deposit", "fpic_density_finish",
     "fpic_read_grid", "fpic_get_particles", "fpic_get_cells", "fpic_device_buffer", "fpic_set_stream",
     "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
-    "fpic_get_substep_counter", "fpic_set_substep_counter",
+    "fpic_get_substep_counter", "fpic_set_substep_counter", "fpic_save_checkpoint", "fpic_load_checkpoint",
 ]
 
 
@@ -105,6 +105,8 @@ def load_library(path=None):
     lib.fpic_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     lib.fpic_get_substep_counter.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.fpic_set_substep_counter.argtypes = [vp, ctypes.c_uint64]
+    lib.fpic_save_checkpoint.argtypes = [vp, ctypes.c_char_p]
+    lib.fpic_load_checkpoint.argtypes = [vp, ctypes.c_char_p]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -305,6 +307,12 @@ class CylindricalParticlePusher:
 
     def setSubstepCounter(self, t):
         self._check(self._lib.fpic_set_substep_counter(self._h, int(t)))
+
+    def saveCheckpoint(self, path):
+        self._check(self._lib.fpic_save_checkpoint(self._h, os.fsencode(path)))
+
+    def loadCheckpoint(self, path):
+        self._check(self._lib.fpic_load_checkpoint(self._h, os.fsencode(path)))
 
     def sort(self):
         self._check(self._lib.fpic_sort(self._h))

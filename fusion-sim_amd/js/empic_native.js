@@ -22,7 +22,10 @@
  *   setRandomState({entropy, rand}) -> reproducible runs (the reference seeds from
  *                          window.crypto and Math.random, empic.js:148-173)
  * Extension keys of spec (all optional): precision 'fp32'|'fp64', device, count,
- * compat (default true: keep quirk Q1 of empic.js:645), sort_interval.
+ * compat (default true: keep quirk Q1 of empic.js:645), sort_interval, fuse_deposit
+ * (default true), rng 'reference'|'counter' + seed (counter = Philox4x32-10 per particle
+ * and sub-step instead of the reference's entropy-table generator; not the reference's
+ * random stream).
  */
 'use strict';
 const path = require('path');
@@ -106,17 +109,22 @@ exports.makeCylindricalParticlePusher = function (spec) {
         radius: 'number', height: 'number', nr: 'number', nz: 'number', dt: 'number',
         nparticles: 'number', particle_mass: 'number', particle_charge: 'number',
         precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
-        sort_interval: [, 'number'],
+        sort_interval: [, 'number'], fuse_deposit: [, 'boolean'], rng: [, 'string'], seed: [, 'number'],
     });
     const n = spec.count ? spec.count : spec.nparticles * spec.nparticles;   // empic.js:107-109
     const fp64 = spec.precision === 'fp64';
     if (spec.precision !== undefined && spec.precision !== 'fp32' && spec.precision !== 'fp64') {
         throw new Error(".precision <- must be 'fp32' or 'fp64'");
     }
+    if (spec.rng !== undefined && spec.rng !== 'reference' && spec.rng !== 'counter') {
+        throw new Error(".rng <- must be 'reference' or 'counter'");
+    }
+    const seed = spec.seed || 0;
     const lib = addon();
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass,
         spec.particle_charge, spec.count || 0, fp64 ? 1 : 0, spec.device || 0, spec.compat === false ? 1 : 0,
-        spec.sort_interval || 0);
+        spec.sort_interval || 0, spec.fuse_deposit === false ? 1 : 0, spec.rng === 'counter' ? 1 : 0,
+        seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296);
     const nr = spec.nr, nz = spec.nz;
     const Real = fp64 ? Float64Array : Float32Array;
     const out = {};
@@ -161,6 +169,8 @@ exports.makeCylindricalParticlePusher = function (spec) {
         const f32 = function (a) { return a === undefined || a === null ? null : (a instanceof Float32Array ? a : Float32Array.from(a)); };
         lib.setRandomState(h, f32(state.entropy), f32(state.rand));
     };
+    out.saveCheckpoint = function (path) { lib.saveCheckpoint(h, String(path)); };
+    out.loadCheckpoint = function (path) { lib.loadCheckpoint(h, String(path)); };
     out.sort = function () { lib.sort(h); };
     out.sync = function () { lib.sync(h); };
     out.profile = function (on) { lib.profile(h, on ? 1 : 0); };

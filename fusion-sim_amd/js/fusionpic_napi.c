@@ -114,19 +114,21 @@ static napi_value undefined(napi_env env)
     return u;
 }
 
-/* create(radius, height, nr, nz, dt, nparticles, mass, charge, count, precision, device, physical_a, sort_interval) */
+/* create(radius, height, nr, nz, dt, nparticles, mass, charge, count, precision, device, physical_a,
+ *        sort_interval, unfused_deposit, rng_mode, seed_lo, seed_hi) */
 static napi_value n_create(napi_env env, napi_callback_info info)
 {
-    napi_value argv[13];
-    if (!get_args(env, info, 13, argv, NULL)) return NULL;
-    double d[13];
-    for (int i = 0; i < 13; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
+    napi_value argv[17];
+    if (!get_args(env, info, 17, argv, NULL)) return NULL;
+    double d[17];
+    for (int i = 0; i < 17; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
     fpic_spec s;
     memset(&s, 0, sizeof s);
     s.radius = d[0]; s.height = d[1]; s.nr = (int32_t)d[2]; s.nz = (int32_t)d[3]; s.dt = d[4];
     s.nparticles = (int32_t)d[5]; s.particle_mass = d[6]; s.particle_charge = d[7];
     s.count = (uint64_t)d[8]; s.precision = (int32_t)d[9]; s.device = (int32_t)d[10];
-    s.physical_a = (int32_t)d[11]; s.sort_interval = (int32_t)d[12];
+    s.physical_a = (int32_t)d[11]; s.sort_interval = (int32_t)d[12]; s.unfused_deposit = (int32_t)d[13];
+    s.rng_mode = (int32_t)d[14]; s.rng_seed_lo = (uint32_t)d[15]; s.rng_seed_hi = (uint32_t)d[16];
     fpic_handle* h = NULL;
     if (fpic_create(&s, &h) != FPIC_OK) return throw_fpic(env, NULL);
     box_t* b = (box_t*)malloc(sizeof *b);
@@ -306,6 +308,22 @@ static napi_value n_get_cells(napi_env env, napi_callback_info info)
     return argv[1];
 }
 
+/* saveCheckpoint(h, path) / loadCheckpoint(h, path) */
+static napi_value checkpoint_call(napi_env env, napi_callback_info info, int (*fn)(fpic_handle*, const char*))
+{
+    napi_value argv[2]; fpic_handle* h;
+    if (!get_args(env, info, 2, argv, &h)) return NULL;
+    char path[4096]; size_t len = 0;
+    if (napi_get_value_string_utf8(env, argv[1], path, sizeof path, &len) != napi_ok) {
+        napi_throw_type_error(env, NULL, "expected a path string");
+        return NULL;
+    }
+    if (fn(h, path) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+static napi_value n_save_checkpoint(napi_env env, napi_callback_info info) { return checkpoint_call(env, info, fpic_save_checkpoint); }
+static napi_value n_load_checkpoint(napi_env env, napi_callback_info info) { return checkpoint_call(env, info, fpic_load_checkpoint); }
+
 static napi_value n_get_stats(napi_env env, napi_callback_info info)
 {
     napi_value argv[1]; fpic_handle* h;
@@ -347,7 +365,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "precalc", n_precalc }, { "step", n_step }, { "density", n_density }, { "deposit", n_deposit },
         { "densityFinish", n_density_finish }, { "readGrid", n_read_grid }, { "getParticles", n_get_particles },
         { "getCells", n_get_cells }, { "sort", n_sort }, { "sync", n_sync }, { "profile", n_profile },
-        { "getStats", n_get_stats }, { "resetStats", n_reset_stats }, { "buildArch", n_build_arch },
+        { "getStats", n_get_stats }, { "saveCheckpoint", n_save_checkpoint }, { "loadCheckpoint", n_load_checkpoint }, { "resetStats", n_reset_stats }, { "buildArch", n_build_arch },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

@@ -216,6 +216,13 @@ int fpic_set_substep_counter(fpic_handle* h, uint64_t t);
 /* Force a re-bin of the particle arrays by cell tile now (normally automatic). */
 int fpic_sort(fpic_handle* h);
 
+/* Read-back / resume (the reference can only display its state,
+ * utilities.js:701-711 is unused): a flat binary dump of the particle arrays in the caller's
+ * order and of the grid tables, and its inverse.  The target handle of a load must have been
+ * created from the same spec.  A run resumed from a checkpoint continues bit-identically. */
+int fpic_save_checkpoint(fpic_handle* h, const char* path);
+int fpic_load_checkpoint(fpic_handle* h, const char* path);
+
 int fpic_sync(fpic_handle* h);
 int fpic_profile(fpic_handle* h, int enable);
 int fpic_get_stats(fpic_handle* h, fpic_stats* out);
