@@ -6,6 +6,7 @@
 // cannot be created without a gfx950 device.
 #include "fpic_kernels.hpp"
 #include "fpic_push.hpp"
+#include "fpic_injection.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -768,6 +769,50 @@ int load_state(fpic_handle* h, FILE* f)
     return launch_precalc<T>(h); // the coefficient records follow from E and B
 }
 
+// out.set({source_pdf}) (empic.js:1263-1349): the 512x512 inverse-CDF table is built on the
+// device (fpic_injection.hpp) into a scratch table and adopted only if the reference would
+// not have thrown.
+template <typename T, typename In>
+int set_source_pdf(fpic_handle* h, const In* host_pdf)
+{
+    const size_t table_elems = static_cast<size_t>(2) * kCdfSide * kCdfSide;
+    In* pdf = nullptr;
+    double *row_cdf = nullptr, *row_sum = nullptr, *col_cdf = nullptr;
+    T* table = nullptr;
+    int* throws = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : { static_cast<void*>(pdf), static_cast<void*>(row_cdf), static_cast<void*>(row_sum),
+                         static_cast<void*>(col_cdf), static_cast<void*>(table), static_cast<void*>(throws) })
+            if (p) (void)hipFree(p);
+    };
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&pdf), h->ncell * sizeof(In));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&row_cdf), h->ncell * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&row_sum), h->nr * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&col_cdf), h->nr * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&table), table_elems * sizeof(T));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&throws), sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(throws, 0, sizeof(int), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(table, 0, table_elems * sizeof(T), h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pdf, host_pdf, h->ncell * sizeof(In), hipMemcpyHostToDevice, h->stream);
+    int flag = 0;
+    if (e == hipSuccess) {
+        cdf_rows_kernel<In><<<blocks_for(h->nr, 64), 64, 0, h->stream>>>(pdf, h->nr, h->nz, row_cdf, row_sum);
+        cdf_cols_kernel<<<1, 1, 0, h->stream>>>(row_sum, h->nr, col_cdf);
+        inverse_cdf_kernel<T><<<blocks_for(static_cast<size_t>(kCdfSide) * kCdfSide), 256, 0, h->stream>>>(col_cdf, row_cdf, h->nr, h->nz, table, throws);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, throws, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && !flag) {
+        e = hipMemcpyAsync(h->inv_cdf_xy, table, table_elems * sizeof(T), hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(h, e == hipErrorOutOfMemory ? FPIC_ERR_OOM : FPIC_ERR_HIP, "inverse-CDF build failed: %s", hipGetErrorString(e));
+    if (flag) return fail(h, FPIC_ERR_INVALID_ARG, ".source_pdf <- the first grid row carries no weight (the reference throws a TypeError here)");
+    return FPIC_OK;
+}
+
 template <typename K>
 hipError_t set_lds(K kernel, size_t bytes)
 {
@@ -930,26 +975,11 @@ int fpic_set_grid(fpic_handle* h, int which, const void* data, int nr, int nz, i
     if (which < FPIC_GRID_E || which > FPIC_GRID_SOURCE_PDF) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown grid %d", which);
     if (ncomp != (vec ? 3 : 1)) return fail(h, FPIC_ERR_INVALID_ARG, ".ncomp <- expected %d", vec ? 3 : 1);
 
-    if (which == FPIC_GRID_SOURCE_PDF) {
-        std::vector<double> pdf(h->ncell);
-        for (size_t c = 0; c < h->ncell; ++c)
-            pdf[c] = dtype == FPIC_F32 ? static_cast<const float*>(data)[c] : static_cast<const double*>(data)[c];
-        std::vector<float> xy;
-        if (!build_inverse_cdf(pdf.data(), h->nr, h->nz, xy))
-            return fail(h, FPIC_ERR_INVALID_ARG, ".source_pdf <- the first grid row carries no weight (the reference throws a TypeError here)");
-        float* stage = nullptr;
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), xy.size() * sizeof(float)));
-        hipError_t e = hipMemcpyAsync(stage, xy.data(), xy.size() * sizeof(float), hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) {
-            if (h->prec == FPIC_F32) convert_kernel<float, float><<<blocks_for(xy.size()), 256, 0, h->stream>>>(stage, static_cast<float*>(h->inv_cdf_xy), xy.size());
-            else convert_kernel<double, float><<<blocks_for(xy.size()), 256, 0, h->stream>>>(stage, static_cast<double*>(h->inv_cdf_xy), xy.size());
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        (void)hipFree(stage);
-        if (e != hipSuccess) return fail(h, FPIC_ERR_HIP, "inverse-CDF upload failed: %s", hipGetErrorString(e));
-        return FPIC_OK;
-    }
+    if (which == FPIC_GRID_SOURCE_PDF)
+        return h->prec == FPIC_F32 ? (dtype == FPIC_F32 ? set_source_pdf<float, float>(h, static_cast<const float*>(data))
+                                                        : set_source_pdf<float, double>(h, static_cast<const double*>(data)))
+                                   : (dtype == FPIC_F32 ? set_source_pdf<double, float>(h, static_cast<const float*>(data))
+                                                        : set_source_pdf<double, double>(h, static_cast<const double*>(data)));
     if (h->prec == FPIC_F32)
         return dtype == FPIC_F32 ? set_grid_t<float, float>(h, which, static_cast<const float*>(data), ncomp)
                                  : set_grid_t<float, double>(h, which, static_cast<const double*>(data), ncomp);

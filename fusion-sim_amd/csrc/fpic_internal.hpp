@@ -30,6 +30,5 @@ struct Constants {
 Constants derive_constants(const fpic_spec& s);
 double shader_literal(double x);
 void build_stamp(float w[kStampCells]);
-bool build_inverse_cdf(const double* pdf, int nr, int nz, std::vector<float>& table_xy);
 
 } // namespace fpic
