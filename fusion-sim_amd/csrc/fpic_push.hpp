@@ -124,9 +124,6 @@ constexpr int kPushThreads = 512;
 constexpr int kNbr = 5;                                // tile neighbourhood tracked in LDS when binning
 constexpr int kNbrSlots = kNbr * kNbr + 1;             // + the bin of clipped particles
 constexpr int kOwnSlot = (kNbr * kNbr) / 2;            // the workgroup's own tile
-constexpr int kStageWords = 260;                       // 256 particles of a wave + 3 words of alignment shift, 16-byte multiple
-typedef uint32_t nat_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t unaligned_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // LDS pointers carry their address space in the type: through a generic pointer the
 // compiler emits flat_load instead of ds_read_b128.  (HIP's float4/double2 classes
@@ -450,24 +447,22 @@ __global__ __launch_bounds__(256) void push_kernel(PushArgs<T> a)
 //
 // SCATTER (needs FUSE) makes this launch the re-binning as well.  The bin of a
 // particle is the tile of the state it is LOADED with — exactly what the previous
-// launch's census counted, from which the host has laid out dst_tile_start.  Per
-// sweep of the chunk the workgroup ranks its particles per bin in LDS, reserves one
-// range per bin with a single global atomic, and stores each final state at
-// start + range + rank in the other particle set.  Consecutive lanes get
-// consecutive ranks, so the 4-byte stores of a wave coalesce.
+// launch's census counted, from which the host has laid out dst_tile_start.  The
+// workgroup first counts its chunk per bin, reserves one range per bin, then pushes
+// and stores each final state at range + rank of arrival in the other particle set.
 template <typename T>
 constexpr size_t push_sums_offset() { return (static_cast<size_t>(kPushLds) * kPushLds * (12 * sizeof(T) + 1) + 15) / 16 * 16; }
 template <typename T>
-constexpr size_t push_stage_offset() // per-wave 1 KiB transposition buffers of the re-binning stores
+constexpr size_t push_stage_offset() // end of: coefficient window | sink bytes | double sums | census | ranks | ranges
 {
     return (push_sums_offset<T>() + static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double) +
-            (1 + 2 * (kPushThreads / 64)) * kNbrSlots * sizeof(uint32_t) + 15) / 16 * 16;
+            3 * kNbrSlots * sizeof(uint32_t) + 15) / 16 * 16;
 }
 template <typename T, bool FUSE>
 constexpr size_t push_tiles_lds_bytes()
 {
     // coefficient window | sink bytes | double sums window | census | per-wave ranks | per-wave ranges
-    return FUSE ? push_stage_offset<T>() + (kPushThreads / 64) * kStageWords * sizeof(uint32_t) : push_sums_offset<T>();
+    return FUSE ? push_stage_offset<T>() : push_sums_offset<T>();
 }
 
 template <typename T, bool FUSE, bool SCATTER, bool CTR>
@@ -483,8 +478,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
     FPIC_LDS double* lsums = (FPIC_LDS double*)((FPIC_LDS unsigned char*)push_lds + push_sums_offset<T>());
     FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lsums + SW * SW * 4);
     FPIC_LDS uint32_t* lrank = lcensus + kNbrSlots;
-    FPIC_LDS uint32_t* lrange = lrank + (kPushThreads / 64) * kNbrSlots;
-    FPIC_LDS uint32_t* lstage = (FPIC_LDS uint32_t*)((FPIC_LDS unsigned char*)push_lds + push_stage_offset<T>());
+    FPIC_LDS uint32_t* lrange = lrank + kNbrSlots;
     if (blockIdx.x >= *t.nwork) return;
     const BlockWork w = t.work[blockIdx.x];
     const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>(w.tile / t.ntx);
@@ -509,7 +503,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
     }
     if constexpr (FUSE) {
         for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) lsums[k] = 0.0;
-        for (int k = threadIdx.x; k < (1 + 2 * (kPushThreads / 64)) * kNbrSlots; k += kPushThreads) lcensus[k] = 0;
+        if (threadIdx.x < 3 * kNbrSlots) lcensus[threadIdx.x] = 0;
     }
     __syncthreads();
     const WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
@@ -531,123 +525,82 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             store_state<T, CTR>(a, base, cnt, q);
         }
     } else {
-        // Ranks and ranges are kept per WAVE (its own 26 counters in LDS): the lanes of a
-        // wave run in lockstep, so the three phases below need no workgroup barrier and the
-        // waves of the (single resident) workgroup keep overlapping loads with arithmetic.
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        FPIC_LDS uint32_t* wrank = lrank + wave * kNbrSlots;
-        FPIC_LDS uint32_t* wrange = lrange + wave * kNbrSlots;
-        FPIC_LDS uint32_t* wstage = lstage + wave * kStageWords;
-        for (size_t g0 = g_begin + static_cast<size_t>(wave) * 64; g0 < g_end; g0 += kPushThreads) {
-            const size_t g = g0 + lane;
-            const bool active = g < g_end;
+        // Pass A: count the chunk's LOADED states per destination bin (one extra read of
+        // x, y, z), then reserve ONE range per bin for the whole chunk.  Everything this
+        // workgroup writes into a bin is then one contiguous run (ranks are handed out by
+        // LDS atomics in lane order), so cache lines are completed by a single L2 instead of
+        // being written piecemeal by many workgroups on several XCDs.
+        for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
             const size_t base = g * PPT;
-            const int cnt = !active ? 0 : ((base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base));
-            Particle<T> q[PPT];
-            uint32_t dest[PPT], pid[PPT];
-            int slot[PPT];
-            if (active) {
-                load_state<T, CTR>(a, base, cnt, q);
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    dest[k] = 0; pid[k] = 0; slot[k] = -2;
-                    if (k < cnt) {
-                        pid[k] = t.id[base + k];
-                        int ic = 0, jc = 0;
-                        const bool visible = sprite_cell(q[k], a.nr, a.nz, ic, jc);
-                        uint32_t key;
-                        slot[k] = nb.slot(visible, ic, jc, key);
-                        if (slot[k] >= 0) dest[k] = __hip_atomic_fetch_add(wrank + slot[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        else dest[k] = t.dst_tile_start[key] + atomicAdd(t.dst_tile_cursor + key, 1u);
-                    }
-                }
-            }
-            // same wave, LDS operations complete in order: fence the compiler, not the hardware
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // one returning global atomic per occupied bin; its result is first used after the
-            // sub-steps below, which hide its latency
-            uint32_t my_count = 0, my_start = 0;
-            if (lane < kNbrSlots) {
-                my_count = wrank[lane];
-                if (my_count) {
-                    const uint32_t bin = nb.bin_of_slot(lane);
-                    my_start = t.dst_tile_start[bin] + atomicAdd(t.dst_tile_cursor + bin, my_count);
-                }
-                wrank[lane] = 0;
-            }
-            if (active)
-                advance_state<T, CTR>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
-            if (lane < kNbrSlots) wrange[lane] = my_start;
-            // the wave's particles that stay in the workgroup's own tile (nearly all of them)
-            // occupy one contiguous range [own_start, own_start + own_count) of every array
-            const uint32_t own_count = __shfl(my_count, kOwnSlot);
-            const uint32_t own_start = __shfl(my_start, kOwnSlot);
-            const uint32_t shift = own_start & 3u; // staging is shifted so that 16-byte stores are aligned
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            bool own[PPT];
+            const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+            T px[PPT], py[PPT], pz[PPT];
+            load_lane<T, PPT>(a.slab + 0 * a.stride, base, px);
+            load_lane<T, PPT>(a.slab + 1 * a.stride, base, py);
+            load_lane<T, PPT>(a.slab + 2 * a.stride, base, pz);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                own[k] = false;
                 if (k < cnt) {
-                    if (slot[k] >= 0) dest[k] += wrange[slot[k]];
-                    own[k] = slot[k] == kOwnSlot;
+                    Particle<T> p;
+                    p.x = px[k]; p.y = py[k]; p.z = pz[k];
+                    p.r = sqrt_(p.x * p.x + p.y * p.y);
+                    int ic = 0, jc = 0;
+                    const bool visible = sprite_cell(p, a.nr, a.nz, ic, jc);
+                    uint32_t key;
+                    const int sl = nb.slot(visible, ic, jc, key);
+                    if (sl >= 0) __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            // Stores.
-            // (1) Each array's words of the own-tile particles are transposed through the wave's
-            //     LDS buffer into destination order and leave as one aligned 16-byte store per
-            //     lane; the up to three words in front of the first and behind the last whole
-            //     vector go out in one masked store from lanes 0-5.
-            const uint32_t end = shift + own_count;                       // staging indices [shift, end)
-            const uint32_t vstart = (shift + 3u) & ~3u, vend = end & ~3u; // whole vectors cover [vstart, vend)
-            const uint32_t first = 4u * lane;
-            const bool whole = first >= vstart && first + 4u <= vend;
-            uint32_t edge = ~0u; // staging index this lane stores singly, if any
-            if (lane < 3) { const uint32_t i = shift + lane; if (i < (vstart < end ? vstart : end)) edge = i; }
-            else if (lane < 6) { const uint32_t i = (vend > vstart ? vend : vstart) + (lane - 3); if (i < end) edge = i; }
-#pragma unroll
-            for (int f = 0; f < 11; ++f) {
-                if (CTR && f >= 6 && f < 10) continue; // no random state to move
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    if (own[k]) {
-                        const T v = f == 0 ? q[k].x : f == 1 ? q[k].y : f == 2 ? q[k].z : f == 3 ? q[k].vx : f == 4 ? q[k].vy
-                                  : f == 5 ? q[k].vz : f == 6 ? q[k].u1 : f == 7 ? q[k].u2 : f == 8 ? q[k].c1 : q[k].c2;
-                        wstage[shift + dest[k] - own_start] = f < 10 ? __builtin_bit_cast(uint32_t, v) : pid[k];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // word i of the staging buffer belongs at element own_start - shift + i
-                uint32_t* out = (f < 10 ? reinterpret_cast<uint32_t*>(t.dst_slab + f * a.stride) : t.dst_id) + (own_start - shift);
-                if (whole) *reinterpret_cast<nat_u32x4*>(out + first) = *reinterpret_cast<const FPIC_LDS nat_u32x4*>(wstage + first);
-                if (edge != ~0u) out[edge] = wstage[edge];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        if (threadIdx.x < kNbrSlots) {
+            const uint32_t c = lrank[threadIdx.x];
+            uint32_t start = 0;
+            if (c) {
+                const uint32_t bin = nb.bin_of_slot(threadIdx.x);
+                start = t.dst_tile_start[bin] + atomicAdd(t.dst_tile_cursor + bin, c);
             }
-            // (2) alive bytes, and the particles that changed tile since the last binning (about
-            //     a quarter of them after four frames at the bench's temperature): stored singly
+            lrange[threadIdx.x] = start;
+            lrank[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        // Pass B: the push proper; a particle's place is its bin's range + its rank of arrival
+        for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
+            const size_t base = g * PPT;
+            const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+            Particle<T> q[PPT];
+            uint32_t dest[PPT], pid[PPT];
+            load_state<T, CTR>(a, base, cnt, q);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                dest[k] = 0; pid[k] = 0;
+                if (k < cnt) {
+                    pid[k] = t.id[base + k];
+                    int ic = 0, jc = 0;
+                    const bool visible = sprite_cell(q[k], a.nr, a.nz, ic, jc);
+                    uint32_t key;
+                    const int sl = nb.slot(visible, ic, jc, key);
+                    if (sl >= 0) dest[k] = lrange[sl] + __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else dest[k] = t.dst_tile_start[key] + atomicAdd(t.dst_tile_cursor + key, 1u); // beyond the 5x5 tiles: rare
+                }
+            }
+            advance_state<T, CTR>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 if (k < cnt) {
                     const size_t d = dest[k];
-                    t.dst_alive[d] = q[k].alive ? 1 : 0;
-                    if (!own[k]) {
-                        t.dst_slab[0 * a.stride + d] = q[k].x; t.dst_slab[1 * a.stride + d] = q[k].y; t.dst_slab[2 * a.stride + d] = q[k].z;
-                        t.dst_slab[3 * a.stride + d] = q[k].vx; t.dst_slab[4 * a.stride + d] = q[k].vy; t.dst_slab[5 * a.stride + d] = q[k].vz;
-                        if constexpr (!CTR) {
-                            t.dst_slab[6 * a.stride + d] = q[k].u1; t.dst_slab[7 * a.stride + d] = q[k].u2;
-                            t.dst_slab[8 * a.stride + d] = q[k].c1; t.dst_slab[9 * a.stride + d] = q[k].c2;
-                        }
-                        t.dst_id[d] = pid[k];
+                    t.dst_slab[0 * a.stride + d] = q[k].x; t.dst_slab[1 * a.stride + d] = q[k].y; t.dst_slab[2 * a.stride + d] = q[k].z;
+                    t.dst_slab[3 * a.stride + d] = q[k].vx; t.dst_slab[4 * a.stride + d] = q[k].vy; t.dst_slab[5 * a.stride + d] = q[k].vz;
+                    if constexpr (!CTR) {
+                        t.dst_slab[6 * a.stride + d] = q[k].u1; t.dst_slab[7 * a.stride + d] = q[k].u2;
+                        t.dst_slab[8 * a.stride + d] = q[k].c1; t.dst_slab[9 * a.stride + d] = q[k].c2;
                     }
+                    t.dst_alive[d] = q[k].alive ? 1 : 0;
+                    t.dst_id[d] = pid[k];
                 }
             }
-            // lrank was reset by the reserving lanes before the second barrier: the next sweep may start
         }
     }
+
 
     if constexpr (FUSE) {
         __syncthreads();
