@@ -80,23 +80,14 @@ template <typename T> struct NatVec16;
 template <> struct NatVec16<float> { using type = nat_f32x4; };
 template <> struct NatVec16<double> { using type = nat_f64x2; };
 
-// FPIC_STREAM_LOAD_AUX / FPIC_STREAM_STORE_AUX (development switches): route the streams
-// through buffer instructions with explicit gfx950 cache-policy bits (1 = sc0, 2 = nt,
-// 16 = sc1) to compare what each policy leaves in the XCD's L2.
-typedef unsigned int nat_b128 __attribute__((ext_vector_type(4)));
-
+// (Tried and rejected on gfx950, profiles/r01_cache_policy.txt: sc1 / sc0 sc1 write-through
+// stores and sc1 loads through buffer instructions; none beat nt loads + nt stores.)
 template <typename T, int N>
 __device__ __forceinline__ void load_lane(const T* arr, size_t base, T (&o)[N])
 {
     using V = typename NatVec16<T>::type;
     static_assert(N == Vec16<T>::N, "one 16-byte vector per lane");
-#ifdef FPIC_STREAM_LOAD_AUX
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(arr), 0, 0xFFFFFFF0u, 0x00020000);
-    const nat_b128 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(base * sizeof(T)), 0, FPIC_STREAM_LOAD_AUX);
-    const V v = __builtin_bit_cast(V, raw);
-#else
     const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(arr + base));
-#endif
     if constexpr (N == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
     else { o[0] = v.x; o[1] = v.y; }
 }
@@ -108,12 +99,7 @@ __device__ __forceinline__ void store_lane(T* arr, size_t base, const T (&o)[N])
     V v;
     if constexpr (N == 4) { v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3]; }
     else { v.x = o[0]; v.y = o[1]; }
-#ifdef FPIC_STREAM_STORE_AUX
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(arr, 0, 0xFFFFFFF0u, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nat_b128, v), rsrc, static_cast<int>(base * sizeof(T)), 0, FPIC_STREAM_STORE_AUX);
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<V*>(arr + base));
-#endif
 }
 
 // ------------------------------------------------------------------ scatter (K4), stage 1

@@ -123,7 +123,6 @@ constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
 constexpr int kPushThreads = 512;
 constexpr int kNbr = 5;                                // tile neighbourhood tracked in LDS when binning
 constexpr int kNbrSlots = kNbr * kNbr + 1;             // + the bin of clipped particles
-constexpr int kOwnSlot = (kNbr * kNbr) / 2;            // the workgroup's own tile
 
 // LDS pointers carry their address space in the type: through a generic pointer the
 // compiler emits flat_load instead of ds_read_b128.  (HIP's float4/double2 classes
