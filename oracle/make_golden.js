@@ -13,6 +13,12 @@
  * values it set, and which resource each draw reads and writes.  No reference
  * source text (JS or GLSL) is written anywhere.
  *
+ * The swgl_* fixtures (section 8) are different in kind: there util.webGL is replaced by
+ * oracle/swgl.js, which EVALUATES the shader strings the reference hands to linkProgram
+ * (oracle/glsl_eval.js), so the reference's own set/precalc/step/density code and shader text
+ * run end to end in software.  They check the restatement's transcription of the shaders;
+ * see glsl_eval.js for what they cannot pin.
+ *
  * The fixtures travel to the GPU box; /root/reference does not.
  */
 'use strict';
@@ -20,6 +26,7 @@ const fs = require('fs');
 const path = require('path');
 const vm = require('vm');
 const zlib = require('zlib');
+const makeSoftwareGL = require('./swgl.js').makeSoftwareGL;
 
 const refRoot = process.argv[2] || '/root/reference';
 const outDir = process.argv[3] || path.join(__dirname, '..', 'tests', 'golden');
@@ -116,17 +123,24 @@ function makeRecorder() {
 let lcg = 12345;
 function nextU32() { lcg = (Math.imul(lcg, 1664525) + 1013904223) >>> 0; return lcg; }
 
-function makeReference() {
-    const r = makeRecorder();
+function makeReference(software) {
+    const r = software ? null : makeRecorder();
+    const sw = software ? makeSoftwareGL({ fbo: FBO_NAMES, tex: TEX_NAMES, prog: PROG_NAMES }) : null;
     const extra = {
         document: { createElement: function () { return { style: {} }; }, body: { appendChild: function () {} } },
         crypto: { getRandomValues: function (a) { for (let i = 0; i < a.length; i++) a[i] = nextU32(); } },
     };
+    if (software) {
+        // Math.random seeds the per-particle random state (empic.js:168-173)
+        const m = Object.create(Math);
+        m.random = function () { return nextU32() / 4294967296; };
+        extra.Math = m;
+    }
     const registry = {};
     const util = loadAmd('utilities', registry, extra);
-    util.webGL = function () { return r.webgl; };
+    util.webGL = function () { return software ? sw.gl : r.webgl; };
     const empic = loadAmd('empic', registry, extra);
-    return { empic: empic, util: util, rec: r.rec };
+    return { empic: empic, util: util, rec: r && r.rec, sw: sw && sw.state };
 }
 
 function f32list(a) { return Array.prototype.slice.call(a); }
@@ -286,5 +300,84 @@ writeJson('stamp.json', { nshape: 11, red: stamp });
     }
     writeJson('validation.json', msgs);
 })();
+
+// (8) the reference's shaders evaluated in software: small scenes, every pass
+function swglScene(name, cfg) {
+    lcg = cfg.seed;
+    const spec = cfg.spec;
+    const ref = makeReference(true);
+    const sim = ref.empic.makeCylindricalParticlePusher(spec);
+    const n = spec.nparticles * spec.nparticles;
+    const by = {};
+    ref.sw.fbos.concat(ref.sw.texs).forEach(function (t) { by[t.name] = t; });
+    let s = cfg.input_seed;
+    function rnd() { s = (Math.imul(s, 1103515245) + 12345) >>> 0; return s / 4294967296; }
+    const pos = [], vel = [], E = [], B = [], sink = [], pdf = [];
+    for (let p = 0; p < n; p++) {
+        const rr = cfg.r_max * spec.radius * Math.sqrt(rnd()), th = 6.283185307179586 * rnd();
+        pos.push([rr * Math.cos(th), rr * Math.sin(th), spec.height * (0.05 + 0.9 * rnd())]);
+        vel.push([cfg.v * (rnd() - 0.5), cfg.v * (rnd() - 0.5), cfg.v * (rnd() - 0.5)]);
+    }
+    for (let i = 0; i < spec.nr; i++) {
+        E.push([]); B.push([]); sink.push([]); pdf.push([]);
+        for (let j = 0; j < spec.nz; j++) {
+            E[i].push([cfg.E * (rnd() - 0.5), cfg.E * (rnd() - 0.5), cfg.E * (rnd() - 0.5)]);
+            B[i].push([cfg.B * (rnd() - 0.5), cfg.B * (rnd() - 0.5), cfg.B * rnd()]);
+            sink[i].push(cfg.sink(i, j));
+            pdf[i].push(cfg.pdf(i, j, rnd));
+        }
+    }
+    const chunks = [], index = {};
+    let offset = 0;
+    function snap(stage, names) {
+        names.forEach(function (nm) {
+            const a = new Float32Array(by[nm].array);
+            index[stage + '/' + nm] = [offset, a.length];
+            chunks.push(Buffer.from(a.buffer));
+            offset += a.length;
+        });
+    }
+    const rand0 = f32list(by.rand_tex.array);
+    sim.set({ E: E, B: B, position: pos, velocity: vel, sink_mask: sink, source_pdf: pdf });
+    snap('set', ['position_A', 'velocity_A', 'rand_A', 'E', 'B', 'sink_mask']);
+    cfg.painters.forEach(function (c) { sim[c[0]].apply(sim, c.slice(1)); });
+    snap('painted', ['E', 'B']);
+    sim.precalc();
+    snap('precalc', ['R1', 'R2', 'R3', 'A']);
+    for (let k = 1; k <= cfg.frames; k++) {
+        sim.step();
+        snap('step' + k, ['position_A', 'velocity_A', 'rand_A']);
+        sim.density();
+        snap('density' + k, ['moments01', 'moments01_norm', 'moments01_avgA', 'moments01_avgB']);
+    }
+    fs.writeFileSync(path.join(outDir, name + '.f32.gz'), zlib.gzipSync(Buffer.concat(chunks), { level: 9 }));
+    writeJson(name + '.json', {
+        what: "outputs of the reference's own host code and shader strings evaluated by oracle/swgl.js + glsl_eval.js (float32 per operation); pins transcription, not GPU arithmetic",
+        spec: spec, frames: cfg.frames, entropy_lcg_seed: cfg.seed,
+        entropy_rule: 'u32 stream x <- 1664525*x + 1013904223 (mod 2^32), texel value = float32(x / 0xFFFFFFFF), 4*1024*1024 values in order',
+        position_in: pos, velocity_in: vel, E_in: E, B_in: B, sink_in: sink, pdf_in: pdf, rand0: rand0,
+        painters: cfg.painters,
+        layout: 'RGBA float32, texel 4*(i + width*j)', file: name + '.f32.gz', index: index,
+    });
+}
+
+// electrons in a squat cylinder, sink frame, block source: deaths and re-injection every frame
+swglScene('swgl_scene', {
+    seed: 0x5EED0008, input_seed: 99, frames: 6, r_max: 0.94, v: 0.3, E: 2e5, B: 0.02,
+    spec: { radius: 0.35, height: 0.2, nr: 24, nz: 16, dt: 5e-10, nparticles: 12, particle_mass: 9.109e-31, particle_charge: -1.602e-19 },
+    sink: function (i, j) { return (i === 23 || j === 0 || j === 15) ? 0 : 1; },
+    pdf: function (i, j, rnd) { return (i < 6 && j >= 5 && j < 11) ? 0.5 + rnd() : 0.0; },
+    painters: [['addCurrentLoop', 0.2, 0.1, 4e4], ['addCurrentZ', 3e3], ['addBZ', 0.01], ['addBTheta', -0.005]],
+});
+// protons in the demo's 1 x 2 m proportions (factor_r != factor_z), no sink on the outer walls so
+// particles leave the unit square (clamped lookups, whole-point clipping in the deposit), an
+// absorbing slab inside, and a source with empty rows (NaN sites of the inverse CDF, quirk Q3)
+swglScene('swgl_tall', {
+    seed: 0x5EED0009, input_seed: 4242, frames: 5, r_max: 0.99, v: 0.25, E: 3e6, B: 1.5,
+    spec: { radius: 1, height: 2, nr: 20, nz: 40, dt: 2e-9, nparticles: 10, particle_mass: 1.67e-27, particle_charge: 1.602e-19 },
+    sink: function (i, j) { return (i >= 8 && i < 12 && j >= 10 && j < 30) ? 0 : 1; },
+    pdf: function (i, j, rnd) { return (i % 3 === 1 || j < 4) ? 0.0 : 0.25 + rnd(); },
+    painters: [['addCurrentLoop', 0.8, 2.0, -1e7], ['addCurrentLoop', 0.8, 0.0, 1e7], ['addBZ', 0.3]],
+});
 
 console.log('golden fixtures written to ' + outDir);

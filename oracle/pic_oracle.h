@@ -15,8 +15,13 @@
  *   literals derived from them, the normalised particle upload, the E/B/sink
  *   texture packing, the 512x512 inverse-CDF table (NaN sites included), and the
  *   pass order and per-pass texture bindings of step() and density().
- * The per-fragment arithmetic (K1-K6, K8, K9) is "parity unpinned": it follows the
- * shader text line by line and is cross-checked by analytic single-particle tests.
+ * The per-fragment arithmetic (K1-K6, K8-K12) is pinned as a TRANSCRIPTION of the shader
+ * text: tests/golden/swgl_scene.* hold every texture of a scene that the reference's own
+ * host code and shader strings produced under a software evaluator (oracle/swgl.js,
+ * oracle/glsl_eval.js; IEEE float32 per operation), and this restatement reproduces them
+ * bit for bit (tests/test_oracle_swgl.py).  It remains "parity unpinned" with respect to a
+ * real GPU: what a GLSL compiler does with that text (built-in precision, contraction,
+ * rasteriser ties) is implementation-defined and cannot be observed in this image.
  *
  * Two instantiations of every kernel: orc_f32_* (float, the reference's precision)
  * and orc_f64_* (double).  Arrays are RGBA textures, texel (i,j) at 4*(i + j*W).

@@ -641,6 +641,59 @@ def test_current_loop_matches_oracle(fp, po):
     assert np.abs(got - want).max() <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("scene", ["swgl_scene", "swgl_tall"])
+def test_against_reference_shaders_evaluated_in_software(fp, scene):
+    """No oracle in between: the HIP path against tests/golden/swgl_*, the outputs of the
+    reference's own host code and shader strings evaluated in software (oracle/make_golden.js
+    section 8).  Driven from the fixture's painted fields, every particle texel of six frames is
+    bit-exact and the density buffers are within the fp32 bar."""
+    meta = load_json(scene + ".json")
+    blob = load_f32gz(meta["file"])
+    get = lambda key: blob[meta["index"][key][0]: meta["index"][key][0] + meta["index"][key][1]]
+    spec, nr, nz = meta["spec"], meta["spec"]["nr"], meta["spec"]["nz"]
+    from test_oracle_swgl import lcg_entropy
+
+    sim = fp.makeCylindricalParticlePusher(spec, precision="fp32")
+    sim.set(position=meta["position_in"], velocity=meta["velocity_in"], E=meta["E_in"], B=meta["B_in"],
+            sink_mask=meta["sink_in"], source_pdf=meta["pdf_in"])
+    sim.setRandomState(lcg_entropy(meta["entropy_lcg_seed"]), np.asarray(meta["rand0"], dtype=np.float32).reshape(-1, 4))
+    got = sim.getParticles()
+    assert same_bits(got["position"], get("set/position_A").reshape(-1, 4)[:, :3])
+    assert same_bits(got["velocity"], get("set/velocity_A").reshape(-1, 4)[:, :3])
+    assert same_bits(sim.readGrid(fp.READ_E), get("set/E"))
+    assert same_bits(sim.readGrid(fp.READ_B), get("set/B"))
+
+    # painters: cos() in the loop shape -> tolerance; uniform adds exact
+    for call in meta["painters"]:
+        getattr(sim, call[0])(*call[1:])
+    want = get("painted/B").reshape(-1, 4)
+    gotB = sim.readGrid(fp.READ_B).reshape(-1, 4)
+    assert same_bits(gotB[:, 3], want[:, 3])
+    assert np.all(np.abs(gotB[:, :3] - want[:, :3]) <= 1e-5 * np.abs(want[:, :3]).max(axis=0))
+
+    # continue from the fixture's painted B (a float32 -> double -> float32 round trip is exact)
+    B_exact = get("painted/B").reshape(nz, nr, 4)[:, :, :3].transpose(1, 0, 2).astype(np.float64)
+    sim.set(B=B_exact)
+    sim.precalc()
+    for name, which in (("R1", fp.READ_R1), ("R2", fp.READ_R2), ("R3", fp.READ_R3), ("A", fp.READ_A)):
+        assert same_bits(sim.readGrid(which), get("precalc/" + name)), name
+    for k in range(1, meta["frames"] + 1):
+        sim.step()
+        got = sim.getParticles()
+        for name, key in (("position", "position_A"), ("velocity", "velocity_A")):
+            assert same_bits(got[name], get("step%d/%s" % (k, key)).reshape(-1, 4)[:, :3]), (k, name)
+        assert same_bits(got["rand"], get("step%d/rand_A" % k).reshape(-1, 4)), k
+        assert np.array_equal(got["alive"], (get("step%d/position_A" % k).reshape(-1, 4)[:, 3] > 0.5).astype(np.uint8))
+        sim.density()
+        for which, key in ((fp.READ_MOMENTS, "moments01"), (fp.READ_NORM, "moments01_norm")):
+            g, w = sim.readGrid(which).reshape(-1, 4), get("density%d/%s" % (k, key)).reshape(-1, 4)
+            assert np.array_equal(np.isnan(g), np.isnan(w)), (k, key)
+            np.testing.assert_allclose(g[:, 3], w[:, 3], rtol=RTOL32, atol=0)
+            for c in range(3):
+                ok = ~np.isnan(w[:, c])
+                assert np.abs(g[ok, c] - w[ok, c]).max() <= RTOL32 * np.abs(w[ok, c]).max(), (k, key, c)
+
+
 # ----------------------------------------------------------------------------- size-independent properties
 
 def test_large_run_properties(fp):
