@@ -182,4 +182,5 @@ exports.makeCylindricalParticlePusher = function (spec) {
 };
 
 exports.validate_object = validate_object;
+exports._addon = addon; // shared with matrix_native.js
 exports.buildArch = function () { return addon().buildArch(); };

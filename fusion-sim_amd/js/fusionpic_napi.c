@@ -356,6 +356,8 @@ static napi_value n_build_arch(napi_env env, napi_callback_info info)
     return s;
 }
 
+int fusionsor_register(napi_env env, napi_value exports); /* fusionsor_napi.c */
+
 static napi_value init(napi_env env, napi_value exports)
 {
     struct { const char* name; napi_callback fn; } table[] = {
@@ -374,6 +376,10 @@ static napi_value init(napi_env env, napi_value exports)
             napi_throw_error(env, NULL, "addon initialisation failed");
             return NULL;
         }
+    }
+    if (!fusionsor_register(env, exports)) {
+        napi_throw_error(env, NULL, "addon initialisation failed");
+        return NULL;
     }
     return exports;
 }

@@ -17,7 +17,7 @@
  * Supported: precision / uniform / varying / attribute declarations; void main(); float,
  * vec2-4 locals; = and += ; if / else; for (float i = a; i < b; i++); ternaries; + - * / ;
  * comparisons; || && ; swizzles; constructors; texture2D, sqrt, length, dot, cross, cos,
- * sign, abs, min, max; gl_FragColor, gl_Position, gl_PointSize, gl_PointCoord.
+ * sign, abs, min, max, floor, fract, mod; gl_FragColor, gl_Position, gl_PointSize, gl_PointCoord.
  */
 'use strict';
 
@@ -190,6 +190,10 @@ function sample(tex, uv) {
 const BUILTINS = {
     sqrt: function (a) { return isVec(a[0]) ? a[0].map(function (x) { return f(Math.sqrt(x)); }) : f(Math.sqrt(a[0])); },
     cos: function (a) { return f(Math.cos(a[0])); },
+    floor: function (a) { return isVec(a[0]) ? a[0].map(Math.floor) : Math.floor(a[0]); },
+    fract: function (a) { const g = function (x) { return f(x - Math.floor(x)); }; return isVec(a[0]) ? a[0].map(g) : g(a[0]); },
+    // mod(x, y) = x - y * floor(x / y), each step rounded (GLSL ES 1.00 section 8.3)
+    mod: function (a) { return map2(a[0], a[1], function (x, y) { return f(x - f(y * Math.floor(f(x / y)))); }); },
     abs: function (a) { return isVec(a[0]) ? a[0].map(Math.abs) : Math.abs(a[0]); },
     sign: function (a) { const s = function (x) { return x > 0 ? 1 : (x < 0 ? -1 : 0); }; return isVec(a[0]) ? a[0].map(s) : s(a[0]); },
     min: function (a) { return map2(a[0], a[1], function (x, y) { return y < x ? y : x; }); },

@@ -380,4 +380,66 @@ swglScene('swgl_tall', {
     painters: [['addCurrentLoop', 0.8, 2.0, -1e7], ['addCurrentLoop', 0.8, 0.0, 1e7], ['addBZ', 0.3]],
 });
 
+// (9) the reference's dense iterative solver (matrix_webgl.js, SURVEY 8(f) next-4), evaluated in
+// software the same way as section 8.  Inputs are float32-representable and stored in the blob.
+(function () {
+    const quiet = { log: function () {} };       // solve() prints R, C and every iterate
+    const chunks = [], cases = {};
+    let offset = 0;
+    function put(arr) {
+        const a = new Float32Array(arr);
+        const at = [offset, a.length];
+        chunks.push(Buffer.from(a.buffer));
+        offset += a.length;
+        return at;
+    }
+    function run(name, cfg) {
+        const sw = makeSoftwareGL({ fbo: ['x_guess', 'x_result', 'x_stats', 'R', 'C', 'mv_product'], tex: ['m_set', 'x_set', 'b_set'] });
+        const registry = {};
+        const extra = { console: quiet, document: {} };
+        loadAmd('utilities', registry, extra);
+        const mw = loadAmd('matrix_webgl', registry, extra);
+        const spec = { n_power: cfg.n_power, webgl: sw.gl };
+        if (cfg.relaxation !== undefined) spec.relaxation = cfg.relaxation;
+        const eq = mw.makeSORIterative(spec);
+        const L = eq.vec_length;
+        let s = cfg.seed;
+        function rnd() { s = (Math.imul(s, 1103515245) + 12345) >>> 0; return s / 4294967296; }
+        const A = [], Aflat = new Float32Array(L * L), b = [], x0 = [];
+        for (let r = 0; r < L; r++) {
+            A.push([]);
+            let off = 0;
+            for (let c = 0; c < L; c++) { const v = Math.fround((rnd() - 0.5) * cfg.coupling); A[r].push(v); off += Math.abs(v); }
+            A[r][r] = Math.fround(cfg.dominance * off + 1 + rnd());
+            for (let c = 0; c < L; c++) Aflat[c + L * r] = A[r][c];
+            b.push(Math.fround(2 * rnd() - 1));
+            x0.push(Math.fround(cfg.x0 * (rnd() - 0.5)));
+        }
+        const by = {};
+        sw.state.fbos.forEach(function (t) { if (t.name) by[t.name] = t; });
+        const out = { n_power: cfg.n_power, relaxation: cfg.relaxation === undefined ? null : cfg.relaxation, vec_length: L,
+            vec_height: eq.vec_height, A: put(Aflat), b: put(b), x0: put(x0), calls: [] };
+        eq.set_matrix(A).set_b(b).init_vector(x0);
+        out.x_after_init = put(by.x_result.array);
+        cfg.calls.forEach(function (params) {
+            const res = eq.solve(params);
+            out.calls.push({ params: params, correlation: Number.isNaN(res.correlation) ? 'NaN' : res.correlation, diff: res.diff, iterations: res.iterations,
+                result: put(res.result), x_result: put(by.x_result.array), x_guess: put(by.x_guess.array),
+                x_stats: put(by.x_stats.array), R: put(by.R.array), C: put(by.C.array) });
+        });
+        cases[name] = out;
+    }
+    run('p1_jacobi', { n_power: 1, seed: 11, coupling: 1.0, dominance: 1.5, x0: 0.0,
+        calls: [{ tolerance: 1e-7, max_iterations: 1 }, { tolerance: 1e-7, max_iterations: 1 }, { tolerance: 1e-7, max_iterations: 6 }] });
+    run('p2_relaxed', { n_power: 2, relaxation: 0.8, seed: 22, coupling: 0.5, dominance: 1.2, x0: 1.0,
+        calls: [{ tolerance: 1e-6, substep: 2, max_iterations: 4 }, { tolerance: 0.5, max_iterations: 50 }] });
+    run('p3_jacobi', { n_power: 3, seed: 33, coupling: 0.25, dominance: 2.0, x0: 0.5,
+        calls: [{ tolerance: 1e-5, max_iterations: 5 }, { tolerance: 1e-5 }] });
+    fs.writeFileSync(path.join(outDir, 'swgl_sor.f32.gz'), zlib.gzipSync(Buffer.concat(chunks), { level: 9 }));
+    writeJson('swgl_sor.json', {
+        what: "the reference's makeSORIterative (host code and shader strings) evaluated by oracle/swgl.js + glsl_eval.js; arrays are [offset, length] into the float32 blob; A is row-major A[col + L*row]",
+        file: 'swgl_sor.f32.gz', cases: cases,
+    });
+})();
+
 console.log('golden fixtures written to ' + outDir);

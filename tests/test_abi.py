@@ -18,10 +18,13 @@ LIB = os.path.join(ROOT, "fusion-sim_amd", "lib", "libfusionpic.so")
 ADDON = os.path.join(ROOT, "fusion-sim_amd", "lib", "fusionpic_napi.node")
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+SOR_HEADER = os.path.join(ROOT, "include", "fusionsor.h")
+
+
+def declared_symbols(header=HEADER, prefix="fpic_"):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fpic_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z_0-9]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")
@@ -51,6 +54,38 @@ def test_header_symbols_are_all_exported(fp):
     lib.fpic_build_arch.restype = ctypes.c_char_p
     assert lib.fpic_build_arch() == b"gfx950"
     assert lib.fpic_abi_version() == 1
+
+
+def test_solver_header_symbols_are_all_exported(fp):
+    """include/fusionsor.h (the dense iterative solver)."""
+    from fusionpic import sor
+    lib = ctypes.CDLL(LIB)
+    syms = declared_symbols(SOR_HEADER, "fsor_")
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(lib, s), "libfusionpic.so does not export " + s
+    assert sorted(sor.ABI_FUNCTIONS) == syms
+    assert lib.fsor_abi_version() == 1
+    text = open(SOR_HEADER).read()
+    for cite in ("matrix_webgl.js:35-711", "matrix_webgl.js:36-40", ":566-697", ":456-475", ":389-424"):
+        assert cite in text
+
+
+def test_solver_validation_and_no_cpu_fallback(fp):
+    from fusionpic import sor
+    with pytest.raises(fp.FusionPicError) as e:
+        sor.makeSORIterative({})
+    assert str(e.value) == ".n_power <- Non-optional property is undefined!"
+    with pytest.raises(fp.FusionPicError) as e:
+        sor.makeSORIterative({"n_power": "3"})
+    assert str(e.value) == ".n_power <- Property does not match any given possible types!"
+    with pytest.raises(fp.FusionPicError) as e:
+        sor.makeSORIterative({"n_power": 0})      # the reference throws while linking programResult
+    assert "u_Vsum" in str(e.value)
+    if not has_gpu():
+        with pytest.raises(fp.FusionPicError) as e:
+            sor.makeSORIterative({"n_power": 2})
+        assert e.value.code == -2 and "no CPU fallback" in str(e.value)
 
 
 def test_header_cites_reference_lines():

@@ -1,0 +1,205 @@
+"""GPU parity tests of the dense iterative solver, through the C ABI
+(include/fusionsor.h): against tests/golden/swgl_sor.* (the reference's own makeSORIterative
+evaluated in software) directly, against the CPU restatement (oracle/sor_oracle.c) at sizes the
+fixture does not hold, and through size-independent properties at a size the oracle cannot reach.
+All outputs are float32 produced by the same operation tree, so the bar is bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import load_f32gz, load_json, same_bits
+
+pytestmark = pytest.mark.gpu
+
+META = load_json("swgl_sor.json")
+BLOB = load_f32gz(META["file"])
+
+
+def arr(at):
+    return BLOB[at[0]: at[0] + at[1]]
+
+
+def num(v):
+    return float("nan") if v == "NaN" else float(v)
+
+
+def same_number(a, b):
+    return (np.isnan(a) and np.isnan(b)) or a == b
+
+
+@pytest.fixture(scope="module")
+def sor():
+    from fusionpic import sor
+    return sor
+
+
+def dominant_system(L, seed, coupling=0.5, dominance=1.5):
+    rng = np.random.default_rng(seed)
+    A = ((rng.random((L, L)) - 0.5) * coupling).astype(np.float32)
+    off = np.abs(A).sum(axis=1) - np.abs(np.diag(A))
+    A[np.arange(L), np.arange(L)] = (dominance * off + 1 + rng.random(L)).astype(np.float32)
+    b = (2 * rng.random(L) - 1).astype(np.float32)
+    x0 = (rng.random(L) - 0.5).astype(np.float32)
+    return A, b, x0
+
+
+@pytest.mark.parametrize("name", sorted(META["cases"]))
+def test_against_reference_solver_evaluated_in_software(sor, name):
+    case = META["cases"][name]
+    L = case["vec_length"]
+    spec = {"n_power": case["n_power"]}
+    if case["relaxation"] is not None:
+        spec["relaxation"] = case["relaxation"]
+    eq = sor.makeSORIterative(spec)
+    assert (eq.vec_length, eq.vec_height) == (L, case["vec_height"])
+    eq.set_matrix(arr(case["A"]).reshape(L, L)).set_b(arr(case["b"])).init_vector(arr(case["x0"]))
+    assert same_bits(eq.readVector(sor.X_RESULT), arr(case["x_after_init"]))
+    for call in case["calls"]:
+        res = eq.solve(call["params"])
+        assert same_bits(eq.readIterationMatrix(), arr(call["R"])), "iteration matrix"
+        assert same_bits(eq.readVector(sor.VEC_C), arr(call["C"])), "constant vector"
+        assert res["iterations"] == call["iterations"]
+        assert same_bits(eq.readVector(sor.X_RESULT), arr(call["x_result"]))
+        assert same_bits(eq.readVector(sor.X_GUESS), arr(call["x_guess"]))
+        if call["iterations"]:
+            assert same_bits(eq.readVector(sor.X_STATS), arr(call["x_stats"]))
+        assert same_bits(res["result"], arr(call["result"]))
+        assert same_number(res["diff"], num(call["diff"]))
+        assert same_number(res["correlation"], num(call["correlation"]))
+    eq.close()
+
+
+@pytest.mark.parametrize("n_power,relaxation", [(1, None), (2, 1.3), (3, 0.6), (4, None), (5, 0.9)])
+def test_against_the_oracle_at_other_sizes(sor, n_power, relaxation):
+    """n_power 4 and 5 use the in-register part of the tree (4 and 16 texels per lane)."""
+    from sor_oracle import OracleSOR
+    L = 4 * 4 ** n_power
+    A, b, x0 = dominant_system(L, seed=100 + n_power)
+    spec = {"n_power": n_power}
+    if relaxation:
+        spec["relaxation"] = relaxation
+    eq, ora = sor.makeSORIterative(spec), OracleSOR(n_power, relaxation)
+    for s in (eq, ora):
+        s.set_matrix(A).set_b(b).init_vector(x0)
+    want = ora.solve(tolerance=1e-7, substep=2, max_iterations=3)
+    got = eq.solve({"tolerance": 1e-7, "substep": 2, "max_iterations": 3})
+    assert got["iterations"] == want["iterations"] == 3
+    assert same_bits(got["result"], want["result"])
+    assert same_bits(eq.readVector(sor.X_GUESS), ora.x_guess)
+    assert same_bits(eq.readVector(sor.X_STATS), ora.x_stats)
+    assert same_bits(eq.readIterationMatrix(), ora.build_R())
+    assert got["diff"] == want["diff"] and got["correlation"] == want["correlation"]
+    # mv_product() alone = one more product
+    eq.mv_product()
+    ora.solve(tolerance=0.0, max_iterations=1)
+    assert same_bits(eq.readVector(sor.X_RESULT), ora.x_result)
+    eq.close()
+
+
+def test_double_input_is_rounded_once(sor):
+    A, b, x0 = dominant_system(64, seed=7)
+    e32, e64 = sor.makeSORIterative({"n_power": 2}), sor.makeSORIterative({"n_power": 2})
+    e32.set_matrix(A).set_b(b).init_vector(x0)
+    e64.set_matrix(A.astype(np.float64)).set_b(b.astype(np.float64)).init_vector(x0.astype(np.float64))
+    r32 = e32.solve({"tolerance": 1e-6, "max_iterations": 4})
+    r64 = e64.solve({"tolerance": 1e-6, "max_iterations": 4})
+    assert same_bits(r32["result"], r64["result"])
+
+
+def test_state_errors(sor):
+    import fusionpic as fp
+    eq = sor.makeSORIterative({"n_power": 1})
+    with pytest.raises(fp.FusionPicError) as e:
+        eq.solve({"tolerance": 1e-3, "max_iterations": 1})
+    assert "set_matrix" in str(e.value)
+    with pytest.raises(fp.FusionPicError) as e:
+        eq.iterate(1)
+    assert "prepare" in str(e.value)
+    with pytest.raises(fp.FusionPicError) as e:
+        eq.solve({"max_iterations": 1})
+    assert str(e.value) == ".tolerance <- Non-optional property is undefined!"
+    with pytest.raises(fp.FusionPicError):
+        eq.set_b(np.zeros(3, dtype=np.float32))
+
+
+def test_natural_rows_mode_solves_the_system(sor):
+    """compat=False drops quirk Q14: the fixed point is the solution of A x = b.  Size-independent
+    check at n_power = 6 (L = 16384, a 1 GiB matrix), where the oracle would take minutes."""
+    n_power = 6
+    L = 4 * 4 ** n_power
+    rng = np.random.default_rng(5)
+    A = ((rng.random((L, L), dtype=np.float32) - 0.5) * (1.0 / L)).astype(np.float32)
+    A[np.arange(L), np.arange(L)] = 1.0 + rng.random(L, dtype=np.float32)
+    x_true = (rng.random(L, dtype=np.float32) - 0.5)
+    b = (A.astype(np.float64) @ x_true.astype(np.float64)).astype(np.float32)
+    eq = sor.makeSORIterative({"n_power": n_power}, compat=False)
+    eq.set_matrix(A).set_b(b).init_vector(np.zeros(L, dtype=np.float32))
+    res = eq.solve({"tolerance": 1e-6, "max_iterations": 40})
+    assert res["iterations"] < 40
+    assert np.abs(res["result"] - x_true).max() < 1e-4
+    # the reference's permuted update does not reach it
+    ref = sor.makeSORIterative({"n_power": n_power})
+    ref.set_matrix(A).set_b(b).init_vector(np.zeros(L, dtype=np.float32))
+    out = ref.solve({"tolerance": 1e-6, "max_iterations": 40})
+    assert np.abs(out["result"] - x_true).max() > 1e-3
+    eq.close(); ref.close()
+
+
+def test_iterate_is_asynchronous_and_counts(sor):
+    A, b, x0 = dominant_system(1024, seed=9)
+    eq = sor.makeSORIterative({"n_power": 4})
+    eq.set_matrix(A).set_b(b).init_vector(x0).prepare()
+    eq.resetStats()
+    eq.profile(True)
+    eq.iterate(10)
+    eq.sync()
+    st = eq.stats()
+    assert st["iterations"] == 10 and st["matrix_bytes"] == 4 * 1024 * 1024 and st["seconds_iterate"] > 0
+    ptr, nbytes = eq.x_result_tex()
+    assert ptr != 0 and nbytes == 4 * 1024
+
+
+def test_node_shim_end_to_end(sor, tmp_path):
+    """The shipped host path: Node -> matrix_native.js -> N-API addon -> libfusionpic.so, with the
+    calls a user of the reference's matrix_webgl module makes (nested JS arrays, chaining), held
+    to the fixture of the reference's solver bit for bit."""
+    import base64
+    import json
+    import os
+    import shutil
+    import subprocess
+    from helpers import ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    case = META["cases"]["p2_relaxed"]
+    L = case["vec_length"]
+    (tmp_path / "in.json").write_text(json.dumps(dict(
+        n_power=case["n_power"], relaxation=case["relaxation"], A=arr(case["A"]).reshape(L, L).astype(float).tolist(),
+        b=arr(case["b"]).astype(float).tolist(), x0=arr(case["x0"]).astype(float).tolist(),
+        calls=[c["params"] for c in case["calls"]])))
+    script = r"""
+const fs = require('fs');
+const matrix = require(process.argv[1]);
+const inp = JSON.parse(fs.readFileSync(process.argv[2]));
+const eq = matrix.makeSORIterative({n_power: inp.n_power, relaxation: inp.relaxation});
+eq.set_matrix(inp.A).set_b(inp.b).init_vector(inp.x0);
+const b64 = a => Buffer.from(a.buffer, a.byteOffset, a.byteLength).toString('base64');
+const out = inp.calls.map(function (p) {
+  const r = eq.solve(p);
+  return {correlation: r.correlation, diff: r.diff, iterations: r.iterations, result: b64(r.result), tex: b64(eq.x_result_tex().read())};
+});
+let threw = null;
+try { eq.solve({}); } catch (e) { threw = e.message; }
+console.log(JSON.stringify({vec_length: eq.vec_length, vec_height: eq.vec_height, calls: out, threw: threw}));
+eq.destroy();
+"""
+    shim = os.path.join(ROOT, "fusion-sim_amd", "js", "matrix_native.js")
+    raw = subprocess.check_output([node, "-e", script, shim, str(tmp_path / "in.json")])
+    out = json.loads(raw.decode().strip().splitlines()[-1])
+    assert (out["vec_length"], out["vec_height"]) == (L, case["vec_height"])
+    assert out["threw"] == ".tolerance <- Non-optional property is undefined!"
+    for got, want in zip(out["calls"], case["calls"]):
+        assert got["iterations"] == want["iterations"]
+        assert got["diff"] == num(want["diff"]) and got["correlation"] == num(want["correlation"])
+        assert same_bits(np.frombuffer(base64.b64decode(got["result"]), dtype=np.float32), arr(want["result"]))
+        assert same_bits(np.frombuffer(base64.b64decode(got["tex"]), dtype=np.float32), arr(want["x_result"]))
