@@ -116,6 +116,34 @@ def js_twin_baseline(grid, seconds_target=8.0):
         return {"value": None, "note": "node run failed: %s" % e}
 
 
+def dense_sor_line(device, n_power=6, products=60):
+    """SURVEY 8(f) next-4, the reference's dense iterative solver (matrix_webgl.js): products/s of
+    x <- R x + C on an L = 16384 system (1 GiB iteration matrix, streamed once per product)."""
+    import numpy as np
+    from fusionpic import sor
+    L = 4 * 4 ** n_power
+    rng = np.random.default_rng(0x50F)
+    A = ((rng.random((L, L), dtype=np.float32) - 0.5) * np.float32(1.0 / L))
+    A[np.arange(L), np.arange(L)] = 1.0 + rng.random(L, dtype=np.float32)
+    eq = sor.makeSORIterative({"n_power": n_power}, device=device)
+    eq.set_matrix(A).set_b(rng.random(L, dtype=np.float32)).init_vector(np.zeros(L, dtype=np.float32)).prepare()
+    eq.iterate(5)
+    eq.sync()
+    eq.resetStats()
+    eq.profile(True)          # HIP events on the launch stream around the whole batch
+    eq.iterate(products)
+    eq.sync()
+    st = eq.stats()
+    per = st["seconds_iterate"] / st["iterations"]
+    gbs = st["matrix_bytes"] / per / 1e9
+    eq.close()
+    return {"what": "dense weighted-Jacobi product x <- R x + C (matrix_webgl.js mv_product), n_power=%d, L=%d, float32, "
+                    "bit-identical to the reference's pass order" % (n_power, L),
+            "value": 1.0 / per, "unit": "products/s", "us_per_product": 1e6 * per,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": st["matrix_bytes"], "launches_timed": st["iterations"]}}
+
+
 def measured_traffic():
     """HBM bytes per push launch from the committed PMC passes (scripts/pmc_bench.sh,
     profiles/*_traffic.json): rocprofv3 cannot run inside the timed process."""
@@ -140,7 +168,7 @@ def main():
     ap.add_argument("--rng", choices=["reference", "counter"], default="reference",
                     help="reference = the reference's entropy-table generator (the drop-in, the headline); "
                          "counter = the Philox extension mode (SURVEY.md 8(d))")
-    ap.add_argument("--no-extensions", action="store_true", help="skip the extra counter-RNG measurement at N=1")
+    ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
 
     import torch
@@ -302,6 +330,7 @@ def main():
             "streamed_bytes_per_launch": 50.0 * n_local,
         }}
         ext.destroy()
+        out["extensions"]["dense_sor"] = dense_sor_line(local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
