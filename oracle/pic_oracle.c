@@ -8,6 +8,11 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+/* libpic_oracle_omp.so only: thread count of the all-cores timing variant */
+void orc_set_threads(int n) { omp_set_num_threads(n); }
+#endif
 
 /* ---- host-side routines of the factory and of out.set() ---- */
 

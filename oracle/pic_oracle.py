@@ -30,6 +30,21 @@ def build(force=False):
 
 
 _lib = None
+_lib_omp = None
+
+
+def lib_omp():
+    """libpic_oracle_omp.so: the same sources built with -fopenmp (per-particle loops in parallel,
+    threaded deposit).  Used only by bench.py's all-cores CPU baseline."""
+    global _lib_omp
+    if _lib_omp is None:
+        path = os.path.join(_HERE, "libpic_oracle_omp.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "libpic_oracle_omp.so"], stdout=subprocess.DEVNULL)
+        _lib_omp = ctypes.CDLL(path)
+        _lib_omp.orc_tofixed20.restype = ctypes.c_double
+        _lib_omp.orc_tofixed20.argtypes = [ctypes.c_double]
+    return _lib_omp
 
 
 def lib():
@@ -84,7 +99,12 @@ def inv_cdf(pdf):
 class OracleSim:
     """CPU twin of empic.makeCylindricalParticlePusher(spec) (empic.js:30)."""
 
-    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None, rng="reference", seed=0):
+    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None, rng="reference", seed=0, threads=1):
+        # threads > 1: the OpenMP build (timing only: the threaded deposit sums in another order)
+        self.threads = int(threads)
+        self._lib = lib_omp() if self.threads > 1 else lib()
+        if self.threads > 1:
+            self._lib.orc_set_threads(self.threads)
         # rng="counter": the Philox extension mode (no per-particle random state), sub-step counter self.t
         self.rng, self.seed, self.t = rng, int(seed), 0
         self.spec = dict(spec)
@@ -120,7 +140,7 @@ class OracleSim:
         self._shapes = None
 
     def _f(self, name):
-        return getattr(lib(), self.prefix + name)
+        return getattr(self._lib, self.prefix + name)
 
     def _c(self, v):
         return self.creal(float(v))
@@ -201,8 +221,8 @@ class OracleSim:
 
     # ---- out.density (empic.js:1471-1495)
     def deposit(self):
-        self._f("deposit")(_p(self.pos_A), _p(self.vel_A), ctypes.c_size_t(self.n), _p(self.stamp), self.nr, self.nz,
-                           _p(self.moments))
+        self._f("deposit_threads" if self.threads > 1 else "deposit")(
+            _p(self.pos_A), _p(self.vel_A), ctypes.c_size_t(self.n), _p(self.stamp), self.nr, self.nz, _p(self.moments))
 
     def density_finish(self):
         self._f("normalise")(_p(self.moments), self.nr, self.nz, _p(self.norm))

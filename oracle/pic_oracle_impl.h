@@ -24,6 +24,9 @@ static inline int FN(ngp)(REAL u, int W)
 /* programStepRandA/B (empic.js:783-820, :858-895), K3. */
 void FN(step_rand)(const REAL* rand_in, const REAL* entropy, REAL* rand_out, size_t n)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t p = 0; p < n; ++p) {
         const REAL* rd = rand_in + 4 * p;
         REAL x0 = rd[2], x1 = rd[3];
@@ -45,6 +48,9 @@ void FN(step_velocity)(const REAL* pos, const REAL* vel, const REAL* rnd,
                        const REAL* R1, const REAL* R2, const REAL* R3, const REAL* A,
                        int nr, int nz, REAL* vel_out, size_t n)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t p = 0; p < n; ++p) {
         const REAL* P = pos + 4 * p;
         const REAL* V = vel + 4 * p;
@@ -78,6 +84,9 @@ void FN(step_position)(const REAL* pos, const REAL* vel_new, const REAL* rnd,
                        const REAL* sink, const REAL* inv_cdf, int nr, int nz,
                        REAL step_factor, REAL* pos_out, size_t n)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t p = 0; p < n; ++p) {
         const REAL* P = pos + 4 * p;
         const REAL* V = vel_new + 4 * p;
@@ -135,6 +144,9 @@ void FN(precalc)(const REAL* B, const REAL* E, int nr, int nz, REAL h,
                  REAL* R1, REAL* R2, REAL* R3, REAL* A, int physical_a)
 {
     size_t ncell = (size_t)nr * nz;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t c = 0; c < ncell; ++c) {
         REAL Bx = B[4 * c], By = B[4 * c + 1], Bz = B[4 * c + 2];
         REAL Ex = E[4 * c], Ey = E[4 * c + 1], Ez = E[4 * c + 2];
@@ -225,6 +237,34 @@ void FN(deposit)(const REAL* pos, const REAL* vel, size_t n, const float* stamp,
     }
 }
 
+#ifdef _OPENMP
+/* Timing variant for bench.py's all-cores baseline (built only into libpic_oracle_omp.so):
+ * the same per-particle arithmetic as deposit(), particles split into contiguous ranges, one
+ * private target per thread, targets added in thread order.  The summation order differs from
+ * the serial one, so parity tests never use it. */
+void FN(deposit_threads)(const REAL* pos, const REAL* vel, size_t n, const float* stamp,
+                         int nr, int nz, REAL* moments)
+{
+    size_t ncell = (size_t)nr * nz;
+    int nt = omp_get_max_threads();
+    REAL* priv = (REAL*)malloc(sizeof(REAL) * 4 * ncell * (size_t)nt);
+    if (!priv) { FN(deposit)(pos, vel, n, stamp, nr, nz, moments); return; }
+#pragma omp parallel num_threads(nt)
+    {
+        int t = omp_get_thread_num();
+        size_t b = n * (size_t)t / (size_t)nt, e = n * (size_t)(t + 1) / (size_t)nt;
+        FN(deposit)(pos + 4 * b, vel + 4 * b, e - b, stamp, nr, nz, priv + 4 * ncell * (size_t)t);
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t c = 0; c < 4 * ncell; ++c) {
+        REAL acc = priv[c];
+        for (int t = 1; t < nt; ++t) acc += priv[c + 4 * ncell * (size_t)t];
+        moments[c] = acc;
+    }
+    free(priv);
+}
+#endif
+
 /* Per-particle deposit cell (ic + (nr+1)*jc, or -1 when the point is clipped). */
 void FN(deposit_cells)(const REAL* pos, size_t n, int nr, int nz, int32_t* cells)
 {
@@ -240,6 +280,9 @@ void FN(deposit_cells)(const REAL* pos, size_t n, int nr, int nz, int32_t* cells
 /* programNormalizeMoments01 (empic.js:1042-1066), K5; v_texCoord.x = (i+0.5)/nr. */
 void FN(normalise)(const REAL* moments, int nr, int nz, REAL* norm)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int j = 0; j < nz; ++j)
         for (int i = 0; i < nr; ++i) {
             size_t c = 4 * ((size_t)i + (size_t)nr * j);
@@ -258,6 +301,9 @@ void FN(normalise)(const REAL* moments, int nr, int nz, REAL* norm)
 void FN(avg)(const REAL* next, REAL* avg_B, REAL* avg_A, REAL ratio, size_t ncell)
 {
     REAL keep = (REAL)1 - ratio;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t c = 0; c < 4 * ncell; ++c) {
         avg_A[c] = ratio * next[c] + keep * avg_B[c];
         avg_B[c] = avg_A[c];
