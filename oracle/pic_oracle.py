@@ -50,8 +50,10 @@ def lib_omp():
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_LIB_PATH)
+        override = os.environ.get("PIC_ORACLE_LIB")   # `make -C oracle sanitize`: an ASan/UBSan build
+        if not override:
+            build()
+        _lib = ctypes.CDLL(override or _LIB_PATH)
         _lib.orc_tofixed20.restype = ctypes.c_double
         _lib.orc_tofixed20.argtypes = [ctypes.c_double]
         _lib.orc_inv_cdf.restype = ctypes.c_int
