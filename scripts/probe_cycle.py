@@ -20,6 +20,7 @@ ap.add_argument("--sort-interval", type=int, default=0)
 ap.add_argument("--sync-each", type=int, default=1)
 ap.add_argument("--rng", default="reference")
 ap.add_argument("--fuse", type=int, default=1)
+ap.add_argument("--precision", default="fp32")
 args = ap.parse_args()
 
 spec = dict(radius=1.0, height=1.0, nr=args.grid, nz=args.grid, dt=2e-9, nparticles=args.side,
@@ -27,7 +28,8 @@ spec = dict(radius=1.0, height=1.0, nr=args.grid, nz=args.grid, dt=2e-9, npartic
 n = args.side ** 2
 pos, vel, entropy, rand = synthetic_inputs(n, spec, 0x5EEDF051)
 sink, pdf = scene_grids(args.grid, args.grid)
-sim = fp.makeCylindricalParticlePusher(spec, sort_interval=args.sort_interval, rng=args.rng, fuse_deposit=bool(args.fuse))
+sim = fp.makeCylindricalParticlePusher(spec, precision=args.precision, sort_interval=args.sort_interval, rng=args.rng,
+                                       fuse_deposit=bool(args.fuse))
 sim.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
 if args.rng == "reference":
     sim.setRandomState(entropy, rand)
