@@ -799,3 +799,61 @@ simulation.destroy();
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=2e-3)
     got, want = dec("moments", np.float32).reshape(-1, 4), ora.moments.reshape(-1, 4)
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-3)
+
+
+def test_c_abi_error_paths(fp, tmp_path):
+    """Raw ctypes against the C ABI: every misuse returns a negative status with a message that
+    names the offending property, never crashes, and leaves the handle usable."""
+    import ctypes
+    lib = fp.load_library()
+    spec = make_spec(8, 6, 3)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    h = sim._h
+    msg = lambda: lib.fpic_last_error(h).decode()
+    f32 = np.zeros(4 * 8 * 6 * 3, dtype=np.float32)
+
+    assert lib.fpic_precalc(None) == -1                                     # null handle
+    assert lib.fpic_set_grid(h, 0, None, 8, 6, 3, 0) == -1 and ".data" in msg()
+    assert lib.fpic_set_grid(h, 0, f32.ctypes.data, 7, 6, 3, 0) == -1 and "expected 8 x 6" in msg()
+    assert lib.fpic_set_grid(h, 0, f32.ctypes.data, 8, 6, 1, 0) == -1 and ".ncomp" in msg()
+    assert lib.fpic_set_grid(h, 9, f32.ctypes.data, 8, 6, 3, 0) == -1 and ".which" in msg()
+    assert lib.fpic_set_grid(h, 0, f32.ctypes.data, 8, 6, 3, 7) == -1 and ".dtype" in msg()
+    assert lib.fpic_set_particles(h, f32.ctypes.data, None, 8, 0) == -1 and "expected 9 particles" in msg()
+    assert lib.fpic_step(h, -1) == -1 and ".ncalls" in msg()
+    assert lib.fpic_read_grid(h, 0, None, 0) == -1
+    assert lib.fpic_read_grid(h, 99, f32.ctypes.data, 0) == -1 and ".which" in msg()
+    assert lib.fpic_get_cells(h, None) == -1
+    p, nb = ctypes.c_void_p(), ctypes.c_size_t()
+    assert lib.fpic_device_buffer(h, 5, ctypes.byref(p), ctypes.byref(nb)) == -1
+    assert lib.fpic_save_checkpoint(h, None) == -1
+    assert lib.fpic_save_checkpoint(h, str(tmp_path / "no" / "such" / "dir" / "x.ckp").encode()) == -5
+    bogus = tmp_path / "bogus.ckp"
+    bogus.write_bytes(b"not a checkpoint at all" * 10)
+    assert lib.fpic_load_checkpoint(h, str(bogus).encode()) == -1 and "not a fusionpic checkpoint" in msg()
+    # a checkpoint of another spec is refused; a truncated one is reported
+    good = tmp_path / "good.ckp"
+    sim.saveCheckpoint(str(good))
+    other = fp.makeCylindricalParticlePusher(make_spec(8, 6, 4))
+    assert lib.fpic_load_checkpoint(other._h, str(good).encode()) == -1
+    assert b".spec" in lib.fpic_last_error(other._h)
+    data = good.read_bytes()
+    (tmp_path / "cut.ckp").write_bytes(data[: len(data) // 2])
+    assert lib.fpic_load_checkpoint(h, str(tmp_path / "cut.ckp").encode()) == -5 and "truncated" in msg()
+    # counter mode has no random state to set
+    ctr = fp.makeCylindricalParticlePusher(spec, rng="counter", seed=1)
+    with pytest.raises(fp.FusionPicError) as e:
+        ctr.setRandomState(np.zeros(4 * 1024 * 1024, dtype=np.float32), np.zeros((9, 4), dtype=np.float32))
+    assert e.value.code == -5
+    # bad specs through the raw struct
+    bad = fp.Spec(radius=1.0, height=1.0, nr=0, nz=4, dt=1e-9, nparticles=2, particle_mass=1.0, particle_charge=1.0)
+    out = ctypes.c_void_p()
+    assert lib.fpic_create(ctypes.byref(bad), ctypes.byref(out)) == -1 and b".nr" in lib.fpic_last_error(None)
+    bad.nr, bad.precision = 4, 5
+    assert lib.fpic_create(ctypes.byref(bad), ctypes.byref(out)) == -1 and b".precision" in lib.fpic_last_error(None)
+    bad.precision, bad.device = 0, 99
+    assert lib.fpic_create(ctypes.byref(bad), ctypes.byref(out)) == -1 and b".device" in lib.fpic_last_error(None)
+    assert lib.fpic_create(None, ctypes.byref(out)) == -1
+    # the handle still works after all of that
+    sim.set(position=[[0.1 * k, 0.0, 0.5] for k in range(1, 10)], velocity=[[0.0, 0.0, 1e-3]] * 9)
+    sim.precalc(); sim.step(); sim.density()
+    assert np.isfinite(sim.getParticles()["position"]).all()
