@@ -857,3 +857,25 @@ def test_c_abi_error_paths(fp, tmp_path):
     sim.set(position=[[0.1 * k, 0.0, 0.5] for k in range(1, 10)], velocity=[[0.0, 0.0, 1e-3]] * 9)
     sim.precalc(); sim.step(); sim.density()
     assert np.isfinite(sim.getParticles()["position"]).all()
+
+
+def test_reference_demo_scene_from_node(tmp_path):
+    """examples/fusionsim_node.js: the demo's own scene (fusionsim.js:71-148: 400x800 grid, 160 000
+    protons, sink frame, source block, two 10 MA loops) and frame loop from Node, pictures written
+    instead of drawn."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    from helpers import ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    out = subprocess.check_output([node, os.path.join(ROOT, "examples", "fusionsim_node.js"), "--frames", "30", "--every", "10",
+                                   "--out", str(tmp_path)], timeout=300)
+    res = json.loads(out.decode().strip().splitlines()[-1])
+    assert res["frames"] == 30 and res["images"] == 3 and res["arch"] == "gfx950"
+    assert 0 < res["alive"] <= res["particles"] and res["density_sum"] > 0
+    for k in (10, 20, 30):
+        data = (tmp_path / ("density_%05d.pgm" % k)).read_bytes()
+        assert data.startswith(b"P5\n400 800\n255\n") and len(data) == len(b"P5\n400 800\n255\n") + 400 * 800
