@@ -879,3 +879,52 @@ def test_reference_demo_scene_from_node(tmp_path):
     for k in (10, 20, 30):
         data = (tmp_path / ("density_%05d.pgm" % k)).read_bytes()
         assert data.startswith(b"P5\n400 800\n255\n") and len(data) == len(b"P5\n400 800\n255\n") + 400 * 800
+
+
+@pytest.mark.parametrize("seed", list(range(16)) + [100, 101, 102, 103, 104, 105])
+def test_randomised_scenes(fp, po, seed):
+    """Sixteen small and six larger scenes drawn at random: grid shape (incl. one-cell and non-tile-multiple sizes),
+    cylinder proportions, particle count (incl. counts that are not a multiple of the vector
+    width), species, time step, precision, Q1 switch, binning policy, fused or separate sums,
+    random sink holes and a random source.  Four frames of step()+density() each; integer outputs
+    and every particle value bit-exact, density buffers within the bar of the precision."""
+    rng = np.random.default_rng(9000 + seed)
+    nr, nz = int(rng.integers(1, 97)), int(rng.integers(1, 97))
+    n = int(rng.integers(1, 6000))
+    if seed >= 100:     # several chunks per tile, several tiles, re-binning inside the push
+        nr, nz, n = int(rng.integers(60, 220)), int(rng.integers(60, 220)), int(rng.integers(50000, 300000))
+    precision = "fp32" if rng.random() < 0.6 else "fp64"
+    physical_a = bool(rng.random() < 0.3)
+    electron = bool(rng.random() < 0.3)
+    spec = dict(radius=float(rng.uniform(0.2, 2.0)), height=float(rng.uniform(0.2, 3.0)), nr=nr, nz=nz,
+                nparticles=int(np.ceil(np.sqrt(n))), dt=float(rng.uniform(2e-10, 4e-9)),
+                particle_mass=9.109e-31 if electron else 1.67e-27, particle_charge=-1.602e-19 if electron else 1.602e-19)
+    dtype = np.float32 if precision == "fp32" else np.float64
+    E = rng.normal(0, 2e4, size=(nr, nz, 3))
+    B = rng.normal(0, 0.05 if electron else 0.5, size=(nr, nz, 3))
+    sink = (rng.random((nr, nz)) > 0.08).astype(np.float64)
+    pdf = rng.random((nr, nz)) * (rng.random((nr, nz)) > 0.3)
+    pdf[0, :] += 0.1                                        # an empty first row makes the reference throw (Q12)
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=77 + seed, v_th=float(rng.uniform(1e-4, 0.05)))
+    sim = fp.makeCylindricalParticlePusher(spec, precision=precision, count=n, compat=not physical_a,
+                                           sort_interval=int(rng.integers(0, 3)), fuse_deposit=bool(rng.random() < 0.7))
+    ora = po.OracleSim(spec, dtype=dtype, physical_a=physical_a, count=n)
+    for s in (sim, ora):
+        s.set(E=E, B=B, position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
+    sim.setRandomState(entropy, rand); ora.set_random_state(entropy, rand)
+    sim.addBZ(0.02); ora.add_bz(0.02)
+    sim.precalc(); ora.precalc()
+    rtol = RTOL32 if precision == "fp32" else RTOL64
+    for _ in range(4):
+        sim.step(); ora.step()
+        sim.density(); ora.density()
+        assert_particles_equal(sim, ora)
+        for which, want in ((fp.READ_MOMENTS, ora.moments), (fp.READ_AVG, ora.avg_A)):
+            g = sim.readGrid(which, np.float64).reshape(-1, 4)
+            w = want.astype(np.float64).reshape(-1, 4)
+            assert np.array_equal(np.isnan(g), np.isnan(w))
+            for c in range(4):
+                ok = ~np.isnan(w[:, c])
+                if ok.any():
+                    assert np.abs(g[ok, c] - w[ok, c]).max() <= rtol * max(np.abs(w[ok, c]).max(), 1e-300), (which, c)
+    sim.destroy()
