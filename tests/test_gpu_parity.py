@@ -63,7 +63,7 @@ def build_pair(fp, po, spec, precision, seed, n=None, with_E=True, pdf=None, phy
     return sim, ora
 
 
-def assert_particles_equal(sim, ora, exact=True, rtol=0.0):
+def assert_particles_equal(sim, ora, exact=True, rtol=0.0, rand=True):
     got = sim.getParticles()
     want_pos, want_vel = ora.positions(), ora.velocities()
     # integer outputs: always bit-exact
@@ -72,7 +72,8 @@ def assert_particles_equal(sim, ora, exact=True, rtol=0.0):
     if exact:
         assert same_bits(got["position"], want_pos)
         assert same_bits(got["velocity"], want_vel)
-        assert same_bits(got["rand"], ora.rand().astype(np.float32))
+        if rand:      # the counter-based mode keeps no per-particle random state
+            assert same_bits(got["rand"], ora.rand().astype(np.float32))
     else:
         np.testing.assert_allclose(got["position"], want_pos, rtol=rtol, atol=rtol * 1e-3)
         np.testing.assert_allclose(got["velocity"], want_vel, rtol=rtol, atol=rtol * 1e-6)
@@ -881,7 +882,7 @@ def test_reference_demo_scene_from_node(tmp_path):
         assert data.startswith(b"P5\n400 800\n255\n") and len(data) == len(b"P5\n400 800\n255\n") + 400 * 800
 
 
-@pytest.mark.parametrize("seed", list(range(16)) + [100, 101, 102, 103, 104, 105])
+@pytest.mark.parametrize("seed", list(range(16)) + [100, 101, 102, 103, 104, 105] + [200, 201, 202, 203, 300, 301])
 def test_randomised_scenes(fp, po, seed):
     """Sixteen small and six larger scenes drawn at random: grid shape (incl. one-cell and non-tile-multiple sizes),
     cylinder proportions, particle count (incl. counts that are not a multiple of the vector
@@ -891,8 +892,9 @@ def test_randomised_scenes(fp, po, seed):
     rng = np.random.default_rng(9000 + seed)
     nr, nz = int(rng.integers(1, 97)), int(rng.integers(1, 97))
     n = int(rng.integers(1, 6000))
-    if seed >= 100:     # several chunks per tile, several tiles, re-binning inside the push
+    if 100 <= seed < 200 or seed >= 300:     # several chunks per tile, several tiles, re-binning inside the push
         nr, nz, n = int(rng.integers(60, 220)), int(rng.integers(60, 220)), int(rng.integers(50000, 300000))
+    counter = seed >= 200                    # the counter-based generator (extension) against the oracle's
     precision = "fp32" if rng.random() < 0.6 else "fp64"
     physical_a = bool(rng.random() < 0.3)
     electron = bool(rng.random() < 0.3)
@@ -906,19 +908,21 @@ def test_randomised_scenes(fp, po, seed):
     pdf = rng.random((nr, nz)) * (rng.random((nr, nz)) > 0.3)
     pdf[0, :] += 0.1                                        # an empty first row makes the reference throw (Q12)
     pos, vel, entropy, rand = uniform_plasma(n, spec, seed=77 + seed, v_th=float(rng.uniform(1e-4, 0.05)))
+    mode = dict(rng="counter", seed=0xC0FFEE + seed) if counter else {}
     sim = fp.makeCylindricalParticlePusher(spec, precision=precision, count=n, compat=not physical_a,
-                                           sort_interval=int(rng.integers(0, 3)), fuse_deposit=bool(rng.random() < 0.7))
-    ora = po.OracleSim(spec, dtype=dtype, physical_a=physical_a, count=n)
+                                           sort_interval=int(rng.integers(0, 3)), fuse_deposit=bool(rng.random() < 0.7), **mode)
+    ora = po.OracleSim(spec, dtype=dtype, physical_a=physical_a, count=n, **mode)
     for s in (sim, ora):
         s.set(E=E, B=B, position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
-    sim.setRandomState(entropy, rand); ora.set_random_state(entropy, rand)
+    if not counter:
+        sim.setRandomState(entropy, rand); ora.set_random_state(entropy, rand)
     sim.addBZ(0.02); ora.add_bz(0.02)
     sim.precalc(); ora.precalc()
     rtol = RTOL32 if precision == "fp32" else RTOL64
     for _ in range(4):
         sim.step(); ora.step()
         sim.density(); ora.density()
-        assert_particles_equal(sim, ora)
+        assert_particles_equal(sim, ora, rand=not counter)
         for which, want in ((fp.READ_MOMENTS, ora.moments), (fp.READ_AVG, ora.avg_A)):
             g = sim.readGrid(which, np.float64).reshape(-1, 4)
             w = want.astype(np.float64).reshape(-1, 4)
