@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""profiles/rNN_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_bench.sh.
+
+  python scripts/pmc_traffic.py profiles/r01_pmc profiles/r01_traffic.json
+
+Mean over the dispatches of the reference-RNG fused push (in-place and re-binning launches).  Units
+and the gfx950 correction follow MI355X_MICROARCH.md: both counters are in KB; FETCH_SIZE counts
+16-B/lane streamed reads at half their bytes, so half of the kernel's known streamed read
+(41 B x particles) is added back; WRITE_SIZE is exact."""
+import csv
+import json
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+particles = 100000000
+
+
+def mean_kb(path, counter):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if r["Counter_Name"] == counter and "push_tiles_kernel<float, true" in r["Kernel_Name"]
+            and r["Kernel_Name"].split("(")[0].rstrip().endswith("false>")]
+    return sum(vals) / len(vals), len(vals)
+
+
+fetch, nf = mean_kb(root + "/fetch_counter_collection.csv", "FETCH_SIZE")
+write, nw = mean_kb(root + "/write_counter_collection.csv", "WRITE_SIZE")
+fetch_b, write_b = fetch * 1024, write * 1024
+fetch_corr = fetch_b + 0.5 * 41 * particles
+json.dump({
+    "bytes_per_launch": fetch_corr + write_b, "fetch_size_raw_bytes": fetch_b, "write_size_raw_bytes": write_b,
+    "fetch_size_corrected_bytes": fetch_corr, "dispatches_averaged": [nf, nw],
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2` "
+              "(profiles/r01_pmc/*.csv), mean over the reference-RNG push_tiles_kernel<float,true,*,false> dispatches "
+              "(in-place and re-binning launches); gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts 16-B/lane "
+              "streamed reads at half their bytes, so half of the kernel's known streamed read (41 B x 1e8 particles) is "
+              "added back; WRITE_SIZE is exact",
+    "algorithmic_bytes_per_launch": 48.0 * 2 * particles,
+}, open(out, "w"), indent=1)
+print(open(out).read())
