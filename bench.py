@@ -241,7 +241,10 @@ def main():
     stream = torch.cuda.Stream(device=local_rank)
 
     def build(rng_mode):
-        s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051)
+        # counter mode: no gather hides the LDS atomics of the fused sums, so only the tile census and
+        # the re-binning stay in the push there (spec.unfused_deposit = 2)
+        s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051,
+                                              fuse_deposit="census" if rng_mode == "counter" else True)
         s_.setStream(stream.cuda_stream)
         s_.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
         if rng_mode == "reference":
@@ -364,7 +367,8 @@ def main():
             "what": "spec.rng_mode = 1: Philox4x32-10(particle id, sub-step) replaces the reference's entropy-table walk; "
                     "parity is bit-exact against the oracle's counter mode, not against the reference's random stream",
             "value": 2.0 * n_local * args.steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / args.steps,
-            "push_avg_launch_ms": pm, "rebinning_launches": es["sort_passes"],
+            "push_avg_launch_ms": pm, "cell_sums_avg_launch_ms": es["ms_deposit"] / max(1, es["deposit_launches"]),
+            "rebinning_launches": es["sort_passes"],
             "roofline_achieved_GBs": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9,
             "roofline_frac": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "streamed_bytes_per_launch": 50.0 * n_local,

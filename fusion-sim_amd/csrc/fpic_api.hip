@@ -382,7 +382,8 @@ int launch_push(fpic_handle* h, int nsub)
     const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
     // float state, binned, fusion not switched off: the push also forms the per-cell sums
     // and the tile census, and on a re-binning launch writes the sorted order itself
-    const bool fuse = sizeof(T) == 4 && h->binned && !h->spec.unfused_deposit;
+    const bool fuse = sizeof(T) == 4 && h->binned && h->spec.unfused_deposit != 1;
+    const bool sums = fuse && h->spec.unfused_deposit == 0; // 2: census and re-binning fused, sums separate
     const bool scatter = fuse && h->scatter_pending;
     TileArgs<T> t{};
     t.ntx = h->ntx; t.ntz = h->ntz; t.ntiles = h->ntiles;
@@ -398,14 +399,22 @@ int launch_push(fpic_handle* h, int nsub)
     if (fuse) {
         if constexpr (sizeof(T) == 4) {
             const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
-            HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
-            HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
             HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
-            constexpr size_t lds = push_tiles_lds_bytes<T, true>();
-            if (scatter && ctr) push_tiles_kernel<T, true, true, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-            else if (scatter) push_tiles_kernel<T, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-            else if (ctr) push_tiles_kernel<T, true, false, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-            else push_tiles_kernel<T, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            if (sums) {
+                HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
+                HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
+                constexpr size_t lds = push_tiles_lds_bytes<T, true>();
+                if (scatter && ctr) push_tiles_kernel<T, true, true, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                else if (scatter) push_tiles_kernel<T, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                else if (ctr) push_tiles_kernel<T, true, false, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                else push_tiles_kernel<T, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            } else {
+                constexpr size_t lds = push_tiles_lds_bytes<T, true, false>();
+                if (scatter && ctr) push_tiles_kernel<T, true, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                else if (scatter) push_tiles_kernel<T, true, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                else if (ctr) push_tiles_kernel<T, true, false, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                else push_tiles_kernel<T, true, false, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            }
         }
     } else if (h->binned) { // the work list of the last binning is valid until the next one: the push is in place
         if (ctr) push_tiles_kernel<T, false, false, true><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
@@ -418,7 +427,8 @@ int launch_push(fpic_handle* h, int nsub)
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     if (fuse) {
-        h->sums_fresh = h->census_fresh = true;
+        h->sums_fresh = sums;
+        h->census_fresh = true;
         if (scatter) { // this launch was the binning: the other set and the other tables are live now
             h->cur ^= 1;
             h->wl ^= 1;
@@ -426,8 +436,8 @@ int launch_push(fpic_handle* h, int nsub)
             h->last_spill = 0;
             h->spill_pending[0] = h->spill_pending[1] = false; // its own count was taken against the old windows
             h->sort_passes++;
-        } else if (int rc = record_spill(h)) {
-            return rc;
+        } else if (sums) {
+            if (int rc = record_spill(h)) return rc;
         }
     }
     return FPIC_OK;
@@ -836,6 +846,7 @@ int validate_spec(const fpic_spec* s)
     if (s->count == 0 && s->nparticles < 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".nparticles <- must be a positive integer");
     if (s->precision != FPIC_F32 && s->precision != FPIC_F64) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".precision <- must be 0 (f32) or 1 (f64)");
     if (s->rng_mode != 0 && s->rng_mode != 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".rng_mode <- must be 0 (reference) or 1 (counter)");
+    if (s->unfused_deposit < 0 || s->unfused_deposit > 2) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".unfused_deposit <- must be 0, 1 or 2");
     return FPIC_OK;
 }
 
@@ -905,6 +916,10 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
         (e = set_lds(push_tiles_kernel<float, true, false, true>, push_tiles_lds_bytes<float, true>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<float, true, true, false>, push_tiles_lds_bytes<float, true>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<float, true, true, true>, push_tiles_lds_bytes<float, true>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, false, false, false>, push_tiles_lds_bytes<float, true, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, false, true, false>, push_tiles_lds_bytes<float, true, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, true, false, false>, push_tiles_lds_bytes<float, true, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<float, true, true, true, false>, push_tiles_lds_bytes<float, true, false>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<double, false, false, false>, push_tiles_lds_bytes<double, false>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<double, false, false, true>, push_tiles_lds_bytes<double, false>())) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e)));
@@ -1090,7 +1105,7 @@ int fpic_deposit(fpic_handle* h)
         }
     }
     if (rebin) {
-        if (h->prec == FPIC_F32 && h->binned && h->census_fresh && !h->spec.unfused_deposit) {
+        if (h->prec == FPIC_F32 && h->binned && h->census_fresh && h->spec.unfused_deposit != 1) {
             // The last push counted the particles per tile as it stored them.  Lay the
             // next order out from that census now; the next push writes it (no extra pass).
             const int nw = h->wl ^ 1;

@@ -285,9 +285,9 @@ struct NoSums {
     __device__ __forceinline__ void add(const Particle<T>&, int, int) const {}
 };
 
-template <typename T>
+template <typename T, bool SUMS = true>
 struct WindowSums {
-    FPIC_LDS double* lsums;      // [kTileLds*kTileLds][4]
+    FPIC_LDS double* lsums;      // [kTileLds*kTileLds][4]; unused when SUMS is false (census only)
     FPIC_LDS uint32_t* lcensus;  // [kNbrSlots]
     int i0, j0;                  // window origin (tile origin - kTileHalo)
     TileNeighbourhood nb;
@@ -302,7 +302,7 @@ struct WindowSums {
         const int s = nb.slot(visible, ic, jc, key);
         if (s >= 0) __hip_atomic_fetch_add(lcensus + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAdd(tile_count + key, 1u);
-        if (!visible) return;
+        if (!SUMS || !visible) return;
         const T dx = q.x / q.r, dy = q.y / q.r;
         const T c0 = static_cast<T>(0.001) * (q.vx * dx + q.vy * dy);
         const T c1 = static_cast<T>(0.001) * (q.vy * dx - q.vx * dy);
@@ -457,14 +457,15 @@ constexpr size_t push_stage_offset() // end of: coefficient window | sink bytes 
     return (push_sums_offset<T>() + static_cast<size_t>(kTileLds) * kTileLds * 4 * sizeof(double) +
             3 * kNbrSlots * sizeof(uint32_t) + 15) / 16 * 16;
 }
-template <typename T, bool FUSE>
+template <typename T, bool FUSE, bool SUMS = true>
 constexpr size_t push_tiles_lds_bytes()
 {
-    // coefficient window | sink bytes | double sums window | census | per-wave ranks | per-wave ranges
-    return FUSE ? push_stage_offset<T>() : push_sums_offset<T>();
+    // coefficient window | sink bytes | double sums window (SUMS) | census | ranks | ranges
+    return !FUSE ? push_sums_offset<T>()
+                 : SUMS ? push_stage_offset<T>() : push_sums_offset<T>() + 3 * kNbrSlots * sizeof(uint32_t) + 16;
 }
 
-template <typename T, bool FUSE, bool SCATTER, bool CTR>
+template <typename T, bool FUSE, bool SCATTER, bool CTR, bool SUMS = true>
 __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, TileArgs<T> t)
 {
     static_assert(FUSE || !SCATTER, "the re-binning launch relies on the census of the fused form");
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
     FPIC_LDS T* lcoef = (FPIC_LDS T*)push_lds;
     FPIC_LDS uint8_t* lsink = (FPIC_LDS uint8_t*)push_lds + static_cast<size_t>(LW) * LW * 12 * sizeof(T);
     FPIC_LDS double* lsums = (FPIC_LDS double*)((FPIC_LDS unsigned char*)push_lds + push_sums_offset<T>());
-    FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lsums + SW * SW * 4);
+    FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lsums + (SUMS ? SW * SW * 4 : 0));
     FPIC_LDS uint32_t* lrank = lcensus + kNbrSlots;
     FPIC_LDS uint32_t* lrange = lrank + kNbrSlots;
     if (blockIdx.x >= *t.nwork) return;
@@ -501,7 +502,8 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         lsink[c] = (gi >= 0 && gi < a.nr && gj >= 0 && gj < a.nz) ? a.sink_alive[static_cast<size_t>(gi) + static_cast<size_t>(a.nr) * gj] : 0;
     }
     if constexpr (FUSE) {
-        for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) lsums[k] = 0.0;
+        if constexpr (SUMS)
+            for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) lsums[k] = 0.0;
         if (threadIdx.x < 3 * kNbrSlots) lcensus[threadIdx.x] = 0;
     }
     __syncthreads();
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             Particle<T> q[PPT];
             load_state<T, CTR>(a, base, cnt, q);
             if constexpr (FUSE)
-                advance_state<T, CTR>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+                advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
             else
                 advance_state<T, CTR>(a, tab, NoSums{}, cnt, q);
             store_state<T, CTR>(a, base, cnt, q);
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
                     else dest[k] = t.dst_tile_start[key] + atomicAdd(t.dst_tile_cursor + key, 1u); // beyond the 5x5 tiles: rare
                 }
             }
-            advance_state<T, CTR>(a, tab, WindowSums<T>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+            advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 if (k < cnt) {
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
         // global addresses, so a wave's atomic is one 256-byte piece
         const size_t gw = static_cast<size_t>(a.nr) + 1;
-        for (int k = threadIdx.x; k < SW * SW * 4; k += kPushThreads) {
+        for (int k = threadIdx.x; SUMS && k < SW * SW * 4; k += kPushThreads) {
             const int lj = k / (SW * 4);
             const int rem = k - lj * (SW * 4);
             double val = lsums[k];

@@ -155,7 +155,9 @@ class CylindricalParticlePusher:
         s.device = int(device)
         s.physical_a = 0 if compat else 1
         s.sort_interval = int(sort_interval)
-        s.unfused_deposit = 0 if fuse_deposit else 1
+        # True: sums, census and re-binning inside the push; False: separate passes; "census": the push
+        # keeps the census and the re-binning, the per-cell sums are a separate pass
+        s.unfused_deposit = 2 if fuse_deposit == "census" else (0 if fuse_deposit else 1)
         s.rng_mode = {"reference": 0, "counter": 1}[rng]
         s.rng_seed_lo, s.rng_seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
         self.precision = s.precision

@@ -23,7 +23,7 @@
  *                          window.crypto and Math.random, empic.js:148-173)
  * Extension keys of spec (all optional): precision 'fp32'|'fp64', device, count,
  * compat (default true: keep quirk Q1 of empic.js:645), sort_interval, fuse_deposit
- * (default true), rng 'reference'|'counter' + seed (counter = Philox4x32-10 per particle
+ * (default true; 'census' keeps only the tile census and re-binning in step()), rng 'reference'|'counter' + seed (counter = Philox4x32-10 per particle
  * and sub-step instead of the reference's entropy-table generator; not the reference's
  * random stream).
  */
@@ -109,7 +109,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
         radius: 'number', height: 'number', nr: 'number', nz: 'number', dt: 'number',
         nparticles: 'number', particle_mass: 'number', particle_charge: 'number',
         precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
-        sort_interval: [, 'number'], fuse_deposit: [, 'boolean'], rng: [, 'string'], seed: [, 'number'],
+        sort_interval: [, 'number'], fuse_deposit: [, 'boolean', 'string'], rng: [, 'string'], seed: [, 'number'],
     });
     const n = spec.count ? spec.count : spec.nparticles * spec.nparticles;   // empic.js:107-109
     const fp64 = spec.precision === 'fp64';
@@ -123,7 +123,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
     const lib = addon();
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass,
         spec.particle_charge, spec.count || 0, fp64 ? 1 : 0, spec.device || 0, spec.compat === false ? 1 : 0,
-        spec.sort_interval || 0, spec.fuse_deposit === false ? 1 : 0, spec.rng === 'counter' ? 1 : 0,
+        spec.sort_interval || 0, spec.fuse_deposit === 'census' ? 2 : (spec.fuse_deposit === false ? 1 : 0), spec.rng === 'counter' ? 1 : 0,
         seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296);
     const nr = spec.nr, nz = spec.nz;
     const Real = fp64 ? Float64Array : Float32Array;

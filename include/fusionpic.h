@@ -106,9 +106,12 @@ typedef struct fpic_spec {
     int32_t physical_a;     /* 0: reference's K9 formula incl. quirk Q1 (empic.js:645);
                                1: h(E.B)B vector form */
     int32_t sort_interval;  /* re-bin particles every k density() calls; 0 = adaptive */
-    int32_t unfused_deposit;/* 1: step() does not also form the per-cell sums of density()'s
-                               scatter (by default it does: the frame loop of fusionsim.js:172-174
-                               always calls density() after step()) */
+    int32_t unfused_deposit;/* 0: step() also forms the per-cell sums of density()'s scatter, counts
+                               particles per tile and re-bins them (the frame loop of
+                               fusionsim.js:172-174 always calls density() after step());
+                               1: separate passes for all of that;
+                               2: census and re-binning stay in step(), the sums are a separate pass
+                               (faster with rng_mode 1, where no gather hides the LDS atomics) */
     int32_t rng_mode;       /* 0: the reference's generator (entropy-table walk K3, per-particle state,
                                empic.js:783-820).  1: counter-based extension: the random
                                vector of particle i at sub-step t is Philox4x32-10(counter (i, t, 0x5EED),

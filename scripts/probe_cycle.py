@@ -29,7 +29,7 @@ n = args.side ** 2
 pos, vel, entropy, rand = synthetic_inputs(n, spec, 0x5EEDF051)
 sink, pdf = scene_grids(args.grid, args.grid)
 sim = fp.makeCylindricalParticlePusher(spec, precision=args.precision, sort_interval=args.sort_interval, rng=args.rng,
-                                       fuse_deposit=bool(args.fuse))
+                                       fuse_deposit="census" if args.fuse == 2 else bool(args.fuse))
 sim.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
 if args.rng == "reference":
     sim.setRandomState(entropy, rand)

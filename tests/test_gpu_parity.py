@@ -354,7 +354,7 @@ def test_binning_preserves_particles_and_order_of_readback(fp, po):
     assert_particles_equal(sim, ora)
 
 
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("fuse", [True, False, "census"])
 def test_rebinning_inside_the_push_every_frame(fp, po, fuse):
     """sort_interval=1 asks for a re-binning at every density(): with the fused push the
     NEXT step() launch writes the sorted order itself (no separate pass).  Hot particles in
@@ -910,7 +910,8 @@ def test_randomised_scenes(fp, po, seed):
     pos, vel, entropy, rand = uniform_plasma(n, spec, seed=77 + seed, v_th=float(rng.uniform(1e-4, 0.05)))
     mode = dict(rng="counter", seed=0xC0FFEE + seed) if counter else {}
     sim = fp.makeCylindricalParticlePusher(spec, precision=precision, count=n, compat=not physical_a,
-                                           sort_interval=int(rng.integers(0, 3)), fuse_deposit=bool(rng.random() < 0.7), **mode)
+                                           sort_interval=int(rng.integers(0, 3)),
+                                           fuse_deposit=[True, True, False, "census"][int(rng.integers(0, 4))], **mode)
     ora = po.OracleSim(spec, dtype=dtype, physical_a=physical_a, count=n, **mode)
     for s in (sim, ora):
         s.set(E=E, B=B, position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
