@@ -68,9 +68,9 @@ def test_against_reference_solver_evaluated_in_software(sor, name):
     eq.close()
 
 
-@pytest.mark.parametrize("n_power,relaxation", [(1, None), (2, 1.3), (3, 0.6), (4, None), (5, 0.9)])
+@pytest.mark.parametrize("n_power,relaxation", [(1, None), (2, 1.3), (3, 0.6), (4, None), (5, 0.9), (6, 1.1)])
 def test_against_the_oracle_at_other_sizes(sor, n_power, relaxation):
-    """n_power 4 and 5 use the in-register part of the tree (4 and 16 texels per lane)."""
+    """n_power 4, 5 and 6 use the in-register part of the tree (4, 16 and 64 texels per lane)."""
     from sor_oracle import OracleSOR
     L = 4 * 4 ** n_power
     A, b, x0 = dominant_system(L, seed=100 + n_power)
