@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--rng", choices=["reference", "counter"], default="reference",
                     help="reference = the reference's entropy-table generator (the drop-in, the headline); "
                          "counter = the Philox extension mode (SURVEY.md 8(d))")
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: all-reduce on the pusher's stream, no overlap")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
 
@@ -261,7 +262,9 @@ def main():
         from fusionpic.multi import ShardedPusher, device_tensor_view
         ptr, nbytes = sim.deviceBuffer()
         sums = device_tensor_view(ptr, nbytes, torch.device("cuda", local_rank))
-        sharded = ShardedPusher(sim, sums, stream=stream)  # density() = scatter, RCCL all-reduce, finish
+        # density() = scatter, then on a side stream: RCCL all-reduce of a copy of the sums and the finish
+        # stage, overlapped with the next frame's push
+        sharded = ShardedPusher(sim, sums, stream=stream, overlap=not args.no_overlap)
 
     def cycle():
         sim.precalc()

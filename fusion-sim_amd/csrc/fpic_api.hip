@@ -94,6 +94,10 @@ struct fpic_handle {
     unsigned long long* spilled = nullptr;      // device counter
     unsigned long long* spilled_host = nullptr; // pinned, kSpillSlots entries
     hipEvent_t spill_event[2] = {};
+    // fpic_density_finish_from on a caller's stream: the grids it writes (moments, norm, avg) are
+    // ordered against this handle's own stream through this event
+    hipEvent_t finish_event = nullptr;
+    bool finish_pending = false;
     bool spill_pending[2] = {};
     unsigned long long deposit_seq = 0;
     unsigned long long last_spill = 0;
@@ -484,16 +488,35 @@ int launch_cell_sums(fpic_handle* h)
     return record_spill(h);
 }
 
+// Work queued on this handle's stream that touches moments/norm/avg must come after a finish stage
+// that ran on a caller's stream.
+int wait_external_finish(fpic_handle* h)
+{
+    if (h->finish_pending) {
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->finish_event, 0));
+        h->finish_pending = false;
+    }
+    return FPIC_OK;
+}
+
 template <typename T>
-int launch_stamp_finish(fpic_handle* h)
+int launch_stamp_finish(fpic_handle* h, const void* sums = nullptr, hipStream_t on = nullptr)
 {
     dim3 grid((h->nr + 31) / 32, (h->nz + 31) / 32);
-    timing_begin(h, KC_STAMP);
-    stamp_finish_kernel<T><<<grid, 256, 0, h->stream>>>(static_cast<const T*>(h->cell_sums), h->nr, h->nz, h->stamp,
-                                                     static_cast<T*>(h->moments), static_cast<T*>(h->norm),
-                                                     static_cast<T*>(h->avg), static_cast<T>(0.01)); // u_ratio (empic.js:1083)
-    timing_end(h);
+    const bool external = on != nullptr && on != h->stream;
+    if (!external) {
+        if (int rc = wait_external_finish(h)) return rc;
+        timing_begin(h, KC_STAMP);
+    }
+    stamp_finish_kernel<T><<<grid, 256, 0, external ? on : h->stream>>>(static_cast<const T*>(sums ? sums : h->cell_sums), h->nr, h->nz,
+                                                                      h->stamp, static_cast<T*>(h->moments), static_cast<T*>(h->norm),
+                                                                      static_cast<T*>(h->avg), static_cast<T>(0.01)); // u_ratio (empic.js:1083)
+    if (!external) timing_end(h);
     HIP_TRY(h, hipGetLastError());
+    if (external) {
+        HIP_TRY(h, hipEventRecord(h->finish_event, on));
+        h->finish_pending = true;
+    }
     return FPIC_OK;
 }
 
@@ -640,6 +663,7 @@ void release(fpic_handle* h)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->spilled_host) (void)hipHostFree(h->spilled_host);
     for (hipEvent_t e : h->spill_event) if (e) (void)hipEventDestroy(e);
+    if (h->finish_event) (void)hipEventDestroy(h->finish_event);
     for (PendingTiming& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -939,6 +963,7 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->spilled_host), 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->spill_event[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->spill_event[1], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->finish_event, hipEventDisableTiming)) != hipSuccess ||
         (e = hipStreamSynchronize(h->stream)) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "handle setup failed: %s", hipGetErrorString(e)));
     h->spilled_host[0] = h->spilled_host[1] = 0;
@@ -1132,6 +1157,14 @@ int fpic_density_finish(fpic_handle* h)
     return h->prec == FPIC_F32 ? launch_stamp_finish<float>(h) : launch_stamp_finish<double>(h);
 }
 
+int fpic_density_finish_from(fpic_handle* h, const void* sums, void* hip_stream)
+{
+    CHECK_HANDLE(h);
+    if (!sums) return fail(h, FPIC_ERR_INVALID_ARG, ".sums <- Non-optional property is undefined!");
+    hipStream_t on = static_cast<hipStream_t>(hip_stream);
+    return h->prec == FPIC_F32 ? launch_stamp_finish<float>(h, sums, on) : launch_stamp_finish<double>(h, sums, on);
+}
+
 int fpic_density(fpic_handle* h)
 {
     if (int rc = fpic_deposit(h)) return rc;
@@ -1141,6 +1174,7 @@ int fpic_density(fpic_handle* h)
 int fpic_read_grid(fpic_handle* h, int which, void* out, int dtype)
 {
     CHECK_HANDLE(h);
+    if (int rc = wait_external_finish(h)) return rc;
     if (!out) return fail(h, FPIC_ERR_INVALID_ARG, ".out <- Non-optional property is undefined!");
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
     if (h->prec == FPIC_F32)
@@ -1207,6 +1241,7 @@ int fpic_save_checkpoint(fpic_handle* h, const char* path)
 {
     CHECK_HANDLE(h);
     if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
+    if (int rc = wait_external_finish(h)) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     FileCloser fc{ std::fopen(path, "wb") };
     if (!fc.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
@@ -1222,6 +1257,7 @@ int fpic_load_checkpoint(fpic_handle* h, const char* path)
 {
     CHECK_HANDLE(h);
     if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
+    if (int rc = wait_external_finish(h)) return rc;
     FileCloser fc{ std::fopen(path, "rb") };
     if (!fc.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
     CheckpointHeader hd{};
@@ -1246,6 +1282,7 @@ int fpic_load_checkpoint(fpic_handle* h, const char* path)
 int fpic_sync(fpic_handle* h)
 {
     CHECK_HANDLE(h);
+    if (int rc = wait_external_finish(h)) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FPIC_OK;
 }

@@ -14,6 +14,7 @@ gfx950 device is present the factory raises.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -30,6 +31,7 @@ ABI_FUNCTIONS = [
     "fpic_last_error", "fpic_abi_version", "fpic_build_arch", "fpic_create", "fpic_destroy", "fpic_set_particles",
     "fpic_set_grid", "fpic_set_random_state", "fpic_add_current_loop", "fpic_add_current_z", "fpic_add_bz",
     "fpic_add_btheta", "fpic_precalc", "fpic_step", "fpic_density", "fpic_deposit", "fpic_density_finish",
+    "fpic_density_finish_from",
     "fpic_read_grid", "fpic_get_particles", "fpic_get_cells", "fpic_device_buffer", "fpic_set_stream",
     "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
     "fpic_get_substep_counter", "fpic_set_substep_counter", "fpic_save_checkpoint", "fpic_load_checkpoint",
@@ -75,6 +77,14 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  Two runtimes in one process do not share
+    # the device (the second one reports "No HIP GPUs"), so when torch is installed it is imported
+    # first and libfusionpic.so then binds to the runtime already loaded.  FUSIONPIC_NO_TORCH=1 skips
+    # this for hosts that never touch torch.
+    if "torch" not in sys.modules and not os.environ.get("FUSIONPIC_NO_TORCH"):
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     if not os.path.exists(path):
         raise ImportError("%s not found: build it with `make -C fusion-sim_amd` (hipcc, gfx950); "
                           "there is no CPU fallback" % path)
@@ -94,6 +104,7 @@ def load_library(path=None):
     for f in ("fpic_precalc", "fpic_density", "fpic_deposit", "fpic_density_finish", "fpic_sort", "fpic_sync",
               "fpic_reset_stats"):
         getattr(lib, f).argtypes = [vp]
+    lib.fpic_density_finish_from.argtypes = [vp, vp, vp]
     lib.fpic_step.argtypes = [vp, ci]
     lib.fpic_profile.argtypes = [vp, ci]
     lib.fpic_read_grid.argtypes = [vp, ci, vp, ci]
@@ -245,6 +256,10 @@ class CylindricalParticlePusher:
 
     def densityFinish(self):
         self._check(self._lib.fpic_density_finish(self._h))
+
+    def densityFinishFrom(self, sums_ptr, stream=None):
+        """finish stage from a caller's copy of the per-cell sums, on a caller's stream (multi-GPU overlap)"""
+        self._check(self._lib.fpic_density_finish_from(self._h, ctypes.c_void_p(sums_ptr), ctypes.c_void_p(stream or 0)))
 
     def setRandomState(self, entropy=None, rand=None):
         e = r = None

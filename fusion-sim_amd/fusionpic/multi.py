@@ -35,10 +35,23 @@ class ShardedPusher:
 
     `sim` offers precalc(), step(n), deposit(), densityFinish(); `sums` is a tensor that
     aliases sim's per-cell sums (a device view on GPU ranks, a CPU tensor in tests).
+
+    overlap=True (GPU ranks): the sums are copied to a buffer of their own, the all-reduce and
+    the stamp / normalise / EMA stage run on a side stream, and the next step() starts at once on
+    the pusher's stream — the deposit is never fed back into the push (empic.js:1471-1505), so
+    nothing on the pusher's stream waits for the exchange.  The copy is 16.8 MB at C2.
     """
 
-    def __init__(self, sim, sums, group=None, stream=None):
+    def __init__(self, sim, sums, group=None, stream=None, overlap=False):
         self.sim, self.sums, self.group, self.stream = sim, sums, group, stream
+        self.overlap = bool(overlap) and stream is not None
+        if self.overlap:
+            import torch
+            self.side = torch.cuda.Stream(device=sums.device)
+            self.buf = torch.empty_like(sums)
+            self.copied = torch.cuda.Event()
+            self.finished = torch.cuda.Event()
+            self.finished.record(self.side)
 
     def precalc(self):
         self.sim.precalc()
@@ -49,6 +62,19 @@ class ShardedPusher:
     def density(self):
         import torch.distributed as dist
         self.sim.deposit()
+        if self.overlap:
+            import torch
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(self.finished)      # the previous frame's finish still reads buf
+                self.buf.copy_(self.sums)
+                self.copied.record(self.stream)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.copied)
+                if dist.is_initialized():
+                    dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+                self.sim.densityFinishFrom(self.buf.data_ptr(), self.side.cuda_stream)
+                self.finished.record(self.side)
+            return
         if dist.is_initialized():  # also with a world of one: the same calls as the N-GPU launch
             if self.stream is not None:
                 import torch
@@ -57,3 +83,8 @@ class ShardedPusher:
             else:
                 dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
         self.sim.densityFinish()
+
+    def sync(self):
+        if self.overlap:
+            self.side.synchronize()
+        self.sim.sync()

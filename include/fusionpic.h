@@ -190,6 +190,12 @@ int fpic_step(fpic_handle* h, int ncalls);
 int fpic_density(fpic_handle* h);
 int fpic_deposit(fpic_handle* h);
 int fpic_density_finish(fpic_handle* h);
+/* fpic_density_finish reading the per-cell sums from a caller's device buffer (same layout as
+ * FPIC_BUF_CELL_SUMS) and running on a caller's stream (NULL: the handle's).  A multi-GPU host
+ * copies the sums out after fpic_deposit, all-reduces the copy and finishes from it on a side
+ * stream while the next step() already runs; the library orders its own later reads of the
+ * density grids after that finish. */
+int fpic_density_finish_from(fpic_handle* h, const void* sums, void* hip_stream);
 
 /* fb.readPixels (utilities.js:701-711) for the grids above.  out holds
  * 4*W*H floats (dtype F32) or doubles (F64). */

@@ -933,3 +933,54 @@ def test_randomised_scenes(fp, po, seed):
                 if ok.any():
                     assert np.abs(g[ok, c] - w[ok, c]).max() <= rtol * max(np.abs(w[ok, c]).max(), 1e-300), (which, c)
     sim.destroy()
+
+
+def test_sharded_pusher_overlapped_exchange_world_of_one(fp, po):
+    """fusionpic.multi.ShardedPusher with overlap: the per-cell sums are copied out, all-reduced
+    (RCCL, world of one here — the same calls as the N-GPU launch) and finished on a side stream
+    while the next step() runs.  Frame by frame the density buffers equal those of a plain pusher
+    on the same scene up to the order of the float atomics (two runs of the same pusher differ by
+    as much), and particles are untouched by the exchange."""
+    import torch
+    import torch.distributed as dist
+    from fusionpic.multi import ShardedPusher, device_tensor_view
+    spec = make_spec(96, 80, 200, radius=1.0, height=2.0)
+    n = 200 * 200
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=31, v_th=5e-3)
+    sink = frame_sink(96, 80)
+    torch.cuda.set_device(0)
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", world_size=1, rank=0,
+                                device_id=torch.device("cuda", 0))
+    def close(a, b):
+        a, b = a.reshape(-1, 4), b.reshape(-1, 4)
+        return all(np.nanmax(np.abs(a[:, c] - b[:, c])) <= 1e-5 * np.nanmax(np.abs(b[:, c])) for c in range(4))
+
+    try:
+        stream = torch.cuda.Stream(device=0)
+        sims = []
+        for k in range(2):
+            s = fp.makeCylindricalParticlePusher(spec)
+            s.setStream(stream.cuda_stream)
+            s.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=sink)
+            s.setRandomState(entropy, rand)
+            s.addBZ(0.02); s.precalc(); s.sort()
+            sims.append(s)
+        plain, shard_sim = sims
+        ptr, nbytes = shard_sim.deviceBuffer()
+        sharded = ShardedPusher(shard_sim, device_tensor_view(ptr, nbytes, torch.device("cuda", 0)), stream=stream, overlap=True)
+        for frame in range(6):
+            plain.step(); plain.density()
+            sharded.step(); sharded.density()
+            if frame % 2 == 1:          # read-back in the middle of the pipeline must see the finished frame
+                assert close(shard_sim.readDensity(), plain.readDensity()), frame
+                assert close(shard_sim.readMoments(), plain.readMoments()), frame
+        sharded.sync()
+        assert close(shard_sim.readDensity(), plain.readDensity())
+        a, b = shard_sim.getParticles(), plain.getParticles()
+        assert same_bits(a["position"], b["position"]) and same_bits(a["velocity"], b["velocity"])
+        plain.destroy(); shard_sim.destroy()
+    finally:
+        if own:
+            dist.destroy_process_group()
