@@ -343,6 +343,12 @@ def main():
         if tr and world == 1:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_source"] = tr.get("source")
+            if push_ms > 0 and tr.get("bytes_per_launch"):
+                # what the kernel really moves per second (PMC bytes / measured launch time): the excess over
+                # `achieved` is the reference RNG's entropy-table gather (64-B lines for 16-B texels), DESIGN.md 4.2
+                rate = tr["bytes_per_launch"] / (push_ms * 1e-3) / 1e9
+                out["roofline"]["traffic_rate_GBs"] = rate
+                out["roofline"]["traffic_rate_frac_of_peak"] = rate / HBM_PEAK_GBS
         if args.rng == "counter":
             out["config"]["workload"] += "; EXTENSION: counter-based RNG (Philox4x32-10) instead of the reference's entropy-table generator"
         if world == 1 and not args.no_cpu_baseline:
