@@ -384,10 +384,11 @@ int launch_push(fpic_handle* h, int nsub)
     a.t0 = h->t_substep;
     const bool ctr = h->spec.rng_mode == 1;
     const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
-    // float state, binned, fusion not switched off: the push also forms the per-cell sums
-    // and the tile census, and on a re-binning launch writes the sorted order itself
-    const bool fuse = sizeof(T) == 4 && h->binned && h->spec.unfused_deposit != 1;
-    const bool sums = fuse && h->spec.unfused_deposit == 0; // 2: census and re-binning fused, sums separate
+    // binned, fusion not switched off: the push also counts the particles per tile and, on a re-binning
+    // launch, writes the sorted order itself; float state with unfused_deposit == 0 forms the per-cell
+    // sums as well (for double the coefficient window alone fills the LDS, so the sums stay separate)
+    const bool fuse = h->binned && h->spec.unfused_deposit != 1;
+    const bool sums = fuse && sizeof(T) == 4 && h->spec.unfused_deposit == 0;
     const bool scatter = fuse && h->scatter_pending;
     TileArgs<T> t{};
     t.ntx = h->ntx; t.ntz = h->ntz; t.ntiles = h->ntiles;
@@ -401,9 +402,9 @@ int launch_push(fpic_handle* h, int nsub)
     const unsigned grid = static_cast<unsigned>(h->work_cap);
     timing_begin(h, KC_PUSH);
     if (fuse) {
+        HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
         if constexpr (sizeof(T) == 4) {
             const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
-            HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
             if (sums) {
                 HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
                 HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
@@ -419,6 +420,12 @@ int launch_push(fpic_handle* h, int nsub)
                 else if (ctr) push_tiles_kernel<T, true, false, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
                 else push_tiles_kernel<T, true, false, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
             }
+        } else {
+            constexpr size_t lds = push_tiles_lds_bytes<T, true, false>();
+            if (scatter && ctr) push_tiles_kernel<T, true, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            else if (scatter) push_tiles_kernel<T, true, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            else if (ctr) push_tiles_kernel<T, true, false, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            else push_tiles_kernel<T, true, false, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
         }
     } else if (h->binned) { // the work list of the last binning is valid until the next one: the push is in place
         if (ctr) push_tiles_kernel<T, false, false, true><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
@@ -944,6 +951,10 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
         (e = set_lds(push_tiles_kernel<float, true, false, true, false>, push_tiles_lds_bytes<float, true, false>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<float, true, true, false, false>, push_tiles_lds_bytes<float, true, false>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<float, true, true, true, false>, push_tiles_lds_bytes<float, true, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<double, true, false, false, false>, push_tiles_lds_bytes<double, true, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<double, true, false, true, false>, push_tiles_lds_bytes<double, true, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<double, true, true, false, false>, push_tiles_lds_bytes<double, true, false>())) != hipSuccess ||
+        (e = set_lds(push_tiles_kernel<double, true, true, true, false>, push_tiles_lds_bytes<double, true, false>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<double, false, false, false>, push_tiles_lds_bytes<double, false>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<double, false, false, true>, push_tiles_lds_bytes<double, false>())) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e)));
@@ -1130,7 +1141,7 @@ int fpic_deposit(fpic_handle* h)
         }
     }
     if (rebin) {
-        if (h->prec == FPIC_F32 && h->binned && h->census_fresh && h->spec.unfused_deposit != 1) {
+        if (h->binned && h->census_fresh && h->spec.unfused_deposit != 1) {
             // The last push counted the particles per tile as it stored them.  Lay the
             // next order out from that census now; the next push writes it (no extra pass).
             const int nw = h->wl ^ 1;
