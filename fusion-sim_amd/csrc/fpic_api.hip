@@ -97,6 +97,7 @@ struct fpic_handle {
     // fpic_density_finish_from on a caller's stream: the grids it writes (moments, norm, avg) are
     // ordered against this handle's own stream through this event
     hipEvent_t finish_event = nullptr;
+    hipEvent_t order_event = nullptr; // "everything queued on the handle's stream so far", for a caller's stream to wait on
     bool finish_pending = false;
     bool spill_pending[2] = {};
     unsigned long long deposit_seq = 0;
@@ -307,10 +308,13 @@ int download_misc(fpic_handle* h, float* rand, uint8_t* alive, int32_t* cells)
     float* srand = nullptr;
     uint8_t* salive = nullptr;
     int32_t* scells = nullptr;
-    if (rand) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&srand), m0 * 4 * sizeof(float)));
-    if (alive) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&salive), m0));
-    if (cells) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&scells), m0 * sizeof(int32_t)));
+    hipError_t ea = hipSuccess;
+    if (rand) ea = hipMalloc(reinterpret_cast<void**>(&srand), m0 * 4 * sizeof(float));
+    if (ea == hipSuccess && alive) ea = hipMalloc(reinterpret_cast<void**>(&salive), m0);
+    if (ea == hipSuccess && cells) ea = hipMalloc(reinterpret_cast<void**>(&scells), m0 * sizeof(int32_t));
     int rc = FPIC_OK;
+    if (ea != hipSuccess)
+        rc = fail(h, ea == hipErrorOutOfMemory ? FPIC_ERR_OOM : FPIC_ERR_HIP, "read-back staging allocation failed: %s", hipGetErrorString(ea));
     for (size_t b = 0; b < h->n && rc == FPIC_OK; b += chunk) {
         const size_t m = std::min(chunk, h->n - b);
         get_rand_kernel<T><<<blocks_for(h->n), 256, 0, h->stream>>>(arrays<T>(h, h->cur), h->n, b, m, srand, salive, scells,
@@ -514,6 +518,11 @@ int launch_stamp_finish(fpic_handle* h, const void* sums = nullptr, hipStream_t 
     if (!external) {
         if (int rc = wait_external_finish(h)) return rc;
         timing_begin(h, KC_STAMP);
+    } else {
+        // the caller's stream follows whatever this handle has queued so far (an earlier finish stage,
+        // a read-back of the density grids), not what it queues later
+        HIP_TRY(h, hipEventRecord(h->order_event, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(on, h->order_event, 0));
     }
     stamp_finish_kernel<T><<<grid, 256, 0, external ? on : h->stream>>>(static_cast<const T*>(sums ? sums : h->cell_sums), h->nr, h->nz,
                                                                       h->stamp, static_cast<T*>(h->moments), static_cast<T*>(h->norm),
@@ -671,6 +680,7 @@ void release(fpic_handle* h)
     if (h->spilled_host) (void)hipHostFree(h->spilled_host);
     for (hipEvent_t e : h->spill_event) if (e) (void)hipEventDestroy(e);
     if (h->finish_event) (void)hipEventDestroy(h->finish_event);
+    if (h->order_event) (void)hipEventDestroy(h->order_event);
     for (PendingTiming& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -975,6 +985,7 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
         (e = hipEventCreateWithFlags(&h->spill_event[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->spill_event[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->finish_event, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->order_event, hipEventDisableTiming)) != hipSuccess ||
         (e = hipStreamSynchronize(h->stream)) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "handle setup failed: %s", hipGetErrorString(e)));
     h->spilled_host[0] = h->spilled_host[1] = 0;
