@@ -228,7 +228,14 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # the exchange overlaps the next frame's push (ShardedPusher): give RCCL's stream priority so its
+        # few workgroups are placed as soon as a push workgroup retires
+        opts = None
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except (AttributeError, TypeError):
+            pass
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
     spec = dict(radius=1.0, height=1.0, nr=args.grid, nz=args.grid, dt=2e-9, nparticles=args.side,
                 particle_mass=1.67e-27, particle_charge=1.602e-19)

@@ -47,7 +47,7 @@ class ShardedPusher:
         self.overlap = bool(overlap) and stream is not None
         if self.overlap:
             import torch
-            self.side = torch.cuda.Stream(device=sums.device)
+            self.side = torch.cuda.Stream(device=sums.device, priority=-1)
             self.buf = torch.empty_like(sums)
             self.copied = torch.cuda.Event()
             self.finished = torch.cuda.Event()
