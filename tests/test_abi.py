@@ -180,3 +180,34 @@ console.log(JSON.stringify(out));
         assert ref_api <= set(out["methods"])
     else:
         assert "no CPU fallback" in out["create_error"]
+
+
+@pytest.mark.skipif(node is None, reason="node is not installed")
+def test_node_solver_shim_mirrors_reference_surface():
+    """matrix_native.js: the factory validates like the reference (utilities.js:118-127), n_power = 0
+    throws as the reference does, and without a device the factory throws instead of falling back."""
+    if not os.path.exists(ADDON):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fusion-sim_amd"), "napi"])
+    script = r"""
+const m = require(process.argv[1]);
+const out = {errors: []};
+for (const bad of [{}, {n_power: '3'}, {n_power: 0}, {n_power: 2, relaxation: 'x'}]) {
+  try { m.makeSORIterative(bad); out.errors.push(null); } catch (x) { out.errors.push(x.message); }
+}
+try { const eq = m.makeSORIterative({n_power: 1}); out.members = Object.keys(eq).sort(); out.vec_length = eq.vec_length; eq.destroy(); }
+catch (x) { out.create_error = x.message; }
+console.log(JSON.stringify(out));
+"""
+    import json
+    shim = os.path.join(ROOT, "fusion-sim_amd", "js", "matrix_native.js")
+    out = json.loads(subprocess.check_output([node, "-e", script, shim]))
+    assert out["errors"][0] == ".n_power <- Non-optional property is undefined!"
+    assert out["errors"][1] == ".n_power <- Property does not match any given possible types!"
+    assert "u_Vsum" in out["errors"][2]
+    assert out["errors"][3] == ".relaxation <- Property does not match any given possible types!"
+    if has_gpu():
+        # members of the object the reference returns (matrix_webgl.js:50-51, :456-704)
+        assert {"vec_length", "vec_height", "set_matrix", "set_b", "init_vector", "mv_product", "solve", "x_result_tex"} <= set(out["members"])
+        assert out["vec_length"] == 16
+    else:
+        assert "no CPU fallback" in out["create_error"]
