@@ -19,7 +19,10 @@ struct ProbeArgs {
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-enum { NO_ENTROPY = 1, NO_COEF = 2, NO_SINK = 4, FAST_MATH = 8, NO_STORE = 16, NO_RAND_IO = 32, ENTROPY_1MB = 64, ENTROPY_16KB = 128, ENTROPY_4MB = 256 };
+enum { NO_ENTROPY = 1, NO_COEF = 2, NO_SINK = 4, FAST_MATH = 8, NO_STORE = 16, NO_RAND_IO = 32, ENTROPY_1MB = 64, ENTROPY_16KB = 128, ENTROPY_4MB = 256,
+       GATHER_AUX_SHIFT = 12 }; // bits 12..: (aux + 1) of a buffer-instruction gather: 1 = sc0, 2 = nt, 16 = sc1, sums thereof
+
+typedef unsigned int nat_b128 __attribute__((ext_vector_type(4)));
 
 template <int M>
 __device__ __forceinline__ void substep_v(Particle<float>& q, const ProbeArgs& a)
@@ -30,7 +33,14 @@ __device__ __forceinline__ void substep_v(Particle<float>& q, const ProbeArgs& a
         if (M & ENTROPY_1MB) et &= 0xFFFF;      // timing only: 64K texels = 1 MB footprint
         if (M & ENTROPY_4MB) et &= 0x3FFFF;     // 4 MB
         if (M & ENTROPY_16KB) et &= 0x3FF;      // 16 KB
-        load4(a.entropy + 4 * static_cast<size_t>(et), s);
+        constexpr int aux1 = M >> GATHER_AUX_SHIFT;
+        if constexpr (aux1 == 0) {
+            load4(a.entropy + 4 * static_cast<size_t>(et), s);
+        } else {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.entropy), 0, 0xFFFFFFF0u, 0x00020000);
+            const nat_b128 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, et * 16, 0, aux1 - 1);
+            s[0] = __uint_as_float(raw.x); s[1] = __uint_as_float(raw.y); s[2] = __uint_as_float(raw.z); s[3] = __uint_as_float(raw.w);
+        }
     }
     float r, dx, dy;
     if (M & FAST_MATH) {
@@ -202,6 +212,13 @@ int main(int argc, char** argv)
         printf("no stores                  %.3f ms\n", run<NO_STORE, 256>(a, reps, p, sorted, grid));
         printf("no rand I/O (6 streams)    %.3f ms\n", run<NO_RAND_IO, 256>(a, reps, p, sorted, grid));
         printf("no coef/sink (~LDS-staged) %.3f ms\n", run<NO_COEF | NO_SINK, 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, buffer load aux 0        %.3f ms\n", run<NO_COEF | NO_SINK | (1 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, buffer load sc0          %.3f ms\n", run<NO_COEF | NO_SINK | (2 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, buffer load nt           %.3f ms\n", run<NO_COEF | NO_SINK | (3 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, buffer load sc0 nt       %.3f ms\n", run<NO_COEF | NO_SINK | (4 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, buffer load sc1          %.3f ms\n", run<NO_COEF | NO_SINK | (17 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, buffer load sc0 sc1      %.3f ms\n", run<NO_COEF | NO_SINK | (18 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, buffer load sc1 nt       %.3f ms\n", run<NO_COEF | NO_SINK | (19 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
         printf(" + entropy footprint 4 MB  %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_4MB, 256>(a, reps, p, sorted, grid));
         printf(" + entropy footprint 1 MB  %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_1MB, 256>(a, reps, p, sorted, grid));
         printf(" + entropy footprint 16 KB %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_16KB, 256>(a, reps, p, sorted, grid));
