@@ -20,7 +20,7 @@ constexpr int kEntropySide = 1024;           // empic.js:142
 constexpr int kTileSide = 32;                // cells per tile edge
 constexpr int kTileHalo = 8;                 // extra cells kept in LDS around a tile
 constexpr int kTileLds = kTileSide + 2 * kTileHalo;
-constexpr int kDepositChunk = 32768;         // particles per scatter workgroup
+constexpr int kDepositChunk = 16384;         // particles per workgroup and chunk (sweep: profiles/r01_rebin_ablation.txt)
 constexpr int kMaxTiles = 16384;             // LDS histogram limit of the binning pass
 
 struct Constants {
