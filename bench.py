@@ -184,16 +184,20 @@ def dense_sor_line(device, n_power=6, products=60):
                          "algorithmic_bytes_per_launch": st["matrix_bytes"], "launches_timed": st["iterations"]}}
 
 
-def measured_traffic():
+def measured_traffic(config):
     """HBM bytes per push launch from the committed PMC passes (scripts/pmc_bench.sh,
-    profiles/*_traffic.json): rocprofv3 cannot run inside the timed process."""
+    profiles/*_traffic.json): rocprofv3 cannot run inside the timed process, so the figure is the
+    builder-side measurement of the SAME configuration (particles per GPU, grid, generator,
+    precision) — for any other configuration there is none and `traffic` stays null."""
     best = None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
         try:
-            best = json.load(open(f))
+            j = json.load(open(f))
         except Exception:
-            pass
+            continue
+        if j.get("config") == config:
+            best = dict(j, file=os.path.relpath(f, ROOT))
     return best
 
 
@@ -346,10 +350,12 @@ def main():
                 "last_spilled": st["deposit_spilled"],
             },
         }
-        tr = measured_traffic()
+        tr = measured_traffic({"particles_per_gpu": n_local, "grid": [spec["nr"], spec["nz"]], "rng": args.rng, "dtype": "f32"})
+        if tr is None:
+            out["roofline"]["traffic_source"] = "no committed PMC pass for this configuration (profiles/r*_traffic.json)"
         if tr and world == 1:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
-            out["roofline"]["traffic_source"] = tr.get("source")
+            out["roofline"]["traffic_source"] = "%s: %s" % (tr.get("file"), tr.get("source"))
             if push_ms > 0 and tr.get("bytes_per_launch"):
                 # what the kernel really moves per second (PMC bytes / measured launch time): the excess over
                 # `achieved` is the reference RNG's entropy-table gather (64-B lines for 16-B texels), DESIGN.md 4.2

@@ -523,6 +523,9 @@ int launch_stamp_finish(fpic_handle* h, const void* sums = nullptr, hipStream_t 
         // a read-back of the density grids), not what it queues later
         HIP_TRY(h, hipEventRecord(h->order_event, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(on, h->order_event, 0));
+        // ... and an earlier finish stage that is still pending on ANOTHER caller's stream: both
+        // read-modify-write the running average
+        if (h->finish_pending) HIP_TRY(h, hipStreamWaitEvent(on, h->finish_event, 0));
     }
     stamp_finish_kernel<T><<<grid, 256, 0, external ? on : h->stream>>>(static_cast<const T*>(sums ? sums : h->cell_sums), h->nr, h->nz,
                                                                       h->stamp, static_cast<T*>(h->moments), static_cast<T*>(h->norm),
@@ -805,7 +808,6 @@ int load_state(fpic_handle* h, FILE* f)
     for (int a = 0; a < 10; ++a)
         if (int rc = load_block(h, f, h->part[h->cur][a], h->n * sizeof(T), host)) return rc;
     if (int rc = load_block(h, f, h->alive[h->cur], h->n, host)) return rc;
-    iota_kernel<<<blocks_for(h->n), 256, 0, h->stream>>>(h->id[h->cur], h->n);
     const size_t rgba = h->ncell * 4 * sizeof(T);
     struct { void* p; size_t bytes; } grids[] = {
         { h->E, rgba }, { h->B, rgba }, { h->sink, rgba },
@@ -1291,12 +1293,29 @@ int fpic_load_checkpoint(fpic_handle* h, const char* path)
     if (hd.spec.radius != h->spec.radius || hd.spec.height != h->spec.height || hd.spec.dt != h->spec.dt ||
         hd.spec.particle_mass != h->spec.particle_mass || hd.spec.particle_charge != h->spec.particle_charge)
         return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint was written with different radius/height/dt/mass/charge");
+    // the whole payload must be there before any device state is touched: a short file is refused
+    // with the handle unchanged
+    const size_t rgba = h->ncell * 4 * h->esize;
+    const unsigned long long want = sizeof hd + 10ull * h->n * h->esize + h->n + 4ull * rgba +
+                                    static_cast<unsigned long long>(kCdfSide) * kCdfSide * 2 * h->esize +
+                                    static_cast<unsigned long long>(kEntropySide) * kEntropySide * 4 * h->esize;
+    if (std::fseek(fc.f, 0, SEEK_END) != 0) return fail(h, FPIC_ERR_STATE, "cannot seek in %s", path);
+    const long long have = std::ftell(fc.f);
+    if (have < 0 || static_cast<unsigned long long>(have) < want)
+        return fail(h, FPIC_ERR_STATE, "checkpoint is truncated: %lld bytes, %llu expected", have, want);
+    if (std::fseek(fc.f, static_cast<long>(sizeof hd), SEEK_SET) != 0) return fail(h, FPIC_ERR_STATE, "cannot seek in %s", path);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // from here on the particle arrays are overwritten in the caller's order: whatever the bins, the
+    // census and the fused sums said about the old order is void, also if a read fails half-way
+    h->binned = false;
+    h->sums_fresh = h->census_fresh = h->scatter_pending = false;
+    h->spill_pending[0] = h->spill_pending[1] = false;
+    h->last_spill = 0;
+    iota_kernel<<<blocks_for(h->n), 256, 0, h->stream>>>(h->id[h->cur], h->n);
+    HIP_TRY(h, hipGetLastError());
     const int rc = h->prec == FPIC_F32 ? load_state<float>(h, fc.f) : load_state<double>(h, fc.f);
     if (rc) return rc;
     h->t_substep = hd.t_substep;
-    h->binned = false;
-    h->sums_fresh = h->census_fresh = h->scatter_pending = false;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FPIC_OK;
 }

@@ -75,6 +75,14 @@ const GRID_OUT = { moments: 0, norm: 1, avg: 2, R1: 3, R2: 4, R3: 5, A: 6, B: 7,
 
 function isFloatArray(a) { return a instanceof Float32Array || a instanceof Float64Array; }
 
+// a caller-supplied output buffer must be exactly as long as what the native call writes
+function checkLength(buf, want, name) {
+    if (buf !== undefined && buf !== null && buf.length !== want) {
+        throw new RangeError('.' + name + ' <- expected a typed array of ' + want + ' elements, got ' + buf.length);
+    }
+    return buf;
+}
+
 // value[i][j][k] or value[i][j] -> Float64Array (JavaScript numbers are doubles)
 function flattenGrid(value, nr, nz, ncomp, name) {
     if (isFloatArray(value)) {
@@ -155,19 +163,21 @@ exports.makeCylindricalParticlePusher = function (spec) {
     out.readGrid = function (name, buf) {
         if (!(name in GRID_OUT)) throw new Error('.name <- unknown grid ' + name);
         const cells = name === 'inv_cdf' ? 512 * 512 : nr * nz;
-        return lib.readGrid(h, GRID_OUT[name], buf || new Real(4 * cells));
+        return lib.readGrid(h, GRID_OUT[name], checkLength(buf, 4 * cells, 'out') || new Real(4 * cells));
     };
     out.readDensity = function (buf) { return out.readGrid('avg', buf); };
     out.readMoments = function (buf) { return out.readGrid('moments', buf); };
     out.getParticles = function (into) {
         const r = into || { position: new Real(3 * n), velocity: new Real(3 * n), rand: new Float32Array(4 * n), alive: new Uint8Array(n) };
+        checkLength(r.position, 3 * n, 'position'); checkLength(r.velocity, 3 * n, 'velocity');
+        checkLength(r.rand, 4 * n, 'rand'); checkLength(r.alive, n, 'alive');
         lib.getParticles(h, r.position || null, r.velocity || null, r.rand || null, r.alive || null);
         return r;
     };
-    out.getCells = function (buf) { return lib.getCells(h, buf || new Int32Array(n)); };
+    out.getCells = function (buf) { return lib.getCells(h, checkLength(buf, n, 'cells') || new Int32Array(n)); };
     out.setRandomState = function (state) {
         const f32 = function (a) { return a === undefined || a === null ? null : (a instanceof Float32Array ? a : Float32Array.from(a)); };
-        lib.setRandomState(h, f32(state.entropy), f32(state.rand));
+        lib.setRandomState(h, checkLength(f32(state.entropy), 4 * 1024 * 1024, 'entropy'), checkLength(f32(state.rand), 4 * n, 'rand'));
     };
     out.saveCheckpoint = function (path) { lib.saveCheckpoint(h, String(path)); };
     out.loadCheckpoint = function (path) { lib.loadCheckpoint(h, String(path)); };

@@ -33,6 +33,8 @@
 
 typedef struct {
     fpic_handle* h;
+    size_t n;     /* particle count of the handle: every typed array is checked against the */
+    size_t cells; /* size the ABI call will read or write before its pointer is passed on   */
 } box_t;
 
 static void box_finalize(napi_env env, void* data, void* hint)
@@ -52,6 +54,19 @@ static napi_value throw_fpic(napi_env env, fpic_handle* h)
     return NULL;
 }
 
+static __thread box_t* g_box; /* box of the call being served on this JS thread (set by get_args) */
+
+/* A typed array whose length differs from what the ABI call touches is a RangeError in
+ * JavaScript, never a native out-of-bounds access. */
+static int check_len(napi_env env, const char* name, size_t len, size_t want)
+{
+    if (len == want) return 1;
+    char msg[160];
+    snprintf(msg, sizeof msg, ".%s <- expected a typed array of %zu elements, got %zu", name, want, len);
+    napi_throw_range_error(env, NULL, msg);
+    return 0;
+}
+
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv, fpic_handle** h)
 {
     size_t argc = want;
@@ -66,6 +81,7 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
             return 0;
         }
         *h = b->h;
+        g_box = b;
     }
     return 1;
 }
@@ -134,6 +150,8 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     box_t* b = (box_t*)malloc(sizeof *b);
     if (!b) { fpic_destroy(h); napi_throw_error(env, NULL, "out of memory"); return NULL; }
     b->h = h;
+    b->n = s.count ? (size_t)s.count : (size_t)s.nparticles * (size_t)s.nparticles;
+    b->cells = (size_t)s.nr * (size_t)s.nz;
     napi_value ext;
     if (napi_create_external(env, b, box_finalize, NULL, &ext) != napi_ok) {
         box_finalize(env, b, NULL);
@@ -201,6 +219,7 @@ static napi_value n_set_random_state(napi_env env, napi_callback_info info)
         if (!get_typed(env, argv[1 + k], &t, &ptr[k], &len)) return NULL;
         if (ptr[k] && t != napi_float32_array) { napi_throw_type_error(env, NULL, "expected Float32Array"); return NULL; }
         if (ptr[k] && k == 0 && len != (size_t)4 * 1024 * 1024) { napi_throw_error(env, NULL, ".entropy <- expected 1024*1024*4 floats"); return NULL; }
+        if (ptr[k] && k == 1 && !check_len(env, "rand", len, 4 * g_box->n)) return NULL;
     }
     if (fpic_set_random_state(h, (const float*)ptr[0], (const float*)ptr[1]) != FPIC_OK) return throw_fpic(env, h);
     return undefined(env);
@@ -272,6 +291,7 @@ static napi_value n_read_grid(napi_env env, napi_callback_info info)
     if (!get_typed(env, argv[2], &t, &data, &len)) return NULL;
     if (!data) { napi_throw_type_error(env, NULL, "expected a typed array"); return NULL; }
     if (!float_dtype(env, t, &dtype)) return NULL;
+    if (!check_len(env, "out", len, 4 * ((int)which == FPIC_READ_INV_CDF ? (size_t)512 * 512 : g_box->cells))) return NULL;
     if (fpic_read_grid(h, (int)which, data, dtype) != FPIC_OK) return throw_fpic(env, h);
     return argv[2];
 }
@@ -293,6 +313,10 @@ static napi_value n_get_particles(napi_env env, napi_callback_info info)
     }
     if (p[2] && t[2] != napi_float32_array) { napi_throw_type_error(env, NULL, "rand must be a Float32Array"); return NULL; }
     if (p[3] && t[3] != napi_uint8_array) { napi_throw_type_error(env, NULL, "alive must be a Uint8Array"); return NULL; }
+    static const char* const names[4] = { "position", "velocity", "rand", "alive" };
+    static const size_t per[4] = { 3, 3, 4, 1 };
+    for (int k = 0; k < 4; ++k)
+        if (p[k] && !check_len(env, names[k], len[k], per[k] * g_box->n)) return NULL;
     if (fpic_get_particles(h, p[0], p[1], (float*)p[2], (uint8_t*)p[3], dtype) != FPIC_OK) return throw_fpic(env, h);
     return undefined(env);
 }
@@ -304,6 +328,7 @@ static napi_value n_get_cells(napi_env env, napi_callback_info info)
     napi_typedarray_type t; void* p; size_t len;
     if (!get_typed(env, argv[1], &t, &p, &len)) return NULL;
     if (!p || t != napi_int32_array) { napi_throw_type_error(env, NULL, "expected an Int32Array"); return NULL; }
+    if (!check_len(env, "cells", len, g_box->n)) return NULL;
     if (fpic_get_cells(h, (int32_t*)p) != FPIC_OK) return throw_fpic(env, h);
     return argv[1];
 }

@@ -13,7 +13,10 @@ import re
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-particles = 100000000
+# the configuration the passes were taken on (scripts/pmc_bench.sh runs bench.py's defaults); bench.py attaches
+# the figure only to a run of exactly this configuration
+particles = int(sys.argv[3]) if len(sys.argv) > 3 else 100000000
+grid = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 
 
 def mean_kb(path, counter):
@@ -33,8 +36,9 @@ json.dump({
     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2` "
               "(profiles/r01_pmc/*.csv), mean over the reference-RNG push_tiles_kernel<float,true,*,false,true> dispatches "
               "(in-place and re-binning launches); gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts 16-B/lane "
-              "streamed reads at half their bytes, so half of the kernel's known streamed read (41 B x 1e8 particles) is "
+              "streamed reads at half their bytes, so half of the kernel's known streamed read (41 B x particles) is "
               "added back; WRITE_SIZE is exact",
     "algorithmic_bytes_per_launch": 48.0 * 2 * particles,
+    "config": {"particles_per_gpu": particles, "grid": [grid, grid], "rng": "reference", "dtype": "f32"},
 }, open(out, "w"), indent=1)
 print(open(out).read())

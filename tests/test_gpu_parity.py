@@ -802,6 +802,52 @@ simulation.destroy();
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-3)
 
 
+def test_node_addon_rejects_wrong_sized_buffers():
+    """A typed array of the wrong length is a JavaScript RangeError in the shim AND in the addon
+    (called directly, without the shim), never a native out-of-bounds access."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    from helpers import ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    script = r"""
+const empic = require(process.argv[1]);
+const spec = {radius: 1, height: 1, nr: 12, nz: 10, dt: 2e-9, nparticles: 5, particle_mass: 1.67e-27, particle_charge: 1.6e-19};
+const sim = empic.makeCylindricalParticlePusher(spec);
+const lib = empic._addon();
+const res = {};
+const tryit = (k, f) => { try { f(); res[k] = 'no error'; } catch (e) { res[k] = e.constructor.name + ': ' + e.message; } };
+tryit('readDensity', () => sim.readDensity(new Float32Array(12 * 10)));
+tryit('readGrid_inv_cdf', () => sim.readGrid('inv_cdf', new Float32Array(4 * 12 * 10)));
+tryit('getParticles', () => sim.getParticles({position: new Float32Array(3 * 24)}));
+tryit('getParticles_alive', () => sim.getParticles({alive: new Uint8Array(26)}));
+tryit('getCells', () => sim.getCells(new Int32Array(3)));
+tryit('setRandomState', () => sim.setRandomState({rand: new Float32Array(4 * 24)}));
+// the addon itself, bypassing the shim (first argument = the native handle is private to the shim:
+// reach the same entry points through a second pusher's closure is impossible, so build one here)
+const h = lib.create(1, 1, 12, 10, 2e-9, 5, 1.67e-27, 1.6e-19, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+tryit('addon_readGrid', () => lib.readGrid(h, 2, new Float32Array(12 * 10)));
+tryit('addon_getParticles', () => lib.getParticles(h, new Float32Array(3), null, null, null));
+tryit('addon_getCells', () => lib.getCells(h, new Int32Array(24)));
+tryit('addon_setRandomState', () => lib.setRandomState(h, null, new Float32Array(8)));
+tryit('addon_ok', () => { lib.readGrid(h, 2, new Float32Array(4 * 12 * 10)); lib.getCells(h, new Int32Array(25)); });
+lib.destroy(h);
+tryit('shim_ok', () => { sim.readDensity(new Float32Array(4 * 12 * 10)); sim.getParticles(); sim.getCells(new Int32Array(25)); });
+sim.destroy();
+console.log(JSON.stringify(res));
+"""
+    shim = os.path.join(ROOT, "fusion-sim_amd", "js", "empic_native.js")
+    out = json.loads(subprocess.check_output([node, "-e", script, shim]).decode().strip().splitlines()[-1])
+    for k, v in out.items():
+        if k.endswith("_ok"):
+            assert v == "no error", (k, v)
+        else:
+            assert v.startswith("RangeError: .") and "expected a typed array of" in v, (k, v)
+
+
 def test_c_abi_error_paths(fp, tmp_path):
     """Raw ctypes against the C ABI: every misuse returns a negative status with a message that
     names the offending property, never crashes, and leaves the handle usable."""
@@ -839,7 +885,15 @@ def test_c_abi_error_paths(fp, tmp_path):
     assert b".spec" in lib.fpic_last_error(other._h)
     data = good.read_bytes()
     (tmp_path / "cut.ckp").write_bytes(data[: len(data) // 2])
+    sim.step(); sim.density()                      # binned, fused sums and census live: the state a bad load must not corrupt
+    before = sim.getParticles()
     assert lib.fpic_load_checkpoint(h, str(tmp_path / "cut.ckp").encode()) == -5 and "truncated" in msg()
+    (tmp_path / "cut1.ckp").write_bytes(data[:-1])  # one byte short is refused as well, before anything is overwritten
+    assert lib.fpic_load_checkpoint(h, str(tmp_path / "cut1.ckp").encode()) == -5 and "truncated" in msg()
+    after = sim.getParticles()
+    for k in before:
+        assert same_bits(before[k], after[k]), k
+    sim.step(); sim.density()                      # and the handle keeps running
     # counter mode has no random state to set
     ctr = fp.makeCylindricalParticlePusher(spec, rng="counter", seed=1)
     with pytest.raises(fp.FusionPicError) as e:
