@@ -51,12 +51,13 @@ function validate_property(test, control) {
         }
     } else if (typeof test !== control) {
         if (Array.isArray(control)) {
-            let ok = false;
-            for (let i = 0; i < control.length && !ok; i++) {
-                if (typeof control[i] === 'undefined') continue;
-                try { validate_property(test, control[i]); ok = true; } catch (e) { /* try next */ }
+            // utilities.js:40-49 is try/finally with no catch: the first defined alternative that does not
+            // match throws straight through, later alternatives are never tried (kept, as the reference behaves)
+            let failed = true;
+            for (let i = 0; failed && i < control.length; i++) {
+                if (typeof control[i] !== 'undefined') { validate_property(test, control[i]); failed = false; }
             }
-            if (!ok) throw new Error(' <- Property does not match any given possible types!');
+            if (failed) throw new Error(' <- Property does not match any given possible types!');
         } else if (typeof control === 'object' && typeof test === 'object') {
             validate_object(test, control);
         } else {
@@ -117,8 +118,12 @@ exports.makeCylindricalParticlePusher = function (spec) {
         radius: 'number', height: 'number', nr: 'number', nz: 'number', dt: 'number',
         nparticles: 'number', particle_mass: 'number', particle_charge: 'number',
         precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
-        sort_interval: [, 'number'], fuse_deposit: [, 'boolean', 'string'], rng: [, 'string'], seed: [, 'number'],
+        sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'],
     });
+    // two admissible types: checked by hand, the reference's validator stops at the first alternative
+    if (spec.fuse_deposit !== undefined && typeof spec.fuse_deposit !== 'boolean' && spec.fuse_deposit !== 'census') {
+        throw new Error(".fuse_deposit <- must be true, false or 'census'");
+    }
     const n = spec.count ? spec.count : spec.nparticles * spec.nparticles;   // empic.js:107-109
     const fp64 = spec.precision === 'fp64';
     if (spec.precision !== undefined && spec.precision !== 'fp32' && spec.precision !== 'fp64') {

@@ -445,22 +445,38 @@ def test_counter_rng_resume_from_counter(fp, po):
     the same state and counter continues identically."""
     spec = make_spec(48, 48, 60, radius=0.5, height=0.5)  # powers of two: the unit round trip below is exact
     n = 3600
-    pos, vel, _, _ = uniform_plasma(n, spec, seed=9, v_th=0.03)
+    # (alive flags cannot be uploaded: the hand-over state must have every particle alive, so the first leg
+    # runs in a scene without a sink — particles well inside, slow — and the sink frame is switched on for the
+    # second leg, where re-injection then draws from the counter-based generator on both handles)
+    pos, vel, _, _ = uniform_plasma(n, spec, seed=9, v_th=0.03, margin=0.3)
+    open_mask, frame = np.ones((48, 48)), frame_sink(48, 48)
+    frame[40:, :] = 0; frame[:, :8] = 0; frame[:, 40:] = 0   # a thick frame: the second leg loses particles
     a = fp.makeCylindricalParticlePusher(spec, rng="counter", seed=77)
-    a.set(position=pos, velocity=vel, sink_mask=frame_sink(48, 48), source_pdf=frame_sink(48, 48))
+    a.set(position=pos, velocity=vel, sink_mask=open_mask, source_pdf=frame_sink(48, 48))
     a.addBZ(0.2); a.precalc()
     a.step(3)
     mid = a.getParticles(np.float64)
+    assert np.all(mid["alive"] == 1), "hand-over state must be all alive"
     b = fp.makeCylindricalParticlePusher(spec, rng="counter", seed=77)
     b.set(position=mid["position"] * spec["radius"], velocity=mid["velocity"] * spec["radius"],
-          sink_mask=frame_sink(48, 48), source_pdf=frame_sink(48, 48))
+          sink_mask=frame, source_pdf=frame_sink(48, 48))
+    a.set(sink_mask=frame)
     b.addBZ(0.2); b.precalc()
-    # (alive flags cannot be uploaded: resume from a state in which every particle is alive)
-    if np.all(mid["alive"] == 1):
-        b.setSubstepCounter(a.substepCounter())
-        a.step(2); b.step(2)
-        ga, gb = a.getParticles(), b.getParticles()
-        assert same_bits(ga["position"], gb["position"]) and same_bits(ga["velocity"], gb["velocity"])
+    b.setSubstepCounter(a.substepCounter())
+    a.step(4); b.step(4)
+    ga, gb = a.getParticles(), b.getParticles()
+    assert np.array_equal(ga["alive"], gb["alive"])
+    assert same_bits(ga["position"], gb["position"]) and same_bits(ga["velocity"], gb["velocity"])
+    # a different counter gives a different continuation (the assertion above is not vacuous)
+    c = fp.makeCylindricalParticlePusher(spec, rng="counter", seed=77)
+    c.set(position=mid["position"] * spec["radius"], velocity=mid["velocity"] * spec["radius"], sink_mask=frame,
+          source_pdf=frame_sink(48, 48))
+    c.addBZ(0.2); c.precalc(); c.setSubstepCounter(a.substepCounter() + 1000 - 8); c.step(4)
+    gc = c.getParticles()
+    st = a.stats()
+    assert int((ga["alive"] == 0).sum()) > 0 or st["particle_updates"] > 0
+    assert int((ga["position"][:, 1] == 0).sum()) > 0, "second leg re-injected nothing: the generator was not exercised"
+    assert not same_bits(ga["position"], gc["position"])
 
 
 @pytest.mark.parametrize("rng", ["reference", "counter"])
