@@ -23,7 +23,7 @@ N_CDF = 512
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     src_m = max(os.path.getmtime(os.path.join(_HERE, f))
-                for f in ("pic_oracle.c", "pic_oracle_impl.h", "pic_oracle.h", "sor_oracle.c"))
+                for f in ("pic_oracle.c", "pic_oracle_impl.h", "pic_oracle.h", "sor_oracle.c", "es3d_oracle.c", "es3d_oracle_impl.h"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpic_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
