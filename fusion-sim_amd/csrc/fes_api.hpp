@@ -1,0 +1,24 @@
+// fes_api.hpp — the CART3D electrostatic extension behind the C ABI (fes_api.hip); the entry
+// points of fpic_api.hip forward here when spec.geometry == FPIC_GEOM_CART3D.  Not part of the ABI.
+#pragma once
+
+#include "fpic_handle.hpp"
+
+namespace fes {
+
+int create(fpic_handle* h);
+void release(fpic_handle* h);
+int add_species(fpic_handle* h, double mass, double charge, uint64_t count, int* index);
+int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype);
+int get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype);
+int get_cells(fpic_handle* h, int species, int32_t* cells);
+int add_b(fpic_handle* h, double bx, double by, double bz);
+int set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int nz, int dtype);
+int read_field3(fpic_handle* h, int which, void* out, int dtype);
+int precalc(fpic_handle* h);
+int step(fpic_handle* h, int ncalls);
+int sort(fpic_handle* h);
+int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
+uint64_t particle_count(const fpic_handle* h);
+
+} // namespace fes

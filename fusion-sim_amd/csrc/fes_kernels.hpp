@@ -1,0 +1,562 @@
+// fes_kernels.hpp — CDNA4 (gfx950) kernels of the CART3D electrostatic extension:
+// the self-consistent push + deposit + field-solve cycle of BASELINE.json configs[2..4].
+//
+// No reference counterpart (the reference never feeds its deposit back into the fields,
+// empic.js:1436-1505): PARITY UNPINNED.  The arithmetic is defined
+// by oracle/es3d_oracle_impl.h and followed here operation for operation
+// (-ffp-contract=off), so particles, cell indices and the deposited charge agree with
+// that oracle bit for bit; the FFT solve agrees within a tolerance.  Conventions kept
+// from the reference: positions normalised by the box (empic.js:1199-1244), velocities
+// in units of c, h = q dt / 2m (empic.js:44), step factor dt*c (empic.js:852), node
+// index i + nx*(j + ny*k) with i fastest (empic.js:1162).
+//
+// Device layout
+//   particles : structure of arrays x,y,z,vx,vy,vz (T) + id (u32), one slab per species
+//               and set; 16-byte vector streams, non-temporal; kept binned by 16x16x8-cell tile.
+//   E4        : 4 T per node (Ex, Ey, Ez, phi): one 16-byte (float) gather per CIC tap.
+//   rho_fixed : int64 per node, 2^42 per unit charge number: the deposit is exact and
+//               independent of the order of additions (bit-reproducible, and the sum over
+//               ranks of a decomposed run equals the single-GPU grid exactly).
+//
+// The push workgroup owns one chunk of one tile's particles, stages the tile's field
+// records (+2-cell halo) in LDS, gathers with ds_read_b128, pushes, and adds the NEW
+// position's eight CIC weights into a second LDS window of int64 accumulators
+// (ds_add_u64), flushed once per chunk with 8-byte global atomics: the particle is read
+// once and written once per sub-step (48 B fp32 / 96 B fp64 per update).
+#pragma once
+
+#include "fpic_kernels.hpp"
+
+namespace fes {
+
+using fpic::BlockWork;
+using fpic::load_lane;
+using fpic::store_lane;
+using fpic::NatVec16;
+using fpic::Vec16;
+
+#ifndef FPIC_LDS
+#define FPIC_LDS __attribute__((address_space(3)))
+#endif
+
+constexpr int kTX = 16, kTY = 16, kTZ = 8;       // cells per tile
+constexpr int kHalo = 2;                         // cells staged around a tile
+constexpr int kWX = kTX + 2 * kHalo + 1;         // nodes of the LDS window per axis
+constexpr int kWY = kTY + 2 * kHalo + 1;
+constexpr int kWZ = kTZ + 2 * kHalo + 1;
+constexpr int kWN = kWX * kWY * kWZ;             // 21 * 21 * 13 = 5733 nodes
+constexpr int kPushThreads3 = 512;
+constexpr int kChunk3 = 32768;                   // particles per workgroup and chunk
+constexpr int kMaxTiles3 = 32768;                // LDS histogram limit of the binning passes (256^3 has 8192 tiles)
+constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
+
+template <typename T> __device__ __forceinline__ T floor_(T v);
+template <> __device__ __forceinline__ float floor_<float>(float v) { return floorf(v); }
+template <> __device__ __forceinline__ double floor_<double>(double v) { return floor(v); }
+
+// cell and upper weight of a normalised coordinate (es3d_axis)
+template <typename T>
+__device__ __forceinline__ void axis(T u, int n, int& i, int& w1)
+{
+    const T g = u * static_cast<T>(n);
+    i = static_cast<int>(g);
+    const T f = g - static_cast<T>(i);
+    if (i >= n) i -= n;
+    w1 = (static_cast<int>(f * static_cast<T>(32768)) + 1) >> 1;
+}
+
+template <typename T>
+__device__ __forceinline__ T wrap01(T u)
+{
+    T r = u - floor_(u);
+    if (!(r < static_cast<T>(1))) r = static_cast<T>(0);
+    return r;
+}
+
+template <typename T>
+struct Push3Args {
+    T* slab;                 // x,y,z,vx,vy,vz, each `stride` elements
+    size_t stride;
+    unsigned long long n;
+    const T* E4;             // node records (Ex,Ey,Ez,phi)
+    unsigned long long* rho; // int64 node accumulators (two's complement adds)
+    int nx, ny, nz;
+    T hc, tx, ty, tz, sx, sy, sz, dx, dy, dz;
+    int Z;                   // charge number of the species
+    // tiled form
+    int ntx, nty, ntz;
+    const BlockWork* work;
+    const uint32_t* nwork;
+    unsigned long long* spilled;
+};
+
+template <typename T>
+struct P3 {
+    T x, y, z, vx, vy, vz;
+};
+
+// Where a particle's eight field records come from / its eight weights go to.
+template <typename T>
+struct GlobalGrid {
+    const T* E4;
+    unsigned long long* rho;
+    int nx, ny, nz;
+    __device__ __forceinline__ void gather(int i, int j, int k, const T (&fx)[2], const T (&fy)[2], const T (&fz)[2], T& Ex, T& Ey, T& Ez) const
+    {
+        Ex = Ey = Ez = static_cast<T>(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
+                    T e[4];
+                    fpic::load4(E4 + 4 * (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)), e);
+                    const T w = (fx[a] * fy[b]) * fz[c];
+                    Ex = Ex + w * e[0];
+                    Ey = Ey + w * e[1];
+                    Ez = Ez + w * e[2];
+                }
+    }
+    __device__ __forceinline__ void deposit(int i, int j, int k, const int (&wx)[2], const int (&wy)[2], const int (&wz)[2], int Z) const
+    {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
+                    const long long w = static_cast<long long>(wx[a]) * wy[b] * wz[c] * Z;
+                    if (w) atomicAdd(rho + (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)),
+                                     static_cast<unsigned long long>(w));
+                }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void load4_lds3(const FPIC_LDS T* p, T (&o)[4])
+{
+    using V = typename NatVec16<T>::type;
+    if constexpr (sizeof(T) == 4) {
+        const V v = *reinterpret_cast<const FPIC_LDS V*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+        const V a = *reinterpret_cast<const FPIC_LDS V*>(p);
+        const V b = *reinterpret_cast<const FPIC_LDS V*>(p + 2);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    }
+}
+
+// The tile's window in LDS, global memory behind it for a particle that has left the window.
+template <typename T>
+struct WindowGrid {
+    GlobalGrid<T> g;
+    const FPIC_LDS T* lE;                  // [kWN][4]
+    FPIC_LDS unsigned long long* lrho;     // [kWN]
+    int ox, oy, oz;                        // node of window slot (0,0,0); may be negative (periodic)
+    unsigned* spilled;
+    // window slot of cell (i,j,k), or -1 when one of its eight nodes lies outside
+    __device__ __forceinline__ int slot(int i, int j, int k) const
+    {
+        int l = i - ox, m = j - oy, n = k - oz;
+        if (l < 0) l += g.nx;
+        if (l >= g.nx) l -= g.nx;
+        if (m < 0) m += g.ny;
+        if (m >= g.ny) m -= g.ny;
+        if (n < 0) n += g.nz;
+        if (n >= g.nz) n -= g.nz;
+        const bool in = l <= kWX - 2 && m <= kWY - 2 && n <= kWZ - 2;
+        return in ? (n * kWY + m) * kWX + l : -1;
+    }
+    __device__ __forceinline__ void gather(int i, int j, int k, const T (&fx)[2], const T (&fy)[2], const T (&fz)[2], T& Ex, T& Ey, T& Ez) const
+    {
+        const int s = slot(i, j, k);
+        if (s < 0) { g.gather(i, j, k, fx, fy, fz, Ex, Ey, Ez); return; }
+        Ex = Ey = Ez = static_cast<T>(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    T e[4];
+                    load4_lds3(lE + 4 * (s + a + kWX * b + kWX * kWY * c), e);
+                    const T w = (fx[a] * fy[b]) * fz[c];
+                    Ex = Ex + w * e[0];
+                    Ey = Ey + w * e[1];
+                    Ez = Ez + w * e[2];
+                }
+    }
+    __device__ __forceinline__ void deposit(int i, int j, int k, const int (&wx)[2], const int (&wy)[2], const int (&wz)[2], int Z) const
+    {
+        const int s = slot(i, j, k);
+        if (s < 0) { g.deposit(i, j, k, wx, wy, wz, Z); ++*spilled; return; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const long long w = static_cast<long long>(wx[a]) * wy[b] * wz[c] * Z;
+                    __hip_atomic_fetch_add(lrho + (s + a + kWX * b + kWX * kWY * c), static_cast<unsigned long long>(w), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+    }
+};
+
+// es3d_push for one particle, then the deposit of its new position (es3d_deposit)
+template <typename T, bool HAS_B, typename Grid>
+__device__ __forceinline__ void substep3(P3<T>& q, const Push3Args<T>& a, const Grid& grid, int& ni, int& nj, int& nk)
+{
+    const T q14 = static_cast<T>(1.0 / 16384.0);
+    int i, j, k, w1;
+    T fx[2], fy[2], fz[2];
+    axis(q.x, a.nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14;
+    axis(q.y, a.ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14;
+    axis(q.z, a.nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14;
+    T Ex, Ey, Ez;
+    grid.gather(i, j, k, fx, fy, fz, Ex, Ey, Ez);
+    const T ax = a.hc * Ex, ay = a.hc * Ey, az = a.hc * Ez;
+    T ux = q.vx + ax, uy = q.vy + ay, uz = q.vz + az;
+    if constexpr (HAS_B) {
+        const T px = ux + (uy * a.tz - uz * a.ty);
+        const T py = uy + (uz * a.tx - ux * a.tz);
+        const T pz = uz + (ux * a.ty - uy * a.tx);
+        const T qx = ux + (py * a.sz - pz * a.sy);
+        const T qy = uy + (pz * a.sx - px * a.sz);
+        const T qz = uz + (px * a.sy - py * a.sx);
+        ux = qx; uy = qy; uz = qz;
+    }
+    q.vx = ux + ax; q.vy = uy + ay; q.vz = uz + az;
+    q.x = wrap01(q.x + a.dx * q.vx);
+    q.y = wrap01(q.y + a.dy * q.vy);
+    q.z = wrap01(q.z + a.dz * q.vz);
+    int wx[2], wy[2], wz[2];
+    axis(q.x, a.nx, ni, wx[1]); wx[0] = 16384 - wx[1];
+    axis(q.y, a.ny, nj, wy[1]); wy[0] = 16384 - wy[1];
+    axis(q.z, a.nz, nk, wz[1]); wz[0] = 16384 - wz[1];
+    grid.deposit(ni, nj, nk, wx, wy, wz, a.Z);
+}
+
+template <typename T>
+__device__ __forceinline__ void load_state3(const Push3Args<T>& a, size_t base, int cnt, P3<T> (&q)[Vec16<T>::N])
+{
+    constexpr int PPT = Vec16<T>::N;
+    T v[6][PPT];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        q[k].x = v[0][k]; q[k].y = v[1][k]; q[k].z = v[2][k];
+        q[k].vx = v[3][k]; q[k].vy = v[4][k]; q[k].vz = v[5][k];
+        if (k >= cnt) { q[k].x = q[k].y = q[k].z = static_cast<T>(0.5); q[k].vx = q[k].vy = q[k].vz = static_cast<T>(0); }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_state3(const Push3Args<T>& a, size_t base, int cnt, const P3<T> (&q)[Vec16<T>::N])
+{
+    constexpr int PPT = Vec16<T>::N;
+    T v[6][PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        v[0][k] = q[k].x; v[1][k] = q[k].y; v[2][k] = q[k].z;
+        v[3][k] = q[k].vx; v[4][k] = q[k].vy; v[5][k] = q[k].vz;
+    }
+    if (cnt == PPT) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) store_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (k < cnt) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) a.slab[f * a.stride + base + k] = v[f][k];
+            }
+    }
+}
+
+__device__ __forceinline__ uint32_t tile_key3(int i, int j, int k, int ntx, int nty)
+{
+    return static_cast<uint32_t>(i / kTX) + static_cast<uint32_t>(ntx) * (static_cast<uint32_t>(j / kTY) + static_cast<uint32_t>(nty) * static_cast<uint32_t>(k / kTZ));
+}
+
+// Flat form: any particle order, everything through global memory (L2 gathers, 8-byte global
+// atomics).  Used until the particles have been binned.  DEPOSIT_ONLY: no push, the deposit of
+// the CURRENT positions (precalc()).
+template <typename T, bool HAS_B, bool DEPOSIT_ONLY>
+__global__ __launch_bounds__(256) void push3_flat_kernel(Push3Args<T> a)
+{
+    constexpr int PPT = Vec16<T>::N;
+    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
+    if (base >= a.n) return;
+    const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+    const GlobalGrid<T> grid{ a.E4, a.rho, a.nx, a.ny, a.nz };
+    P3<T> q[PPT];
+    load_state3(a, base, cnt, q);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        if (k >= cnt) continue;
+        int ni, nj, nk;
+        if constexpr (DEPOSIT_ONLY) {
+            int wx[2], wy[2], wz[2];
+            axis(q[k].x, a.nx, ni, wx[1]); wx[0] = 16384 - wx[1];
+            axis(q[k].y, a.ny, nj, wy[1]); wy[0] = 16384 - wy[1];
+            axis(q[k].z, a.nz, nk, wz[1]); wz[0] = 16384 - wz[1];
+            grid.deposit(ni, nj, nk, wx, wy, wz, a.Z);
+        } else {
+            substep3<T, HAS_B>(q[k], a, grid, ni, nj, nk);
+        }
+    }
+    if constexpr (!DEPOSIT_ONLY) store_state3(a, base, cnt, q);
+}
+
+template <typename T>
+constexpr size_t push3_lds_bytes() { return static_cast<size_t>(kWN) * (4 * sizeof(T) + 8) + 16; }
+
+// Tiled form for binned particles: one workgroup per chunk of one tile's particles.
+template <typename T, bool HAS_B, bool DEPOSIT_ONLY>
+__global__ __launch_bounds__(kPushThreads3) void push3_tiles_kernel(Push3Args<T> a)
+{
+    constexpr int PPT = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    FPIC_LDS T* lE = (FPIC_LDS T*)lds3;
+    FPIC_LDS unsigned long long* lrho = (FPIC_LDS unsigned long long*)((FPIC_LDS unsigned char*)lds3 + static_cast<size_t>(kWN) * 4 * sizeof(T));
+    if (blockIdx.x >= *a.nwork) return;
+    const BlockWork w = a.work[blockIdx.x];
+    const int ti = static_cast<int>(w.tile % a.ntx), tj = static_cast<int>((w.tile / a.ntx) % a.nty), tk = static_cast<int>(w.tile / (a.ntx * a.nty));
+    const int ox = ti * kTX - kHalo, oy = tj * kTY - kHalo, oz = tk * kTZ - kHalo;
+    // stage the window: one node record (16 B float / 32 B double) per lane and iteration
+    using V = typename NatVec16<T>::type;
+    constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
+    for (int s = threadIdx.x; s < kWN; s += kPushThreads3) {
+        const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
+        const int m = rem / kWX, l = rem - m * kWX;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        if (gi < 0) gi += a.nx;
+        if (gj < 0) gj += a.ny;
+        if (gk < 0) gk += a.nz;
+        lrho[s] = 0ull;
+        if constexpr (!DEPOSIT_ONLY) {
+            const T* src = a.E4 + 4 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk));
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p)
+                *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(src + p * Vec16<T>::N);
+        }
+    }
+    __syncthreads();
+    unsigned my_spill = 0;
+    const WindowGrid<T> grid{ GlobalGrid<T>{ a.E4, a.rho, a.nx, a.ny, a.nz }, lE, lrho, ox, oy, oz, &my_spill };
+    const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
+    const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
+    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads3) {
+        const size_t base = g * PPT;
+        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+        P3<T> q[PPT];
+        load_state3(a, base, cnt, q);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (k >= cnt) continue;
+            int ni, nj, nk;
+            if constexpr (DEPOSIT_ONLY) {
+                int wx[2], wy[2], wz[2];
+                axis(q[k].x, a.nx, ni, wx[1]); wx[0] = 16384 - wx[1];
+                axis(q[k].y, a.ny, nj, wy[1]); wy[0] = 16384 - wy[1];
+                axis(q[k].z, a.nz, nk, wz[1]); wz[0] = 16384 - wz[1];
+                grid.deposit(ni, nj, nk, wx, wy, wz, a.Z);
+            } else {
+                substep3<T, HAS_B>(q[k], a, grid, ni, nj, nk);
+            }
+        }
+        if constexpr (!DEPOSIT_ONLY) store_state3(a, base, cnt, q);
+    }
+    __syncthreads();
+    // flush the non-zero accumulators: consecutive lanes take consecutive slots of one window row
+    for (int s = threadIdx.x; s < kWN; s += kPushThreads3) {
+        const unsigned long long v = lrho[s];
+        if (v == 0ull) continue;
+        const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
+        const int m = rem / kWX, l = rem - m * kWX;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        if (gi < 0) gi += a.nx;
+        if (gj < 0) gj += a.ny;
+        if (gk < 0) gk += a.nz;
+        atomicAdd(a.rho + (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)), v);
+    }
+    if (my_spill) atomicAdd(a.spilled, static_cast<unsigned long long>(my_spill));
+}
+
+// ------------------------------------------------------------------ field solve
+
+// rho[node] = (T)((double)fixed * scale)   (es3d_rho_real)
+template <typename T>
+__global__ __launch_bounds__(256) void rho_real_kernel(const long long* __restrict__ fixed, size_t nodes, double scale, T* __restrict__ rho)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < nodes) rho[c] = static_cast<T>(static_cast<double>(fixed[c]) * scale);
+}
+
+// phi_hat = rho_hat / (eps0 K^2 N) on the half spectrum of the real transform ((nx/2+1) x ny x nz,
+// interleaved complex); k2x/k2y/k2z are the per-axis eigenvalue tables in double; the mean mode is 0
+template <typename T>
+__global__ __launch_bounds__(256) void kspace_kernel(T* __restrict__ hat, int nxh, int ny, int nz, const double* __restrict__ k2x,
+                                                     const double* __restrict__ k2y, const double* __restrict__ k2z, double inv_eps0_n)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nxh) * ny * nz) return;
+    const int i = static_cast<int>(c % nxh);
+    const int j = static_cast<int>((c / nxh) % ny);
+    const int k = static_cast<int>(c / (static_cast<size_t>(nxh) * ny));
+    const double K2 = (k2x[i] + k2y[j]) + k2z[k];
+    const T g = (i | j | k) ? static_cast<T>(inv_eps0_n / K2) : static_cast<T>(0);
+    hat[2 * c] = hat[2 * c] * g;
+    hat[2 * c + 1] = hat[2 * c + 1] * g;
+}
+
+// node records (Ex,Ey,Ez,phi) from phi by central differences, periodic (es3d_gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void gradient_kernel(const T* __restrict__ phi, int nx, int ny, int nz, T hx, T hy, T hz, T* __restrict__ E4)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
+    if (c >= sz * nz) return;
+    const int i = static_cast<int>(c % nx);
+    const int j = static_cast<int>((c / nx) % ny);
+    const int k = static_cast<int>(c / sz);
+    const int im = i ? i - 1 : nx - 1, ip = (i + 1 == nx) ? 0 : i + 1;
+    const int jm = j ? j - 1 : ny - 1, jp = (j + 1 == ny) ? 0 : j + 1;
+    const int km = k ? k - 1 : nz - 1, kp = (k + 1 == nz) ? 0 : k + 1;
+    using V = typename NatVec16<T>::type;
+    T o[4];
+    o[0] = (phi[im + sy * j + sz * k] - phi[ip + sy * j + sz * k]) * hx;
+    o[1] = (phi[i + sy * jm + sz * k] - phi[i + sy * jp + sz * k]) * hy;
+    o[2] = (phi[i + sy * j + sz * km] - phi[i + sy * j + sz * kp]) * hz;
+    o[3] = phi[c];
+    if constexpr (sizeof(T) == 4) {
+        V v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+        *reinterpret_cast<V*>(E4 + 4 * c) = v;
+    } else {
+        V v0, v1; v0.x = o[0]; v0.y = o[1]; v1.x = o[2]; v1.y = o[3];
+        *reinterpret_cast<V*>(E4 + 4 * c) = v0;
+        *reinterpret_cast<V*>(E4 + 4 * c + 2) = v1;
+    }
+}
+
+// ------------------------------------------------------------------ uploads, read-back, binning
+
+// out.set({position}) for the box: u = (T)(x * (1/L)) wrapped into [0,1) (es3d_normalise)
+template <typename T, typename In>
+__global__ __launch_bounds__(256) void set_pos3_kernel(const In* __restrict__ aos, size_t chunk_begin, size_t chunk_n, double fx, double fy, double fz,
+                                                       T* x, T* y, T* z, const uint32_t* __restrict__ id, size_t n)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t i = id[s];
+    if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
+    const In* v = aos + 3 * (i - chunk_begin);
+    x[s] = wrap01(static_cast<T>(static_cast<double>(v[0]) * fx));
+    y[s] = wrap01(static_cast<T>(static_cast<double>(v[1]) * fy));
+    z[s] = wrap01(static_cast<T>(static_cast<double>(v[2]) * fz));
+}
+
+// out.set({E}) for the box: value[i][j][k][c] -> node record i + nx*(j + ny*k), phi = 0
+template <typename T, typename In>
+__global__ __launch_bounds__(256) void pack_field3_kernel(const In* __restrict__ in, int nx, int ny, int nz, T* __restrict__ E4)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nx) * ny * nz) return;
+    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / (static_cast<size_t>(nx) * ny));
+    const In* v = in + 3 * ((static_cast<size_t>(i) * ny + j) * nz + k);
+    E4[4 * c] = static_cast<T>(v[0]); E4[4 * c + 1] = static_cast<T>(v[1]); E4[4 * c + 2] = static_cast<T>(v[2]); E4[4 * c + 3] = static_cast<T>(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cells3_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
+                                                     const uint32_t* __restrict__ id, size_t n, size_t chunk_begin, size_t chunk_n, int nx, int ny,
+                                                     int nz, int32_t* __restrict__ cells)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t p = id[s];
+    if (p < chunk_begin || p >= chunk_begin + chunk_n) return;
+    int i, j, k, w;
+    axis(x[s], nx, i, w); axis(y[s], ny, j, w); axis(z[s], nz, k, w);
+    cells[p - chunk_begin] = i + nx * (j + ny * k);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void init3_kernel(T* slab, size_t stride, uint32_t* id)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= stride) return;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) slab[f * stride + i] = static_cast<T>(0);
+    id[i] = static_cast<uint32_t>(i);
+}
+
+template <typename T>
+__device__ __forceinline__ uint32_t key_of(T x, T y, T z, int nx, int ny, int nz, int ntx, int nty)
+{
+    int i, j, k, w;
+    axis(x, nx, i, w); axis(y, ny, j, w); axis(z, nz, k, w);
+    return tile_key3(i, j, k, ntx, nty);
+}
+
+constexpr int kBinPer3 = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ slab, size_t stride, size_t n, int nx, int ny, int nz, int ntx, int nty,
+                                                         uint32_t ntiles, uint32_t* __restrict__ tile_count)
+{
+    extern __shared__ uint32_t hist3[];
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) hist3[t] = 0;
+    __syncthreads();
+    const size_t base = static_cast<size_t>(blockIdx.x) * (256 * kBinPer3);
+    for (int k = 0; k < kBinPer3; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&hist3[key_of(slab[i], slab[stride + i], slab[2 * stride + i], nx, ny, nz, ntx, nty)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256)
+        if (hist3[t]) atomicAdd(&tile_count[t], hist3[t]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t stride, const uint32_t* __restrict__ src_id,
+                                                           uint32_t* __restrict__ dst_id, size_t n, int nx, int ny, int nz, int ntx, int nty,
+                                                           uint32_t ntiles, const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor)
+{
+    extern __shared__ uint32_t hist3[];
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) hist3[t] = 0;
+    __syncthreads();
+    const size_t base = static_cast<size_t>(blockIdx.x) * (256 * kBinPer3);
+    uint32_t key[kBinPer3], rank[kBinPer3];
+#pragma unroll
+    for (int k = 0; k < kBinPer3; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
+        key[k] = 0; rank[k] = 0;
+        if (i < n) {
+            key[k] = key_of(src[i], src[stride + i], src[2 * stride + i], nx, ny, nz, ntx, nty);
+            rank[k] = atomicAdd(&hist3[key[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) {
+        const uint32_t c = hist3[t];
+        if (c) hist3[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBinPer3; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const size_t d = static_cast<size_t>(hist3[key[k]]) + rank[k];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) dst[f * stride + d] = src[f * stride + i];
+        dst_id[d] = src_id[i];
+    }
+}
+
+} // namespace fes

@@ -4,9 +4,11 @@
 //
 // There is no CPU fallback in this file or anywhere in the library: a handle
 // cannot be created without a gfx950 device.
+#include "fpic_handle.hpp"
 #include "fpic_kernels.hpp"
 #include "fpic_push.hpp"
 #include "fpic_injection.hpp"
+#include "fes_api.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -19,129 +21,15 @@
 
 using namespace fpic;
 
-namespace {
-
-enum KernelClass { KC_PUSH = 0, KC_DEPOSIT, KC_STAMP, KC_PRECALC, KC_SORT, KC_COUNT };
-
-struct PendingTiming {
-    hipEvent_t a, b;
-    int cls;
-};
-
-thread_local std::string g_create_error;
-
-} // namespace
-
-struct fpic_handle {
-    fpic_spec spec{};
-    Constants k{};
-    int prec = FPIC_F32;
-    int device = 0;
-    size_t n = 0, n_pad = 0;
-    int nr = 0, nz = 0;
-    size_t ncell = 0;
-    size_t esize = 4;
-
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    std::string err;
-
-    // particle state, two sets (binning is out of place), cur selects the live one;
-    // the ten arrays of a set are consecutive pieces of one slab, n_pad elements each
-    void* slab[2] = {};
-    void* part[2][10] = {};
-    uint8_t* alive[2] = {};
-    uint32_t* id[2] = {};
-    int cur = 0;
-
-    // grid state
-    void* E = nullptr;
-    void* B = nullptr;
-    void* sink = nullptr;
-    uint8_t* sink_alive = nullptr;
-    void* inv_cdf_xy = nullptr;
-    void* entropy = nullptr;
-    void* coef = nullptr;
-    void* cell_sums = nullptr;
-    void* moments = nullptr;
-    void* norm = nullptr;
-    void* avg = nullptr;
-    float* stamp = nullptr;
-    void* shape_half = nullptr;
-    void* shape_tenth = nullptr;
-    bool shapes_ready = false;
-
-    // binning by cell tile
-    int ntx = 0, ntz = 0;
-    uint32_t ntiles = 0; // real tiles + 1 bin for clipped particles
-    uint32_t* tile_count = nullptr;
-    // two bin tables: [wl] describes the live particle order, [wl ^ 1] is laid out by the
-    // next binning (which may be the next push, see scatter_pending)
-    uint32_t* tile_start2[2] = {};
-    uint32_t* nwork2[2] = {};
-    BlockWork* work2[2] = {};
-    int wl = 0;
-    uint32_t* tile_cursor = nullptr;
-    size_t work_cap = 0;
-    bool binned = false;
-    int deposits_since_bin = 0;
-    unsigned long long t_substep = 0; // counter-based RNG mode: global index of the next sub-step
-    bool sums_fresh = false;      // cell_sums already holds the sums of the current particle state (fused push)
-    bool census_fresh = false;    // tile_count holds the census of the current particle state (fused push)
-    bool scatter_pending = false; // tables [wl ^ 1] are laid out from that census: the next push re-bins
-    // Particles that missed their LDS tile in a scatter, read back with a lag of two
-    // scatters so that the host may run ahead of the GPU by at most two frames.
-    unsigned long long* spilled = nullptr;      // device counter
-    unsigned long long* spilled_host = nullptr; // pinned, kSpillSlots entries
-    hipEvent_t spill_event[2] = {};
-    // fpic_density_finish_from on a caller's stream: the grids it writes (moments, norm, avg) are
-    // ordered against this handle's own stream through this event
-    hipEvent_t finish_event = nullptr;
-    hipEvent_t order_event = nullptr; // "everything queued on the handle's stream so far", for a caller's stream to wait on
-    bool finish_pending = false;
-    bool spill_pending[2] = {};
-    unsigned long long deposit_seq = 0;
-    unsigned long long last_spill = 0;
-
-    // statistics
-    bool profiling = false;
-    std::vector<PendingTiming> pending;
-    std::vector<hipEvent_t> event_pool;
-    double ms[KC_COUNT] = {};
-    uint64_t particle_updates = 0, step_launches = 0, deposit_launches = 0, sort_passes = 0;
-    uint64_t bytes_particles = 0, bytes_grid = 0;
-};
-
-namespace {
-
-int fail(fpic_handle* h, int code, const char* fmt, ...)
+namespace fpic {
+std::string& create_error()
 {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    std::vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (h) h->err = buf;
-    else g_create_error = buf;
-    return code;
+    thread_local std::string text;
+    return text;
 }
+} // namespace fpic
 
-#define HIP_TRY(h, expr)                                                                                      \
-    do {                                                                                                      \
-        hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess)                                                                                 \
-            return fail(h, e_ == hipErrorOutOfMemory ? FPIC_ERR_OOM : FPIC_ERR_HIP, "%s failed: %s", #expr,   \
-                        hipGetErrorString(e_));                                                               \
-    } while (0)
-
-#define CHECK_HANDLE(h)                                                                                       \
-    do {                                                                                                      \
-        if (!(h)) return fail(nullptr, FPIC_ERR_INVALID_ARG, "null handle");                                  \
-        hipError_t e_ = hipSetDevice((h)->device);                                                            \
-        if (e_ != hipSuccess) return fail(h, FPIC_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e_)); \
-    } while (0)
-
-inline unsigned blocks_for(size_t n, unsigned per = 256) { return static_cast<unsigned>((n + per - 1) / per); }
+namespace {
 
 template <typename T>
 ParticleArrays<T> arrays(fpic_handle* h, int which)
@@ -154,47 +42,6 @@ ParticleArrays<T> arrays(fpic_handle* h, int which)
     p.alive = h->alive[which];
     p.id = h->id[which];
     return p;
-}
-
-int dev_alloc(fpic_handle* h, void** p, size_t bytes, uint64_t* account)
-{
-    HIP_TRY(h, hipMalloc(p, bytes ? bytes : 16));
-    HIP_TRY(h, hipMemsetAsync(*p, 0, bytes ? bytes : 16, h->stream));
-    if (account) *account += bytes;
-    return FPIC_OK;
-}
-
-void timing_begin(fpic_handle* h, int cls)
-{
-    if (!h->profiling) return;
-    PendingTiming t;
-    t.cls = cls;
-    for (hipEvent_t* e : { &t.a, &t.b }) {
-        if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); }
-        else (void)hipEventCreate(e);
-    }
-    (void)hipEventRecord(t.a, h->stream);
-    h->pending.push_back(t);
-}
-
-void timing_collect(fpic_handle* h)
-{
-    if (h->pending.empty()) return;
-    (void)hipStreamSynchronize(h->stream);
-    for (PendingTiming& t : h->pending) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) h->ms[t.cls] += ms;
-        h->event_pool.push_back(t.a);
-        h->event_pool.push_back(t.b);
-    }
-    h->pending.clear();
-}
-
-void timing_end(fpic_handle* h)
-{
-    if (!h->profiling) return;
-    (void)hipEventRecord(h->pending.back().b, h->stream);
-    if (h->pending.size() > 2048) timing_collect(h);
 }
 
 // counter-based RNG mode: the random vector of caller's particle i at sub-step t
@@ -671,6 +518,7 @@ void release(fpic_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    fes::release(h);
     for (int s = 0; s < 2; ++s) {
         if (h->slab[s]) (void)hipFree(h->slab[s]);
         if (h->alive[s]) (void)hipFree(h->alive[s]);
@@ -890,6 +738,7 @@ int validate_spec(const fpic_spec* s)
     if (s->precision != FPIC_F32 && s->precision != FPIC_F64) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".precision <- must be 0 (f32) or 1 (f64)");
     if (s->rng_mode != 0 && s->rng_mode != 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".rng_mode <- must be 0 (reference) or 1 (counter)");
     if (s->unfused_deposit < 0 || s->unfused_deposit > 2) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".unfused_deposit <- must be 0, 1 or 2");
+    if (s->geometry != FPIC_GEOM_CYL_RZ && s->geometry != FPIC_GEOM_CART3D) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".geometry <- must be 0 (cyl_rz) or 1 (cart3d)");
     return FPIC_OK;
 }
 
@@ -897,9 +746,19 @@ int validate_spec(const fpic_spec* s)
 
 // =============================================================================== ABI
 
+// calls that exist only on the reference's (r,z) pusher / only on the CART3D box
+#define RZ_ONLY(h, name)                                                                                            \
+    do {                                                                                                            \
+        if ((h)->es) return fail(h, FPIC_ERR_STATE, name " is not available on a CART3D handle (spec.geometry = 1)"); \
+    } while (0)
+#define BOX_ONLY(h, name)                                                                                           \
+    do {                                                                                                            \
+        if (!(h)->es) return fail(h, FPIC_ERR_STATE, name " needs a CART3D handle (spec.geometry = 1)");            \
+    } while (0)
+
 extern "C" {
 
-const char* fpic_last_error(const fpic_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* fpic_last_error(const fpic_handle* h) { return h ? h->err.c_str() : create_error().c_str(); }
 int fpic_abi_version(void) { return FPIC_ABI_VERSION; }
 const char* fpic_build_arch(void) { return "gfx950"; }
 
@@ -939,15 +798,21 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     h->ntiles = static_cast<uint32_t>(h->ntx) * h->ntz + 1;
     int rc = FPIC_OK;
     if (h->n >= 0xFFFFFFFFull - 4096) rc = fail(nullptr, FPIC_ERR_INVALID_ARG, ".nparticles <- at most 2^32 particles per device");
-    else if (h->ntiles > static_cast<uint32_t>(kMaxTiles)) rc = fail(nullptr, FPIC_ERR_INVALID_ARG, ".nr <- grid of %d x %d cells exceeds %d tiles of %d^2 cells", h->nr, h->nz, kMaxTiles, kTileSide);
+    else if (spec->geometry == FPIC_GEOM_CYL_RZ && h->ntiles > static_cast<uint32_t>(kMaxTiles)) rc = fail(nullptr, FPIC_ERR_INVALID_ARG, ".nr <- grid of %d x %d cells exceeds %d tiles of %d^2 cells", h->nr, h->nz, kMaxTiles, kTileSide);
     if (rc) { delete h; return rc; }
 
-    auto bail = [&](int code) { g_create_error = h->err; release(h); return code; };
+    auto bail = [&](int code) { create_error() = h->err; release(h); return code; };
     if (hipSetDevice(h->device) != hipSuccess) return bail(fail(h, FPIC_ERR_HIP, "hipSetDevice failed"));
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return bail(fail(h, FPIC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)));
     h->stream = h->own_stream;
 
+    if (spec->geometry == FPIC_GEOM_CART3D) { // the electrostatic box: its own state and kernels (fes_api.hip)
+        if ((rc = fes::create(h))) return bail(rc);
+        if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(fail(h, FPIC_ERR_HIP, "handle setup failed: %s", hipGetErrorString(e)));
+        *out = h;
+        return FPIC_OK;
+    }
     rc = (h->prec == FPIC_F32) ? create_state<float>(h) : create_state<double>(h);
     if (rc) return bail(rc);
     // the scatter's LDS image (72 KiB of double accumulators) exceeds the 64 KiB static limit
@@ -1005,6 +870,7 @@ int fpic_destroy(fpic_handle* h)
 int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype)
 {
     CHECK_HANDLE(h);
+    if (h->es) return fes::set_particles(h, 0, pos_aos, vel_aos, n, dtype);
     if (n != h->n) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- expected %zu particles, got %llu", h->n, static_cast<unsigned long long>(n));
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
     const double fr = h->k.factor_r, fz = h->k.factor_z;
@@ -1032,6 +898,7 @@ int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos,
 int fpic_set_grid(fpic_handle* h, int which, const void* data, int nr, int nz, int ncomp, int dtype)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_set_grid");
     if (!data) return fail(h, FPIC_ERR_INVALID_ARG, ".data <- Non-optional property is undefined!");
     if (nr != h->nr || nz != h->nz) return fail(h, FPIC_ERR_INVALID_ARG, ".grid <- expected %d x %d, got %d x %d", h->nr, h->nz, nr, nz);
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
@@ -1054,6 +921,7 @@ int fpic_set_grid(fpic_handle* h, int which, const void* data, int nr, int nz, i
 int fpic_set_random_state(fpic_handle* h, const float* entropy, const float* rand)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_set_random_state");
     if (h->spec.rng_mode == 1 && (entropy || rand))
         return fail(h, FPIC_ERR_STATE, ".rng_mode <- the counter-based generator has no entropy table or per-particle state; use rng_seed and fpic_set_substep_counter");
     if (entropy) {
@@ -1075,27 +943,32 @@ int fpic_set_random_state(fpic_handle* h, const float* entropy, const float* ran
 int fpic_add_current_loop(fpic_handle* h, double r, double z, double current)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_add_current_loop");
     return h->prec == FPIC_F32 ? paint_loop<float>(h, r, z, current) : paint_loop<double>(h, r, z, current);
 }
 int fpic_add_current_z(fpic_handle* h, double current)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_add_current_z");
     return h->prec == FPIC_F32 ? paint_uniform<float>(h, 0, current) : paint_uniform<double>(h, 0, current);
 }
 int fpic_add_bz(fpic_handle* h, double bz)
 {
     CHECK_HANDLE(h);
+    if (h->es) return fes::add_b(h, 0.0, 0.0, bz);
     return h->prec == FPIC_F32 ? paint_uniform<float>(h, 1, bz) : paint_uniform<double>(h, 1, bz);
 }
 int fpic_add_btheta(fpic_handle* h, double btheta)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_add_btheta");
     return h->prec == FPIC_F32 ? paint_uniform<float>(h, 2, btheta) : paint_uniform<double>(h, 2, btheta);
 }
 
 int fpic_precalc(fpic_handle* h)
 {
     CHECK_HANDLE(h);
+    if (h->es) return fes::precalc(h);
     return h->prec == FPIC_F32 ? launch_precalc<float>(h) : launch_precalc<double>(h);
 }
 
@@ -1105,6 +978,7 @@ int fpic_step(fpic_handle* h, int ncalls)
     if (ncalls < 0) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- must be >= 0");
     if (ncalls == 0) return FPIC_OK;
     if (ncalls > (1 << 29)) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- too large");
+    if (h->es) return fes::step(h, ncalls);
     const int rc = h->prec == FPIC_F32 ? launch_push<float>(h, 2 * ncalls) : launch_push<double>(h, 2 * ncalls);
     if (rc == FPIC_OK) {
         h->step_launches++;
@@ -1130,12 +1004,14 @@ int fpic_set_substep_counter(fpic_handle* h, uint64_t t)
 int fpic_sort(fpic_handle* h)
 {
     CHECK_HANDLE(h);
+    if (h->es) return fes::sort(h);
     return h->prec == FPIC_F32 ? launch_bin<float>(h) : launch_bin<double>(h);
 }
 
 int fpic_deposit(fpic_handle* h)
 {
     CHECK_HANDLE(h);
+    if (h->es) return FPIC_OK; // the charge density of the current positions is always at hand
     bool rebin = !h->binned;
     if (!rebin) {
         if (h->spec.sort_interval > 0) {
@@ -1178,12 +1054,14 @@ int fpic_deposit(fpic_handle* h)
 int fpic_density_finish(fpic_handle* h)
 {
     CHECK_HANDLE(h);
+    if (h->es) return FPIC_OK;
     return h->prec == FPIC_F32 ? launch_stamp_finish<float>(h) : launch_stamp_finish<double>(h);
 }
 
 int fpic_density_finish_from(fpic_handle* h, const void* sums, void* hip_stream)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_density_finish_from");
     if (!sums) return fail(h, FPIC_ERR_INVALID_ARG, ".sums <- Non-optional property is undefined!");
     hipStream_t on = static_cast<hipStream_t>(hip_stream);
     return h->prec == FPIC_F32 ? launch_stamp_finish<float>(h, sums, on) : launch_stamp_finish<double>(h, sums, on);
@@ -1198,6 +1076,7 @@ int fpic_density(fpic_handle* h)
 int fpic_read_grid(fpic_handle* h, int which, void* out, int dtype)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_read_grid");
     if (int rc = wait_external_finish(h)) return rc;
     if (!out) return fail(h, FPIC_ERR_INVALID_ARG, ".out <- Non-optional property is undefined!");
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
@@ -1212,6 +1091,11 @@ int fpic_get_particles(fpic_handle* h, void* pos_aos, void* vel_aos, float* rand
 {
     CHECK_HANDLE(h);
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
+    if (h->es) { // the periodic box loses no particle and keeps no random state
+        if (rand) std::memset(rand, 0, sizeof(float) * 4 * h->n);
+        if (alive) std::memset(alive, 1, h->n);
+        return fes::get_particles(h, 0, pos_aos, vel_aos, dtype);
+    }
     int rc = FPIC_OK;
     for (int pass = 0; pass < 2 && rc == FPIC_OK; ++pass) {
         void* dst = pass == 0 ? pos_aos : vel_aos;
@@ -1232,6 +1116,7 @@ int fpic_get_particles(fpic_handle* h, void* pos_aos, void* vel_aos, float* rand
 int fpic_get_cells(fpic_handle* h, int32_t* cells)
 {
     CHECK_HANDLE(h);
+    if (h->es) return fes::get_cells(h, 0, cells);
     if (!cells) return fail(h, FPIC_ERR_INVALID_ARG, ".cells <- Non-optional property is undefined!");
     return h->prec == FPIC_F32 ? download_misc<float>(h, nullptr, nullptr, cells) : download_misc<double>(h, nullptr, nullptr, cells);
 }
@@ -1239,6 +1124,7 @@ int fpic_get_cells(fpic_handle* h, int32_t* cells)
 int fpic_device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes)
 {
     CHECK_HANDLE(h);
+    if (h->es) return fes::device_buffer(h, which, dptr, bytes);
     if (which != FPIC_BUF_CELL_SUMS) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown buffer %d", which);
     if (dptr) *dptr = h->cell_sums;
     if (bytes) *bytes = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1) * 4 * h->esize;
@@ -1264,6 +1150,7 @@ int fpic_get_stream(fpic_handle* h, void** hip_stream)
 int fpic_save_checkpoint(fpic_handle* h, const char* path)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_save_checkpoint");
     if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
     if (int rc = wait_external_finish(h)) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1280,6 +1167,7 @@ int fpic_save_checkpoint(fpic_handle* h, const char* path)
 int fpic_load_checkpoint(fpic_handle* h, const char* path)
 {
     CHECK_HANDLE(h);
+    RZ_ONLY(h, "fpic_load_checkpoint");
     if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
     if (int rc = wait_external_finish(h)) return rc;
     FileCloser fc{ std::fopen(path, "rb") };
@@ -1320,6 +1208,50 @@ int fpic_load_checkpoint(fpic_handle* h, const char* path)
     return FPIC_OK;
 }
 
+// ---- CART3D extension entry points
+int fpic_add_species(fpic_handle* h, double mass, double charge, uint64_t count, int* index)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_add_species");
+    return fes::add_species(h, mass, charge, count, index);
+}
+int fpic_set_particles_of(fpic_handle* h, int species, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_set_particles_of");
+    return fes::set_particles(h, species, pos_aos, vel_aos, n, dtype);
+}
+int fpic_get_particles_of(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_get_particles_of");
+    return fes::get_particles(h, species, pos_aos, vel_aos, dtype);
+}
+int fpic_get_cells_of(fpic_handle* h, int species, int32_t* cells)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_get_cells_of");
+    return fes::get_cells(h, species, cells);
+}
+int fpic_add_b(fpic_handle* h, double bx, double by, double bz)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_add_b");
+    return fes::add_b(h, bx, by, bz);
+}
+int fpic_set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int nz, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_set_field3");
+    return fes::set_field3(h, which, data, nx, ny, nz, dtype);
+}
+int fpic_read_field3(fpic_handle* h, int which, void* out, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_read_field3");
+    return fes::read_field3(h, which, out, dtype);
+}
+
 int fpic_sync(fpic_handle* h)
 {
     CHECK_HANDLE(h);
@@ -1347,7 +1279,7 @@ int fpic_get_stats(fpic_handle* h, fpic_stats* out)
         if (h->spill_pending[newest]) h->last_spill = h->spilled_host[newest];
     }
     std::memset(out, 0, sizeof *out);
-    out->n_particles = h->n;
+    out->n_particles = h->es ? fes::particle_count(h) : h->n;
     out->particle_updates = h->particle_updates;
     out->step_launches = h->step_launches;
     out->deposit_launches = h->deposit_launches;
@@ -1358,6 +1290,8 @@ int fpic_get_stats(fpic_handle* h, fpic_stats* out)
     out->ms_stamp = h->ms[KC_STAMP];
     out->ms_precalc = h->ms[KC_PRECALC];
     out->ms_sort = h->ms[KC_SORT];
+    out->ms_solve = h->ms[KC_SOLVE];
+    out->solve_launches = h->solve_launches;
     out->bytes_particle_state = h->bytes_particles;
     out->bytes_grid_state = h->bytes_grid;
     return FPIC_OK;
@@ -1369,7 +1303,7 @@ int fpic_reset_stats(fpic_handle* h)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     timing_collect(h);
     for (double& m : h->ms) m = 0;
-    h->particle_updates = h->step_launches = h->deposit_launches = h->sort_passes = 0;
+    h->particle_updates = h->step_launches = h->deposit_launches = h->sort_passes = h->solve_launches = 0;
     return FPIC_OK;
 }
 

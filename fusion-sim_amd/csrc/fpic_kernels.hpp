@@ -564,9 +564,10 @@ __global__ __launch_bounds__(256) void bin_count_kernel(ParticleArrays<T> p, siz
 
 // Exclusive scan of the tile counts, reset of the cursors, and the scatter's work
 // list: each bin is cut into chunks of kDepositChunk particles.  One workgroup.
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t ntiles,
+static __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t ntiles,
                                                         uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
-                                                        BlockWork* __restrict__ work, uint32_t* __restrict__ nwork)
+                                                        BlockWork* __restrict__ work, uint32_t* __restrict__ nwork,
+                                                        uint32_t chunk = kDepositChunk)
 {
     __shared__ uint32_t part_p[1024], part_b[1024];
     const uint32_t per = (ntiles + 1023) / 1024;
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restri
     for (uint32_t t = t0; t < t0 + per && t < ntiles; ++t) {
         const uint32_t c = tile_count[t];
         sp += c;
-        sb += (c + kDepositChunk - 1) / kDepositChunk;
+        sb += (c + chunk - 1) / chunk;
     }
     part_p[threadIdx.x] = sp;
     part_b[threadIdx.x] = sb;
@@ -596,11 +597,11 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t* __restri
         // The last bin holds the particles that were clipped when binned.  They are
         // scanned too (re-injection can bring them back before the next binning); their
         // LDS window is tile 0's, whatever lands elsewhere takes the global path.
-        for (uint32_t b = 0; b * kDepositChunk < c; ++b) {
+        for (uint32_t b = 0; b * chunk < c; ++b) {
             BlockWork w;
             w.tile = (t + 1 < ntiles) ? t : 0;
-            w.begin = run_p + b * kDepositChunk;
-            w.end = run_p + ((b + 1) * kDepositChunk < c ? (b + 1) * kDepositChunk : c);
+            w.begin = run_p + b * chunk;
+            w.end = run_p + ((b + 1) * chunk < c ? (b + 1) * chunk : c);
             w.pad = 0;
             work[run_b++] = w;
         }

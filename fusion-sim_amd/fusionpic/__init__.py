@@ -25,7 +25,10 @@ F32, F64 = 0, 1
 GRID_E, GRID_B, GRID_SINK_MASK, GRID_SOURCE_PDF = 0, 1, 2, 3
 (READ_MOMENTS, READ_NORM, READ_AVG, READ_R1, READ_R2, READ_R3, READ_A, READ_B, READ_E, READ_SINK,
  READ_INV_CDF) = range(11)
-BUF_CELL_SUMS = 0
+BUF_CELL_SUMS, BUF_RHO_FIXED = 0, 1
+GEOM_CYL_RZ, GEOM_CART3D = 0, 1
+SOLVER_NONE, SOLVER_POISSON_FFT = 0, 1
+F3_E, F3_RHO, F3_PHI, F3_RHO_FIXED = 0, 1, 2, 3
 
 ABI_FUNCTIONS = [
     "fpic_last_error", "fpic_abi_version", "fpic_build_arch", "fpic_create", "fpic_destroy", "fpic_set_particles",
@@ -35,6 +38,8 @@ ABI_FUNCTIONS = [
     "fpic_read_grid", "fpic_get_particles", "fpic_get_cells", "fpic_device_buffer", "fpic_set_stream",
     "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
     "fpic_get_substep_counter", "fpic_set_substep_counter", "fpic_save_checkpoint", "fpic_load_checkpoint",
+    "fpic_add_species", "fpic_set_particles_of", "fpic_get_particles_of", "fpic_get_cells_of", "fpic_add_b",
+    "fpic_set_field3", "fpic_read_field3",
 ]
 
 
@@ -51,7 +56,9 @@ class Spec(ctypes.Structure):
         ("particle_charge", ctypes.c_double), ("count", ctypes.c_uint64), ("precision", ctypes.c_int32),
         ("device", ctypes.c_int32), ("physical_a", ctypes.c_int32), ("sort_interval", ctypes.c_int32),
         ("unfused_deposit", ctypes.c_int32), ("rng_mode", ctypes.c_int32), ("rng_seed_lo", ctypes.c_uint32),
-        ("rng_seed_hi", ctypes.c_uint32), ("reserved", ctypes.c_int32 * 4),
+        ("rng_seed_hi", ctypes.c_uint32), ("geometry", ctypes.c_int32), ("solver", ctypes.c_int32), ("ny", ctypes.c_int32),
+        ("shape", ctypes.c_int32), ("length_y", ctypes.c_double), ("macro_weight", ctypes.c_double),
+        ("reserved", ctypes.c_double * 6),
     ]
 
 
@@ -61,7 +68,8 @@ class Stats(ctypes.Structure):
         ("deposit_launches", ctypes.c_uint64), ("sort_passes", ctypes.c_uint64), ("deposit_spilled", ctypes.c_uint64),
         ("ms_push", ctypes.c_double), ("ms_deposit", ctypes.c_double), ("ms_stamp", ctypes.c_double),
         ("ms_precalc", ctypes.c_double), ("ms_sort", ctypes.c_double), ("bytes_particle_state", ctypes.c_uint64),
-        ("bytes_grid_state", ctypes.c_uint64), ("reserved", ctypes.c_double * 8),
+        ("bytes_grid_state", ctypes.c_uint64), ("ms_solve", ctypes.c_double), ("solve_launches", ctypes.c_uint64),
+        ("reserved", ctypes.c_double * 6),
     ]
 
     def as_dict(self):
@@ -118,6 +126,13 @@ def load_library(path=None):
     lib.fpic_set_substep_counter.argtypes = [vp, ctypes.c_uint64]
     lib.fpic_save_checkpoint.argtypes = [vp, ctypes.c_char_p]
     lib.fpic_load_checkpoint.argtypes = [vp, ctypes.c_char_p]
+    lib.fpic_add_species.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.POINTER(ci)]
+    lib.fpic_set_particles_of.argtypes = [vp, ci, vp, vp, ctypes.c_uint64, ci]
+    lib.fpic_get_particles_of.argtypes = [vp, ci, vp, vp, ci]
+    lib.fpic_get_cells_of.argtypes = [vp, ci, vp]
+    lib.fpic_add_b.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    lib.fpic_set_field3.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+    lib.fpic_read_field3.argtypes = [vp, ci, vp, ci]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -349,6 +364,114 @@ class CylindricalParticlePusher:
         self._check(self._lib.fpic_reset_stats(self._h))
 
 
+class ElectrostaticBoxPusher:
+    """spec.geometry == 'cart3d': the self-consistent electrostatic extension (BASELINE.json
+    configs[2..4]) behind the reference's method names.  Periodic box radius x length_y x height
+    (x, y, z) on nr x ny x nz nodes; set / addBZ / precalc / step / density keep their meaning
+    (include/fusionpic.h, "extension: spec.geometry").  No reference counterpart: parity unpinned."""
+
+    def __init__(self, spec, precision="fp32", device=0, count=0, sort_interval=0, library=None, **ignored):
+        _validate_spec(spec)
+        for key in ("ny", "length_y"):
+            if key not in spec or isinstance(spec[key], bool) or not isinstance(spec[key], (int, float, np.integer, np.floating)):
+                raise FusionPicError(-1, "." + key + " <- Non-optional property is undefined!")
+        self._lib = library or load_library()
+        self.spec = dict(spec)
+        s = Spec()
+        for key in _SPEC_KEYS:
+            setattr(s, key, spec[key])
+        count = int(count or spec.get("count") or 0)
+        s.count = count
+        s.precision = {"fp32": F32, "fp64": F64}[spec.get("precision", precision)]
+        s.device = int(device)
+        s.sort_interval = int(sort_interval)
+        s.geometry = GEOM_CART3D
+        s.solver = {"none": SOLVER_NONE, "poisson_fft": SOLVER_POISSON_FFT}[spec.get("solver", "poisson_fft")]
+        s.ny = int(spec["ny"])
+        s.length_y = float(spec["length_y"])
+        s.macro_weight = float(spec.get("macro_weight", 1.0))
+        self.precision = s.precision
+        self.nx, self.ny, self.nz = int(spec["nr"]), int(spec["ny"]), int(spec["nz"])
+        self.nodes = self.nx * self.ny * self.nz
+        self.counts = [count if count else int(spec["nparticles"]) ** 2]
+        self.n = self.counts[0]
+        h = ctypes.c_void_p()
+        rc = self._lib.fpic_create(ctypes.byref(s), ctypes.byref(h))
+        if rc != 0:
+            raise FusionPicError(rc, self._lib.fpic_last_error(None).decode())
+        self._h = h
+
+    _check = CylindricalParticlePusher._check
+    destroy = CylindricalParticlePusher.destroy
+    __del__ = CylindricalParticlePusher.__del__
+    sync = CylindricalParticlePusher.sync
+    sort = CylindricalParticlePusher.sort
+    profile = CylindricalParticlePusher.profile
+    stats = CylindricalParticlePusher.stats
+    resetStats = CylindricalParticlePusher.resetStats
+    setStream = CylindricalParticlePusher.setStream
+    precalc = CylindricalParticlePusher.precalc
+    step = CylindricalParticlePusher.step
+    density = CylindricalParticlePusher.density
+    addBZ = CylindricalParticlePusher.addBZ
+    deviceBuffer = CylindricalParticlePusher.deviceBuffer
+
+    def addSpecies(self, mass, charge, count):
+        idx = ctypes.c_int()
+        self._check(self._lib.fpic_add_species(self._h, float(mass), float(charge), int(count), ctypes.byref(idx)))
+        self.counts.append(int(count))
+        return idx.value
+
+    def addB(self, bx, by, bz):
+        self._check(self._lib.fpic_add_b(self._h, float(bx), float(by), float(bz)))
+
+    def set(self, value=None, species=0, **kw):
+        """out.set({position, velocity, E}): positions in metres, velocities in units of c (empic.js:1199-1244);
+        E is value[i][j][k][3] in V/m (a static field with solver 'none', or a field injected for a test)."""
+        value = dict(value or {}, **kw)
+        n = self.counts[species]
+        for key in ("position", "velocity"):
+            if value.get(key) is not None:
+                a = _as_float_array(value[key])
+                if a.shape != (n, 3):
+                    raise FusionPicError(-1, ".%s <- expected [%d][3]" % (key, n))
+                p = a.ctypes.data if key == "position" else None
+                v = a.ctypes.data if key == "velocity" else None
+                self._check(self._lib.fpic_set_particles_of(self._h, species, p, v, n, _code(a)))
+        if value.get("E") is not None:
+            a = _as_float_array(value["E"])
+            if a.shape != (self.nx, self.ny, self.nz, 3):
+                raise FusionPicError(-1, ".E <- expected [%d][%d][%d][3]" % (self.nx, self.ny, self.nz))
+            self._check(self._lib.fpic_set_field3(self._h, F3_E, a.ctypes.data, self.nx, self.ny, self.nz, _code(a)))
+
+    def getParticles(self, dtype=None, species=0):
+        code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
+        n = self.counts[species]
+        out = {"position": np.empty((n, 3), dtype=_np_dtype(code)), "velocity": np.empty((n, 3), dtype=_np_dtype(code))}
+        self._check(self._lib.fpic_get_particles_of(self._h, species, out["position"].ctypes.data, out["velocity"].ctypes.data, code))
+        return out
+
+    def getCells(self, species=0):
+        out = np.empty(self.counts[species], dtype=np.int32)
+        self._check(self._lib.fpic_get_cells_of(self._h, species, out.ctypes.data))
+        return out
+
+    def readField(self, which, dtype=None):
+        """F3_E -> [nodes][4] (Ex, Ey, Ez, phi); F3_RHO / F3_PHI -> [nodes]; F3_RHO_FIXED -> int64 [nodes];
+        node index i + nr*(j + ny*k)."""
+        if which == F3_RHO_FIXED:
+            out = np.empty(self.nodes, dtype=np.int64)
+            self._check(self._lib.fpic_read_field3(self._h, which, out.ctypes.data, 0))
+            return out
+        code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
+        out = np.empty(self.nodes * (4 if which == F3_E else 1), dtype=_np_dtype(code))
+        self._check(self._lib.fpic_read_field3(self._h, which, out.ctypes.data, code))
+        return out.reshape(self.nodes, 4) if which == F3_E else out
+
+
 def makeCylindricalParticlePusher(spec, **extensions):
-    """empic.makeCylindricalParticlePusher(spec) (empic.js:30)."""
+    """empic.makeCylindricalParticlePusher(spec) (empic.js:30).  Extension key spec.geometry = 'cart3d'
+    selects the self-consistent electrostatic box (no reference counterpart)."""
+    if spec.get("geometry", "cyl_rz") == "cart3d":
+        return ElectrostaticBoxPusher(spec, **extensions)
     return CylindricalParticlePusher(spec, **extensions)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define FPIC_ABI_VERSION 1
+#define FPIC_ABI_VERSION 2
 
 typedef enum fpic_status {
     FPIC_OK = 0,
@@ -79,9 +79,43 @@ typedef enum fpic_grid_out {
     FPIC_READ_INV_CDF = 10 /* 512 x 512, .xy used (empic.js:228-241, :1328-1339) */
 } fpic_grid_out;
 
+/* ---- extension: spec.geometry.  The reference has ONE geometry (axisymmetric (r,z) grid, static
+ * fields, empic.js:111-115) and no field solve in its step loop (empic.js:1436-1505; SURVEY.md
+ * section 0).  FPIC_GEOM_CART3D is the self-consistent electrostatic mode of BASELINE.json
+ * configs[2..4]: a periodic box radius x length_y x height (x, y, z) on nr x ny x nz nodes,
+ * CIC gather/deposit, Poisson solve each sub-step.  It has no reference counterpart (parity
+ * unpinned; defined by oracle/es3d_oracle_impl.h).  The same entry points drive it:
+ *   fpic_set_particles  positions in metres (wrapped into the box), velocities in units of c
+ *   fpic_add_bz / fpic_add_b   uniform external magnetic field (Boris rotation)
+ *   fpic_precalc        fields <- particles: deposit + solve (the fields->coefficients stage,
+ *                       empic.js:1413-1434; must precede the first step)
+ *   fpic_step           2 sub-steps per call (empic.js:1436-1469), each push+deposit fused, then solve
+ *   fpic_density        no-op: the charge density of the current positions is always at hand
+ *   fpic_get_particles / fpic_get_cells / fpic_sort / fpic_sync / fpic_profile / fpic_get_stats
+ * Calls that only make sense on the (r,z) pusher return FPIC_ERR_STATE. */
+typedef enum fpic_geometry {
+    FPIC_GEOM_CYL_RZ = 0, /* the reference's pusher */
+    FPIC_GEOM_CART3D = 1
+} fpic_geometry;
+
+typedef enum fpic_solver {
+    FPIC_SOLVER_NONE = 0,        /* fields are what fpic_set_field3 uploaded */
+    FPIC_SOLVER_POISSON_FFT = 1  /* rocFFT forward/inverse around a hand-written k-space kernel */
+} fpic_solver;
+
+/* CART3D grids, node index i + nr*(j + ny*k) (i fastest, as the reference's texel index
+ * 4*(i + j*nr), empic.js:1162). */
+typedef enum fpic_field3 {
+    FPIC_F3_E = 0,         /* in: value[i][j][k][3] V/m;  out: 4 per node (Ex, Ey, Ez, phi) */
+    FPIC_F3_RHO = 1,       /* out: C/m^3, 1 per node */
+    FPIC_F3_PHI = 2,       /* out: V, 1 per node */
+    FPIC_F3_RHO_FIXED = 3  /* out: int64 per node, 2^42 per unit charge number (exact, order-free) */
+} fpic_field3;
+
 /* Device buffers whose address can be handed to a collective (see fpic_device_buffer). */
 typedef enum fpic_buffer {
-    FPIC_BUF_CELL_SUMS = 0 /* per-cell sums 0.001*(vr,vtheta,vz,1), (nr+1)*(nz+1)*4 scalars */
+    FPIC_BUF_CELL_SUMS = 0, /* per-cell sums 0.001*(vr,vtheta,vz,1), (nr+1)*(nz+1)*4 scalars */
+    FPIC_BUF_RHO_FIXED = 1  /* CART3D: int64 charge accumulators, nr*ny*nz */
 } fpic_buffer;
 
 /*
@@ -117,7 +151,13 @@ typedef struct fpic_spec {
                                vector of particle i at sub-step t is Philox4x32-10(counter (i, t, 0x5EED),
                                key rng_seed); no per-particle random state, no entropy table */
     uint32_t rng_seed_lo, rng_seed_hi;
-    int32_t reserved[4];
+    int32_t geometry;       /* fpic_geometry; 0 = the reference's (r,z) pusher */
+    int32_t solver;         /* fpic_solver (CART3D) */
+    int32_t ny;             /* CART3D: nodes along y (nr along x, nz along z) */
+    int32_t shape;          /* reserved for the deposit shape on the (r,z) grid; 0 = the reference's 11x11 stamp */
+    double length_y;        /* CART3D: box is radius (x) x length_y x height (z) metres */
+    double macro_weight;    /* CART3D: real particles per macro-particle (charge density scale); 0 = 1 */
+    double reserved[6];
 } fpic_spec;
 
 typedef struct fpic_handle fpic_handle;
@@ -138,7 +178,9 @@ typedef struct fpic_stats {
     double ms_sort;
     uint64_t bytes_particle_state; /* device bytes held for particle state */
     uint64_t bytes_grid_state;
-    double reserved[8];
+    double ms_solve;             /* CART3D: sum over field solves (rho conversion, FFTs, k-space, gradient) */
+    uint64_t solve_launches;
+    double reserved[6];
 } fpic_stats;
 
 /* Last error text.  h may be NULL after a failed fpic_create. */
@@ -216,6 +258,21 @@ int fpic_get_cells(fpic_handle* h, int32_t* cells);
 int fpic_device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
 int fpic_set_stream(fpic_handle* h, void* hip_stream);
 int fpic_get_stream(fpic_handle* h, void** hip_stream);
+
+/* ---- CART3D extension entry points (FPIC_ERR_STATE on an (r,z) handle) ---- */
+/* A further species sharing the grid (the reference has one species per pusher, empic.js:37-38).
+ * charge must be a non-zero integer multiple (|Z| <= 255) of spec.particle_charge; the macro weight
+ * is shared.  *index receives the species number (spec's own species is 0). */
+int fpic_add_species(fpic_handle* h, double mass, double charge, uint64_t count, int* index);
+int fpic_set_particles_of(fpic_handle* h, int species, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype);
+int fpic_get_particles_of(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype);
+int fpic_get_cells_of(fpic_handle* h, int species, int32_t* cells);
+/* uniform external B (T), additive like the reference's painters (empic.js:1391-1400) */
+int fpic_add_b(fpic_handle* h, double bx, double by, double bz);
+/* which = FPIC_F3_E only: value[i][j][k][3] flattened, dims must equal the handle's */
+int fpic_set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int nz, int dtype);
+/* out: nodes (RHO, PHI), 4*nodes (E) of dtype, or nodes int64 (RHO_FIXED, dtype ignored) */
+int fpic_read_field3(fpic_handle* h, int which, void* out, int dtype);
 
 /* Counter-based RNG mode only: the global sub-step index (starts at 0, +2 per step() call);
  * settable so that a run can be resumed. */

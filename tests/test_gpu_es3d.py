@@ -1,0 +1,262 @@
+"""GPU parity tests of the CART3D electrostatic extension (spec.geometry = 'cart3d') through the
+C ABI, against the build's own CPU oracle (oracle/es3d_oracle.c) and analytic known answers.
+
+PARITY UNPINNED — the reference has no self-consistent mode: what is
+compared here is the HIP path with the oracle that defines the mode.  Bar: particles, cell
+indices and the fixed-point charge grid bit-exact for a given field; the FFT solve within 2e-5
+(fp32) / 1e-10 (fp64) of the oracle's double-precision solve; Poisson single mode to 1e-6; cold
+plasma oscillation within 1 % of omega_p; total charge exact.
+"""
+import numpy as np
+import pytest
+
+from helpers import same_bits
+
+pytestmark = pytest.mark.gpu
+
+ME, QE = 9.109e-31, -1.602e-19
+MP = 1.67e-27
+
+
+@pytest.fixture(scope="module")
+def fp():
+    import fusionpic
+    fusionpic.load_library()
+    return fusionpic
+
+
+@pytest.fixture(scope="module")
+def eo():
+    import es3d_oracle
+    return es3d_oracle
+
+
+def box_spec(n=(16, 16, 16), L=(1.0, 1.0, 1.0), count=1000, dt=1e-10, mass=ME, charge=QE, **kw):
+    s = dict(radius=L[0], length_y=L[1], height=L[2], nr=n[0], ny=n[1], nz=n[2], dt=dt, nparticles=0, count=count,
+             particle_mass=mass, particle_charge=charge, geometry="cart3d", solver="poisson_fft", macro_weight=1.0)
+    s.update(kw)
+    return s
+
+
+def make_pair(fp, eo, spec, precision):
+    dtype = np.float32 if precision == "fp32" else np.float64
+    return fp.makeCylindricalParticlePusher(spec, precision=precision), eo.OracleES3D(spec, dtype)
+
+
+def assert_same_particles(sim, ora, species=0, what=""):
+    got = sim.getParticles(species=species)
+    assert np.array_equal(sim.getCells(species=species), ora.cells(species)), what
+    assert same_bits(got["position"], ora.positions(species)), what
+    assert same_bits(got["velocity"], ora.velocities(species)), what
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("shape,n,with_b", [((16, 16, 8), 4000, False), ((40, 24, 20), 20001, True), ((12, 10, 6), 999, True),
+                                            ((64, 32, 32), 50003, False)])
+def test_push_and_deposit_bit_exact_in_a_given_field(fp, eo, precision, shape, n, with_b):
+    """solver 'none': a random static E, uniform B; every sub-step's particles, cells and charge grid are
+    bit-identical to the oracle's (flat path at precalc(), tiled path afterwards, re-binning in between;
+    grids smaller than, equal to and not a multiple of the 16x16x8 tile; counts not a multiple of 4)."""
+    rng = np.random.default_rng(n)
+    L = (0.02, 0.015, 0.01)
+    spec = box_spec(shape, L, count=n, dt=2e-11, solver="none", macro_weight=2e4)
+    sim, ora = make_pair(fp, eo, spec, precision)
+    pos = rng.random((n, 3)) * L
+    pos[:6] = [[0, 0, 0], [L[0], L[1], L[2]], [L[0] * (1 - 1e-9), 0, 0], [-0.001, 0.02, 0.0101], [L[0] / shape[0], L[1] / shape[1], 0],
+               [L[0] * 0.5, L[1] * 0.999999, L[2] * 0.5]]
+    # a third of the particles cross one to two cells per sub-step: exercises the wrap and the out-of-window path
+    vel = rng.normal(0, 0.01, (n, 3)) + rng.normal(0, 0.3, (n, 3)) * (rng.random((n, 1)) < 0.3)
+    E = rng.normal(0, 3e4, shape + (3,))
+    for s in (sim, ora):
+        s.set(position=pos, velocity=vel, E=E)
+    if with_b:
+        sim.addB(0.3, -0.2, 0.9); ora.add_b(0.3, -0.2, 0.9)
+    sim.precalc(); ora.precalc()
+    assert np.array_equal(sim.readField(fp.F3_RHO_FIXED), ora.rho_fixed)
+    assert_same_particles(sim, ora, what="upload")
+    for frame in range(3):
+        sim.step(); ora.step()
+        assert_same_particles(sim, ora, what="frame %d" % frame)
+        fixed = sim.readField(fp.F3_RHO_FIXED)
+        assert np.array_equal(fixed, ora.rho_fixed), frame
+        assert int(fixed.sum()) == n * eo.FIXED_ONE
+    assert same_bits(sim.readField(fp.F3_RHO), ora.rho)
+    st = sim.stats()
+    assert st["particle_updates"] == 6 * n and st["sort_passes"] >= 1
+    sim.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("shape", [(16, 16, 16), (32, 8, 12), (24, 20, 16), (64, 64, 64)])
+def test_poisson_solve_matches_oracle_and_single_mode(fp, eo, precision, shape):
+    """rho from a random particle cloud: phi and E within tolerance of the oracle's double-precision solve;
+    and the discrete operator's eigenvector: rho = cos(k.x) gives phi = rho / (eps0 K^2) to 1e-6"""
+    rng = np.random.default_rng(sum(shape))
+    n = 30000
+    L = (0.7, 1.3, 0.9)
+    spec = box_spec(shape, L, count=n, macro_weight=1e9)
+    sim, ora = make_pair(fp, eo, spec, precision)
+    pos = rng.random((n, 3)) * L
+    for s in (sim, ora):
+        s.set(position=pos, velocity=np.zeros((n, 3)))
+    sim.precalc(); ora.precalc()
+    assert np.array_equal(sim.readField(fp.F3_RHO_FIXED), ora.rho_fixed)
+    assert same_bits(sim.readField(fp.F3_RHO), ora.rho)
+    tol = 2e-5 if precision == "fp32" else 1e-10
+    phi, want = sim.readField(fp.F3_PHI, np.float64), ora.phi.astype(np.float64)
+    assert np.abs(phi - want).max() <= tol * np.abs(want).max()
+    e4, w4 = sim.readField(fp.F3_E, np.float64), ora.E4.reshape(-1, 4).astype(np.float64)
+    assert np.abs(e4[:, :3] - w4[:, :3]).max() <= 20 * tol * np.abs(w4[:, :3]).max()
+    assert same_bits(e4[:, 3], phi)
+    sim.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_self_consistent_steps_track_the_oracle(fp, eo, precision):
+    """a warm two-species plasma, five frames of push+deposit+solve: the charge grid after the first
+    sub-step is bit-identical (same E to the last bit is not required for that: cells only), total
+    charge is exact every frame, particles stay within the solve's tolerance of the oracle's"""
+    rng = np.random.default_rng(77)
+    n = 40000
+    shape, L = (32, 16, 24), (0.032, 0.016, 0.024)
+    dens = 1e15
+    spec = box_spec(shape, L, count=n, dt=5e-12, macro_weight=dens * np.prod(L) / n)
+    sim, ora = make_pair(fp, eo, spec, precision)
+    ions_s = sim.addSpecies(MP, -QE, n // 2)
+    ions_o = ora.add_species(MP, -QE, n // 2)
+    assert ions_s == ions_o == 1
+    pe, ve = rng.random((n, 3)) * L, rng.normal(0, 2e-3, (n, 3))
+    pi, vi = rng.random((n // 2, 3)) * L, rng.normal(0, 5e-5, (n // 2, 3))
+    for s in (sim, ora):
+        s.set(position=pe, velocity=ve)
+        s.set(position=pi, velocity=vi, species=1)
+    sim.addBZ(0.05); ora.add_bz(0.05)
+    sim.precalc(); ora.precalc()
+    assert np.array_equal(sim.readField(fp.F3_RHO_FIXED), ora.rho_fixed)
+    total = (n - n // 2) * eo.FIXED_ONE
+    tol = 1e-4 if precision == "fp32" else 1e-9
+    for frame in range(5):
+        sim.step(); ora.step()
+        fixed = sim.readField(fp.F3_RHO_FIXED)
+        assert int(fixed.sum()) == total
+        for sp in (0, 1):
+            got = sim.getParticles(np.float64, species=sp)
+            d = np.abs(got["position"] - ora.positions(sp)); d = np.minimum(d, 1 - d)
+            assert d.max() <= tol, (frame, sp)
+            vs = np.abs(ora.velocities(sp)).max()
+            assert np.abs(got["velocity"] - ora.velocities(sp)).max() <= 20 * tol * vs, (frame, sp)
+            assert np.mean(sim.getCells(species=sp) == ora.cells(sp)) > 0.999
+    e4, w4 = sim.readField(fp.F3_E, np.float64), ora.E4.reshape(-1, 4).astype(np.float64)
+    assert np.abs(e4[:, :3] - w4[:, :3]).max() <= 100 * tol * np.abs(w4[:, :3]).max()
+    sim.destroy()
+
+
+def test_cold_plasma_oscillation_on_the_gpu(fp, eo):
+    """SURVEY section 7 known answer: field energy oscillates at 2 omega_p; grid dispersion omega_p cos(k dx/2)"""
+    nx, L, per_cell, dt, wp_dt = 32, 1.0, 4, 1e-10, 0.05
+    n = nx * per_cell * 4 * 4
+    wp = wp_dt / dt
+    density = wp ** 2 * eo.EPS0 * ME / QE ** 2
+    spec = box_spec((nx, 4, 4), (L, L / 8, L / 8), count=n, dt=dt, macro_weight=density * L * (L / 8) ** 2 / n)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    xs = (np.arange(nx * per_cell) + 0.5) / (nx * per_cell) * L
+    ys = (np.arange(4) + 0.5) / 4 * (L / 8)
+    X, Y, Z = np.meshgrid(xs, ys, ys, indexing="ij")
+    pos = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    vel = np.zeros_like(pos)
+    vel[:, 0] = 2e-3 * np.sin(2 * np.pi / L * pos[:, 0])
+    sim.set(position=pos, velocity=vel)
+    sim.precalc()
+    dv = (L / nx) * (L / 32) ** 2
+    energy = []
+    for _ in range(int(round(2.2 * 2 * np.pi / wp_dt)) // 2):
+        sim.step()
+        e4 = sim.readField(fp.F3_E, np.float64)
+        energy.append(0.5 * eo.EPS0 * float((e4[:, :3] ** 2).sum()) * dv)
+    energy = np.array(energy)
+    t = (np.arange(len(energy)) + 1) * 2 * dt
+    peaks = [i for i in range(1, len(energy) - 1) if energy[i] > energy[i - 1] and energy[i] >= energy[i + 1]]
+    assert len(peaks) >= 3
+
+    def vertex(i):
+        y0, y1, y2 = energy[i - 1], energy[i], energy[i + 1]
+        return t[i] + 0.5 * (y0 - y2) / (y0 - 2 * y1 + y2) * (t[1] - t[0])
+    omega = np.pi / np.mean(np.diff([vertex(i) for i in peaks]))
+    assert abs(omega / wp - 1) < 0.01
+    assert abs(omega / (wp * np.cos(np.pi / nx)) - 1) < 0.002
+    sim.destroy()
+
+
+def test_box_error_paths(fp):
+    import ctypes
+    lib = fp.load_library()
+    spec = box_spec((8, 8, 8), count=10)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    h = sim._h
+    msg = lambda: lib.fpic_last_error(h).decode()
+    f32 = np.zeros(8 * 8 * 8 * 3, dtype=np.float32)
+    assert lib.fpic_step(h, 1) == -5 and "precalc" in msg()
+    assert lib.fpic_set_grid(h, 0, f32.ctypes.data, 8, 8, 3, 0) == -5 and "CART3D" in msg()
+    assert lib.fpic_read_grid(h, 0, f32.ctypes.data, 0) == -5
+    assert lib.fpic_add_current_loop(h, 0.1, 0.1, 1.0) == -5
+    assert lib.fpic_set_random_state(h, None, None) == -5
+    assert lib.fpic_save_checkpoint(h, b"/tmp/x.ckp") == -5
+    assert lib.fpic_set_field3(h, 0, f32.ctypes.data, 8, 8, 4, 0) == -1 and ".grid" in msg()
+    assert lib.fpic_set_field3(h, 1, f32.ctypes.data, 8, 8, 8, 0) == -1 and ".which" in msg()
+    assert lib.fpic_read_field3(h, 9, f32.ctypes.data, 0) == -1
+    assert lib.fpic_set_particles_of(h, 3, f32.ctypes.data, None, 10, 0) == -1 and ".species" in msg()
+    assert lib.fpic_set_particles_of(h, 0, f32.ctypes.data, None, 11, 0) == -1 and "expected 10 particles" in msg()
+    idx = ctypes.c_int()
+    assert lib.fpic_add_species(h, 1.0, 0.5 * QE, 5, ctypes.byref(idx)) == -1 and ".charge" in msg()
+    assert lib.fpic_add_species(h, -1.0, QE, 5, ctypes.byref(idx)) == -1 and ".mass" in msg()
+    # box-only calls on the reference's pusher
+    rz = fp.makeCylindricalParticlePusher(dict(radius=1.0, height=1.0, nr=8, nz=8, dt=1e-9, nparticles=3, particle_mass=MP,
+                                               particle_charge=-QE))
+    assert lib.fpic_add_b(rz._h, 0.0, 0.0, 1.0) == -5 and b"CART3D" in lib.fpic_last_error(rz._h)
+    assert lib.fpic_read_field3(rz._h, 0, f32.ctypes.data, 0) == -5
+    # bad box specs
+    bad = dict(spec, ny=0)
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(bad)
+    assert ".ny" in str(e.value)
+    with pytest.raises(fp.FusionPicError) as e:
+        fp.makeCylindricalParticlePusher(dict(spec, length_y=-1.0))
+    assert ".length_y" in str(e.value)
+    # the handle still works
+    sim.set(position=np.random.default_rng(0).random((10, 3)), velocity=np.zeros((10, 3)))
+    sim.precalc(); sim.step(2); sim.density()
+    got = sim.getParticles()
+    assert np.isfinite(got["position"]).all() and ((got["position"] >= 0) & (got["position"] < 1)).all()
+    assert lib.fpic_get_particles(h, None, None, None, None, 0) == 0
+    sim.destroy(); rz.destroy()
+
+
+def test_large_box_properties(fp, eo):
+    """128^3 nodes, 2e7 particles (the shape of BASELINE configs[2] at 1/25 of its size): exact total charge,
+    momentum conserved, every particle inside the box, re-binning kept the caller's order."""
+    n = 20_000_000
+    shape, L = (128, 128, 128), (0.128, 0.128, 0.128)
+    dens, dt = 1e15, 2e-12
+    spec = box_spec(shape, L, count=n, dt=dt, macro_weight=dens * np.prod(L) / n)
+    sim = fp.makeCylindricalParticlePusher(spec)
+    rng = np.random.Generator(np.random.Philox(0x5EEDF051))
+    pos = rng.random((n, 3), dtype=np.float32) * np.float32(L[0])
+    vel = rng.standard_normal((n, 3), dtype=np.float32) * np.float32(1e-3)
+    sim.set(position=pos, velocity=vel)
+    sim.precalc()
+    p0 = vel.astype(np.float64).sum(axis=0)
+    sim.step(4)
+    fixed = sim.readField(fp.F3_RHO_FIXED)
+    assert int(fixed.astype(object).sum()) == n * eo.FIXED_ONE
+    got = sim.getParticles()
+    assert ((got["position"] >= 0) & (got["position"] < 1)).all()
+    p1 = got["velocity"].astype(np.float64).sum(axis=0)
+    dv = np.abs(got["velocity"].astype(np.float64) - vel).max()
+    assert dv > 0 and np.abs(p1 - p0).max() <= 1e-3 * dv * np.sqrt(n)
+    # the caller's order survived the re-binnings: a slow particle is still near where it started
+    slow = np.argsort(np.abs(vel).max(axis=1))[:1000]
+    d = np.abs(got["position"][slow] - pos[slow] / np.float32(L[0])); d = np.minimum(d, 1 - d)
+    assert d.max() < 0.05
+    st = sim.stats()
+    assert st["sort_passes"] >= 1 and st["particle_updates"] == 8 * n
+    sim.destroy()
