@@ -184,6 +184,117 @@ def dense_sor_line(device, n_power=6, products=60):
                          "algorithmic_bytes_per_launch": st["matrix_bytes"], "launches_timed": st["iterations"]}}
 
 
+def es3d_scene(n, grid, seed=0x5EEDF051):
+    """BASELINE configs[2] shape: periodic box of grid^3 nodes, warm electron plasma against a neutralising
+    background: dx = Debye length, omega_p dt = 0.1, v_th = 1e-3 c, so v_th dt = 0.1 dx."""
+    dt, vth = 1e-11, 1e-3
+    c, eps0, me, qe = 2.998e8, 8.8541878128e-12, 9.109e-31, -1.602e-19
+    dx = vth * c * dt / 0.1
+    L = grid * dx
+    wp = 0.1 / dt
+    n0 = wp ** 2 * eps0 * me / qe ** 2
+    spec = dict(radius=L, length_y=L, height=L, nr=grid, ny=grid, nz=grid, dt=dt, nparticles=0, count=n, particle_mass=me,
+                particle_charge=qe, geometry="cart3d", solver="poisson_fft", macro_weight=n0 * L ** 3 / n)
+    return spec, L, vth
+
+
+def es3d_blocks(n, L, vth, seed=0x5EEDF051, block=1 << 24):
+    """The population in blocks of <= 2^24 particles (a 5e8-particle host array would be 12 GB): positions are a
+    Kronecker lattice frac(i * alpha) with the three R3 multipliers (uniform in the volume, and cheap: three integer
+    multiplies per particle), velocities one Maxwellian block permuted and sign-flipped per block."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    vplus = rng.standard_normal((min(block, n), 3), dtype=np.float32) * np.float32(vth)
+    vminus = -vplus                                                           # pairs of blocks carry no net momentum
+    mult = np.array([3518319155, 2882110345, 2360945575], dtype=np.uint32)   # round(2^32 / phi3^k), phi3 = 1.2207440846
+    pos = np.empty((min(block, n), 3), dtype=np.float32)                      # one buffer, refilled per block
+    idx = np.arange(min(block, n), dtype=np.uint32)
+    tmp = np.empty(min(block, n), dtype=np.uint32)
+    for b in range(0, n, block):
+        m = min(block, n - b)
+        for a in range(3):
+            np.multiply(idx[:m] + np.uint32(b), mult[a], out=tmp[:m])
+            np.right_shift(tmp[:m], np.uint32(8), out=tmp[:m])
+            pos[:m, a] = tmp[:m]
+            pos[:m, a] *= np.float32(L / 16777216.0)
+        yield b, pos[:m], (vplus if (b // block) % 2 == 0 else vminus)[:m]
+
+
+def es3d_line(device, n, grid, steps, warmup, stream=None, cpu=True):
+    """Extension (no reference counterpart, parity unpinned): the self-consistent electrostatic cycle of BASELINE
+    configs[2] — per sub-step one fused kernel (CIC gather, Boris, drift, int64 CIC deposit) and one Poisson solve
+    (rocFFT around hand-written conversion, k-space and gradient kernels)."""
+    import fusionpic as fp
+    import torch
+    spec, L, vth = es3d_scene(n, grid)
+    sim = fp.makeCylindricalParticlePusher(spec, device=device)
+    if stream is not None:
+        sim.setStream(stream.cuda_stream)
+    for first, pos, vel in es3d_blocks(n, L, vth):
+        sim.setRange(first, position=pos, velocity=vel)
+    sim.sort()
+    sim.precalc()
+    for _ in range(warmup):
+        sim.step()
+    sim.sync(); torch.cuda.synchronize()
+    sim.resetStats(); sim.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.step()
+    sim.sync(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = sim.stats()
+    sim.destroy()
+    substeps = 2 * steps
+    push_ms = st["ms_push"] / max(1, st["step_launches"])
+    solve_ms = st["ms_solve"] / max(1, st["solve_launches"])
+    algo = 48.0 * n
+    ach = algo / (push_ms * 1e-3) / 1e9 if push_ms > 0 else 0.0
+    nodes = grid ** 3
+    out = {
+        "what": "spec.geometry='cart3d' (EXTENSION, parity unpinned: no reference counterpart): %d^3 periodic grid, %.1e electrons, "
+                "fp32, CIC, Poisson solve every sub-step; bit-exact against the build's own oracle for a given field, solve within 2e-5"
+                % (grid, n),
+        "value": n * substeps / el, "unit": "particle-updates/s", "ms_per_substep": 1e3 * el / substeps,
+        "kernel_ms_per_substep": {"push_gather_deposit": push_ms, "poisson_solve": solve_ms,
+                                  "rebinning": st["ms_sort"] / substeps, "rebinning_passes": st["sort_passes"]},
+        "roofline": {"bound": "hbm", "kernel": "push3_tiles_kernel<float> (gather + Boris + drift + deposit, one read and one write of the "
+                                                "particle per sub-step)",
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo, "avg_launch_ms": push_ms, "launches_timed": st["step_launches"]},
+        "solve": {"algorithmic_bytes": 2 * 4 * nodes, "avg_ms": solve_ms,
+                  "achieved_GBs": 2 * 4 * nodes / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else 0.0,
+                  "note": "SURVEY 8(d): algorithmic = read rho + write phi; rocFFT's passes, the int64 conversion and the gradient move more"},
+        "cycle_bytes_per_update": 48.0 + 8.0 * nodes / n,
+    }
+    if cpu:
+        try:
+            out["cpu_port"] = es3d_cpu_port()
+        except Exception as e:  # a report, never a reason to fail the bench
+            out["cpu_port"] = {"value": None, "note": str(e)}
+    return out
+
+
+def es3d_cpu_port(seconds_target=5.0):
+    """The build's own CPU oracle of the same cycle (oracle/es3d_oracle.c, OpenMP) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import es3d_oracle as eo
+    cores = usable_cores()
+    n, grid = 2_000_000, 64
+    spec, L, vth = es3d_scene(n, grid)
+    sim = eo.OracleES3D(spec, np.float32, threads=cores)
+    _, pos, vel = next(es3d_blocks(n, L, vth))
+    sim.set(position=pos.astype(np.float64), velocity=vel.astype(np.float64))
+    sim.precalc()
+    k, t0 = 0, time.perf_counter()
+    while True:
+        sim.substep(); k += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or k >= 100:
+            break
+    return {"value": n * k / dt, "unit": "particle-updates/s", "cores": cores, "kind": "port",
+            "sample": "oracle/es3d_oracle.c with -fopenmp, fp32, %d threads, %d^3 grid, %d particles, %d sub-steps in %.1f s" % (cores, grid, n, k, dt)}
+
+
 def measured_traffic(config):
     """HBM bytes per push launch from the committed PMC passes (scripts/pmc_bench.sh,
     profiles/*_traffic.json): rocprofv3 cannot run inside the timed process, so the figure is the
@@ -213,6 +324,9 @@ def main():
                     help="reference = the reference's entropy-table generator (the drop-in, the headline); "
                          "counter = the Philox extension mode (SURVEY.md 8(d))")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: all-reduce on the pusher's stream, no overlap")
+    ap.add_argument("--c3-particles", type=int, default=500_000_000, help="extensions.c3: particles of the electrostatic box (BASELINE configs[2]: 5e8)")
+    ap.add_argument("--c3-grid", type=int, default=256, help="extensions.c3: nodes per axis (BASELINE configs[2]: 256)")
+    ap.add_argument("--only-c3", action="store_true", help="development: measure extensions.c3 alone and print it")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
 
@@ -240,6 +354,10 @@ def main():
         except (AttributeError, TypeError):
             pass
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+
+    if args.only_c3:
+        print(json.dumps({"c3": es3d_line(local_rank, args.c3_particles, args.c3_grid, args.steps, args.warmup, cpu=not args.no_cpu_baseline)}), flush=True)
+        return
 
     spec = dict(radius=1.0, height=1.0, nr=args.grid, nz=args.grid, dt=2e-9, nparticles=args.side,
                 particle_mass=1.67e-27, particle_charge=1.602e-19)
@@ -397,6 +515,8 @@ def main():
         }}
         ext.destroy()
         out["extensions"]["dense_sor"] = dense_sor_line(local_rank)
+        out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, stream=stream,
+                                            cpu=not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

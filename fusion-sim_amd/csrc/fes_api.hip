@@ -281,19 +281,20 @@ int substep(fpic_handle* h)
     return launch_solve<T>(h);
 }
 
+// host holds the caller's particles [first, first + count)
 template <typename T, typename In>
-int upload_pos(fpic_handle* h, Species& s, const In* host)
+int upload_pos(fpic_handle* h, Species& s, const In* host, size_t first, size_t count)
 {
     State* st = h->es;
     const size_t chunk = 8u << 20;
     In* stage = nullptr;
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, s.n) * 3 * sizeof(In)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, count) * 3 * sizeof(In)));
     T* a = static_cast<T*>(s.slab[s.cur]);
-    for (size_t b = 0; b < s.n; b += chunk) {
-        const size_t m = std::min(chunk, s.n - b);
+    for (size_t b = 0; b < count; b += chunk) {
+        const size_t m = std::min(chunk, count - b);
         hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) {
-            set_pos3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, b, m, 1 / st->lx, 1 / st->ly, 1 / st->lz, a, a + s.n_pad,
+            set_pos3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1 / st->lx, 1 / st->ly, 1 / st->lz, a, a + s.n_pad,
                                                                          a + 2 * s.n_pad, s.id[s.cur], s.n);
             e = hipGetLastError();
         }
@@ -305,18 +306,18 @@ int upload_pos(fpic_handle* h, Species& s, const In* host)
 }
 
 template <typename T, typename In>
-int upload_vel(fpic_handle* h, Species& s, const In* host)
+int upload_vel(fpic_handle* h, Species& s, const In* host, size_t first, size_t count)
 {
     const size_t chunk = 8u << 20;
     In* stage = nullptr;
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, s.n) * 3 * sizeof(In)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, count) * 3 * sizeof(In)));
     T* a = static_cast<T*>(s.slab[s.cur]);
-    for (size_t b = 0; b < s.n; b += chunk) {
-        const size_t m = std::min(chunk, s.n - b);
+    for (size_t b = 0; b < count; b += chunk) {
+        const size_t m = std::min(chunk, count - b);
         hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) {
             // velocities stay in units of c, unscaled
-            set_vec3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, b, m, 1.0, 1.0, a + 3 * s.n_pad, a + 4 * s.n_pad,
+            set_vec3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1.0, 1.0, a + 3 * s.n_pad, a + 4 * s.n_pad,
                                                                          a + 5 * s.n_pad, nullptr, s.id[s.cur], s.n);
             e = hipGetLastError();
         }
@@ -483,6 +484,10 @@ int check_species(fpic_handle* h, int species)
 } // namespace
 
 uint64_t particle_count(const fpic_handle* h) { return total_particles(h->es); }
+uint64_t species_count(const fpic_handle* h, int species)
+{
+    return species >= 0 && species < static_cast<int>(h->es->sp.size()) ? h->es->sp[species].n : ~0ull;
+}
 
 int create(fpic_handle* h)
 {
@@ -558,26 +563,28 @@ int add_species(fpic_handle* h, double mass, double charge, uint64_t count, int*
     return FPIC_OK;
 }
 
-int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype)
+int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* vel_aos, uint64_t first, uint64_t n, int dtype)
 {
     if (int rc = check_species(h, species)) return rc;
     Species& s = h->es->sp[species];
-    if (n != s.n) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- expected %zu particles, got %llu", s.n, static_cast<unsigned long long>(n));
+    if (first > s.n || n > s.n - first)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".position <- particles [%llu, %llu) do not lie within the species' %zu", static_cast<unsigned long long>(first),
+                    static_cast<unsigned long long>(first + n), s.n);
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
     int rc = FPIC_OK;
-    if (pos_aos && s.n) {
+    if (pos_aos && n) {
         if (h->prec == FPIC_F32)
-            rc = dtype == FPIC_F32 ? upload_pos<float, float>(h, s, static_cast<const float*>(pos_aos)) : upload_pos<float, double>(h, s, static_cast<const double*>(pos_aos));
+            rc = dtype == FPIC_F32 ? upload_pos<float, float>(h, s, static_cast<const float*>(pos_aos), first, n) : upload_pos<float, double>(h, s, static_cast<const double*>(pos_aos), first, n);
         else
-            rc = dtype == FPIC_F32 ? upload_pos<double, float>(h, s, static_cast<const float*>(pos_aos)) : upload_pos<double, double>(h, s, static_cast<const double*>(pos_aos));
+            rc = dtype == FPIC_F32 ? upload_pos<double, float>(h, s, static_cast<const float*>(pos_aos), first, n) : upload_pos<double, double>(h, s, static_cast<const double*>(pos_aos), first, n);
         s.binned = false;
         if (h->es->solver != FPIC_SOLVER_NONE) h->es->fields_ready = false; // the fields of these positions are not known yet
     }
-    if (rc == FPIC_OK && vel_aos && s.n) {
+    if (rc == FPIC_OK && vel_aos && n) {
         if (h->prec == FPIC_F32)
-            rc = dtype == FPIC_F32 ? upload_vel<float, float>(h, s, static_cast<const float*>(vel_aos)) : upload_vel<float, double>(h, s, static_cast<const double*>(vel_aos));
+            rc = dtype == FPIC_F32 ? upload_vel<float, float>(h, s, static_cast<const float*>(vel_aos), first, n) : upload_vel<float, double>(h, s, static_cast<const double*>(vel_aos), first, n);
         else
-            rc = dtype == FPIC_F32 ? upload_vel<double, float>(h, s, static_cast<const float*>(vel_aos)) : upload_vel<double, double>(h, s, static_cast<const double*>(vel_aos));
+            rc = dtype == FPIC_F32 ? upload_vel<double, float>(h, s, static_cast<const float*>(vel_aos), first, n) : upload_vel<double, double>(h, s, static_cast<const double*>(vel_aos), first, n);
     }
     return rc;
 }

@@ -40,11 +40,15 @@ using fpic::Vec16;
 #endif
 
 constexpr int kTX = 16, kTY = 16, kTZ = 8;       // cells per tile
-constexpr int kHalo = 2;                         // cells staged around a tile
-constexpr int kWX = kTX + 2 * kHalo + 1;         // nodes of the LDS window per axis
-constexpr int kWY = kTY + 2 * kHalo + 1;
-constexpr int kWZ = kTZ + 2 * kHalo + 1;
-constexpr int kWN = kWX * kWY * kWZ;             // 21 * 21 * 13 = 5733 nodes
+// The LDS window of a tile: its nodes plus a halo of H cells.  A node costs 16 B of field record + 8 B of
+// accumulator in float (H = 2: 21 * 21 * 13 = 5733 nodes, 137.6 KB) and 32 + 8 B in double (H = 1:
+// 19 * 19 * 11 = 3971 nodes, 158.8 KB of the CU's 160 KB).
+template <typename T>
+struct Win {
+    static constexpr int H = sizeof(T) == 4 ? 2 : 1;
+    static constexpr int X = kTX + 2 * H + 1, Y = kTY + 2 * H + 1, Z = kTZ + 2 * H + 1;
+    static constexpr int N = X * Y * Z;
+};
 constexpr int kPushThreads3 = 512;
 constexpr int kChunk3 = 32768;                   // particles per workgroup and chunk
 constexpr int kMaxTiles3 = 32768;                // LDS histogram limit of the binning passes (256^3 has 8192 tiles)
@@ -153,8 +157,8 @@ __device__ __forceinline__ void load4_lds3(const FPIC_LDS T* p, T (&o)[4])
 template <typename T>
 struct WindowGrid {
     GlobalGrid<T> g;
-    const FPIC_LDS T* lE;                  // [kWN][4]
-    FPIC_LDS unsigned long long* lrho;     // [kWN]
+    const FPIC_LDS T* lE;                  // [Win<T>::N][4]
+    FPIC_LDS unsigned long long* lrho;     // [Win<T>::N]
     int ox, oy, oz;                        // node of window slot (0,0,0); may be negative (periodic)
     unsigned* spilled;
     // window slot of cell (i,j,k), or -1 when one of its eight nodes lies outside
@@ -167,8 +171,8 @@ struct WindowGrid {
         if (m >= g.ny) m -= g.ny;
         if (n < 0) n += g.nz;
         if (n >= g.nz) n -= g.nz;
-        const bool in = l <= kWX - 2 && m <= kWY - 2 && n <= kWZ - 2;
-        return in ? (n * kWY + m) * kWX + l : -1;
+        const bool in = l <= Win<T>::X - 2 && m <= Win<T>::Y - 2 && n <= Win<T>::Z - 2;
+        return in ? (n * Win<T>::Y + m) * Win<T>::X + l : -1;
     }
     __device__ __forceinline__ void gather(int i, int j, int k, const T (&fx)[2], const T (&fy)[2], const T (&fz)[2], T& Ex, T& Ey, T& Ez) const
     {
@@ -182,7 +186,7 @@ struct WindowGrid {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     T e[4];
-                    load4_lds3(lE + 4 * (s + a + kWX * b + kWX * kWY * c), e);
+                    load4_lds3(lE + 4 * (s + a + Win<T>::X * b + Win<T>::X * Win<T>::Y * c), e);
                     const T w = (fx[a] * fy[b]) * fz[c];
                     Ex = Ex + w * e[0];
                     Ey = Ey + w * e[1];
@@ -200,7 +204,7 @@ struct WindowGrid {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const long long w = static_cast<long long>(wx[a]) * wy[b] * wz[c] * Z;
-                    __hip_atomic_fetch_add(lrho + (s + a + kWX * b + kWX * kWY * c), static_cast<unsigned long long>(w), __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(lrho + (s + a + Win<T>::X * b + Win<T>::X * Win<T>::Y * c), static_cast<unsigned long long>(w), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
     }
@@ -314,13 +318,14 @@ __global__ __launch_bounds__(256) void push3_flat_kernel(Push3Args<T> a)
 }
 
 template <typename T>
-constexpr size_t push3_lds_bytes() { return static_cast<size_t>(kWN) * (4 * sizeof(T) + 8) + 16; }
+constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 * sizeof(T) + 8) + 16; }
 
 // Tiled form for binned particles: one workgroup per chunk of one tile's particles.
 template <typename T, bool HAS_B, bool DEPOSIT_ONLY>
 __global__ __launch_bounds__(kPushThreads3) void push3_tiles_kernel(Push3Args<T> a)
 {
     constexpr int PPT = Vec16<T>::N;
+    constexpr int kWX = Win<T>::X, kWY = Win<T>::Y, kWN = Win<T>::N, kHalo = Win<T>::H;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     FPIC_LDS T* lE = (FPIC_LDS T*)lds3;
     FPIC_LDS unsigned long long* lrho = (FPIC_LDS unsigned long long*)((FPIC_LDS unsigned char*)lds3 + static_cast<size_t>(kWN) * 4 * sizeof(T));

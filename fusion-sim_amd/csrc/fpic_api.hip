@@ -870,7 +870,10 @@ int fpic_destroy(fpic_handle* h)
 int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype)
 {
     CHECK_HANDLE(h);
-    if (h->es) return fes::set_particles(h, 0, pos_aos, vel_aos, n, dtype);
+    if (h->es) {
+        if (n != h->n) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- expected %zu particles, got %llu", h->n, static_cast<unsigned long long>(n));
+        return fes::set_particles(h, 0, pos_aos, vel_aos, 0, n, dtype);
+    }
     if (n != h->n) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- expected %zu particles, got %llu", h->n, static_cast<unsigned long long>(n));
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
     const double fr = h->k.factor_r, fz = h->k.factor_z;
@@ -1219,7 +1222,15 @@ int fpic_set_particles_of(fpic_handle* h, int species, const void* pos_aos, cons
 {
     CHECK_HANDLE(h);
     BOX_ONLY(h, "fpic_set_particles_of");
-    return fes::set_particles(h, species, pos_aos, vel_aos, n, dtype);
+    const uint64_t have = fes::species_count(h, species);
+    if (have != ~0ull && n != have) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- expected %llu particles, got %llu", static_cast<unsigned long long>(have), static_cast<unsigned long long>(n));
+    return fes::set_particles(h, species, pos_aos, vel_aos, 0, n, dtype);
+}
+int fpic_set_particles_range(fpic_handle* h, int species, uint64_t first, uint64_t n, const void* pos_aos, const void* vel_aos, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_set_particles_range");
+    return fes::set_particles(h, species, pos_aos, vel_aos, first, n, dtype);
 }
 int fpic_get_particles_of(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype)
 {

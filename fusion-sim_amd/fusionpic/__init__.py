@@ -39,7 +39,7 @@ ABI_FUNCTIONS = [
     "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
     "fpic_get_substep_counter", "fpic_set_substep_counter", "fpic_save_checkpoint", "fpic_load_checkpoint",
     "fpic_add_species", "fpic_set_particles_of", "fpic_get_particles_of", "fpic_get_cells_of", "fpic_add_b",
-    "fpic_set_field3", "fpic_read_field3",
+    "fpic_set_field3", "fpic_read_field3", "fpic_set_particles_range",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library(path=None):
     lib.fpic_add_species.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.POINTER(ci)]
     lib.fpic_set_particles_of.argtypes = [vp, ci, vp, vp, ctypes.c_uint64, ci]
     lib.fpic_get_particles_of.argtypes = [vp, ci, vp, vp, ci]
+    lib.fpic_set_particles_range.argtypes = [vp, ci, ctypes.c_uint64, ctypes.c_uint64, vp, vp, ci]
     lib.fpic_get_cells_of.argtypes = [vp, ci, vp]
     lib.fpic_add_b.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     lib.fpic_set_field3.argtypes = [vp, ci, vp, ci, ci, ci, ci]
@@ -443,6 +444,16 @@ class ElectrostaticBoxPusher:
             if a.shape != (self.nx, self.ny, self.nz, 3):
                 raise FusionPicError(-1, ".E <- expected [%d][%d][%d][3]" % (self.nx, self.ny, self.nz))
             self._check(self._lib.fpic_set_field3(self._h, F3_E, a.ctypes.data, self.nx, self.ny, self.nz, _code(a)))
+
+    def setRange(self, first, position=None, velocity=None, species=0):
+        """the caller's particles [first, first + len) of a species (piecewise upload of a large population)"""
+        arrs = [None if a is None else _as_float_array(a) for a in (position, velocity)]
+        m = next(a.shape[0] for a in arrs if a is not None)
+        codes = {_code(a) for a in arrs if a is not None}
+        if len(codes) != 1 or any(a is not None and a.shape != (m, 3) for a in arrs):
+            raise FusionPicError(-1, ".position <- position and velocity must be [m][3] of one element type")
+        ptr = lambda a: None if a is None else a.ctypes.data
+        self._check(self._lib.fpic_set_particles_range(self._h, species, int(first), m, ptr(arrs[0]), ptr(arrs[1]), codes.pop()))
 
     def getParticles(self, dtype=None, species=0):
         code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)

@@ -53,7 +53,7 @@ def test_header_symbols_are_all_exported(fp):
     assert sorted(fp.ABI_FUNCTIONS) == syms
     lib.fpic_build_arch.restype = ctypes.c_char_p
     assert lib.fpic_build_arch() == b"gfx950"
-    assert lib.fpic_abi_version() == 1
+    assert lib.fpic_abi_version() == 2
 
 
 def test_solver_header_symbols_are_all_exported(fp):
