@@ -30,10 +30,16 @@ struct Species {
     void* slab[2] = {};
     uint32_t* id[2] = {};
     int cur = 0;
-    uint32_t *tile_count = nullptr, *tile_start = nullptr, *tile_cursor = nullptr, *nwork = nullptr;
-    BlockWork* work = nullptr;
+    // two bin tables: [wl] describes the live particle order, [wl ^ 1] is laid out by the next binning
+    // (which may be the next push, see rebin_pending)
+    uint32_t *tile_count = nullptr, *tile_cursor = nullptr;
+    uint32_t *tile_start2[2] = {}, *nwork2[2] = {};
+    BlockWork* work2[2] = {};
+    int wl = 0;
     size_t work_cap = 0;
     bool binned = false;
+    bool census_fresh = false;  // tile_count holds the census of the current positions (written by the last push)
+    bool rebin_pending = false; // tables [wl ^ 1] are laid out from that census: the next push re-bins
 };
 
 struct State {
@@ -88,11 +94,13 @@ int alloc_species(fpic_handle* h, Species& s)
     uint64_t* acc = &h->bytes_grid;
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_start), sizeof(uint32_t) * (st->ntiles + 1), acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * st->ntiles, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.nwork), sizeof(uint32_t), acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.work), sizeof(BlockWork) * s.work_cap, acc)))
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * st->ntiles, acc)))
         return rc;
+    for (int k = 0; k < 2; ++k)
+        if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_start2[k]), sizeof(uint32_t) * (st->ntiles + 1), acc)) ||
+            (rc = dev_alloc(h, reinterpret_cast<void**>(&s.nwork2[k]), sizeof(uint32_t), acc)) ||
+            (rc = dev_alloc(h, reinterpret_cast<void**>(&s.work2[k]), sizeof(BlockWork) * s.work_cap, acc)))
+            return rc;
     return FPIC_OK;
 }
 
@@ -102,8 +110,9 @@ void free_species(Species& s)
         if (s.slab[k]) (void)hipFree(s.slab[k]);
         if (s.id[k]) (void)hipFree(s.id[k]);
     }
-    for (void* p : { static_cast<void*>(s.tile_count), static_cast<void*>(s.tile_start), static_cast<void*>(s.tile_cursor),
-                     static_cast<void*>(s.nwork), static_cast<void*>(s.work) })
+    for (void* p : { static_cast<void*>(s.tile_count), static_cast<void*>(s.tile_cursor), static_cast<void*>(s.tile_start2[0]),
+                     static_cast<void*>(s.tile_start2[1]), static_cast<void*>(s.nwork2[0]), static_cast<void*>(s.nwork2[1]),
+                     static_cast<void*>(s.work2[0]), static_cast<void*>(s.work2[1]) })
         if (p) (void)hipFree(p);
 }
 
@@ -129,8 +138,14 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     a.dx = static_cast<T>(step / st->lx); a.dy = static_cast<T>(step / st->ly); a.dz = static_cast<T>(step / st->lz);
     a.Z = s.Z;
     a.ntx = st->ntx; a.nty = st->nty; a.ntz = st->ntz;
-    a.work = s.work; a.nwork = s.nwork;
+    a.work = s.work2[s.wl]; a.nwork = s.nwork2[s.wl];
     a.spilled = st->spilled;
+    a.tile_count = s.tile_count;
+    a.id = s.id[s.cur];
+    a.dst_slab = static_cast<T*>(s.slab[s.cur ^ 1]);
+    a.dst_id = s.id[s.cur ^ 1];
+    a.dst_tile_start = s.tile_start2[s.wl ^ 1];
+    a.dst_tile_cursor = s.tile_cursor;
     return a;
 }
 
@@ -144,12 +159,28 @@ int launch_push(fpic_handle* h, Species& s)
     if (s.binned) {
         const unsigned grid = static_cast<unsigned>(s.work_cap);
         constexpr size_t lds = push3_lds_bytes<T>();
-        if (has_b && !DEPOSIT_ONLY) push3_tiles_kernel<T, true, DEPOSIT_ONLY><<<grid, kPushThreads3, lds, h->stream>>>(a);
-        else push3_tiles_kernel<T, false, DEPOSIT_ONLY><<<grid, kPushThreads3, lds, h->stream>>>(a);
+        if constexpr (DEPOSIT_ONLY) {
+            push3_tiles_kernel<T, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
+        } else {
+            const bool rebin = s.rebin_pending;
+            s.census_fresh = s.rebin_pending = false;
+            HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
+            if (rebin && has_b) push3_tiles_kernel<T, true, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
+            else if (rebin) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
+            else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
+            else push3_tiles_kernel<T, false, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
+            HIP_TRY(h, hipGetLastError());
+            s.census_fresh = true;
+            if (rebin) { // this launch was the binning: the other set and the other tables are live now
+                s.cur ^= 1;
+                s.wl ^= 1;
+            }
+        }
     } else {
         const size_t lanes = (s.n + Vec16<T>::N - 1) / Vec16<T>::N;
         if (has_b && !DEPOSIT_ONLY) push3_flat_kernel<T, true, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
         else push3_flat_kernel<T, false, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+        if (!DEPOSIT_ONLY) s.census_fresh = false;
     }
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
@@ -165,25 +196,39 @@ int launch_bin(fpic_handle* h, Species& s)
     const unsigned nb = blocks_for(s.n, 256 * kBinPer3);
     const T* src = static_cast<const T*>(s.slab[s.cur]);
     T* dst = static_cast<T*>(s.slab[s.cur ^ 1]);
+    const int nw = s.wl ^ 1;
     HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
     bin3_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
-    bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start, s.tile_cursor, s.work, s.nwork, static_cast<uint32_t>(kChunk3));
+    bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
     bin3_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
-                                                        st->nty, st->ntiles, s.tile_start, s.tile_cursor);
+                                                        st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
     HIP_TRY(h, hipGetLastError());
     s.cur ^= 1;
+    s.wl = nw;
     s.binned = true;
+    s.census_fresh = s.rebin_pending = false; // tile_count now describes this binning, not a push
     return FPIC_OK;
 }
 
+// Re-bin every species.  A species whose last push left a census of the current positions is not moved now:
+// its next bin table is laid out from that census and the next push writes the sorted order itself (no
+// extra pass); otherwise (first binning, positions uploaded since, `force`) the three-pass binning runs.
 template <typename T>
-int bin_all(fpic_handle* h)
+int bin_all(fpic_handle* h, bool force)
 {
     State* st = h->es;
     timing_begin(h, KC_SORT);
     int rc = FPIC_OK;
-    for (Species& s : st->sp)
-        if ((rc = launch_bin<T>(h, s))) break;
+    for (Species& s : st->sp) {
+        if (!force && s.binned && s.census_fresh && s.n) {
+            const int nw = s.wl ^ 1;
+            bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
+            if (hipGetLastError() != hipSuccess) { rc = fail(h, FPIC_ERR_HIP, "bin table scan failed"); break; }
+            s.rebin_pending = true;
+        } else if ((rc = launch_bin<T>(h, s))) {
+            break;
+        }
+    }
     timing_end(h);
     if (rc) return rc;
     st->substeps_since_bin = 0;
@@ -265,11 +310,14 @@ int substep(fpic_handle* h)
                 st->last_spill = st->spilled_host[slot];
                 st->spill_pending[slot] = false;
             }
-            rebin = st->last_spill * 128 > total_particles(st) || st->substeps_since_bin >= 16;
+            // the count of deposits outside the LDS window grows slowly, then explodes once the bulk reaches the
+            // halo (profiles/r02_c3_rebin_policy.txt: 0.002 %, 0.006 %, 0.08 %, 0.4 % after 4, 8, 10, 12 sub-steps
+            // of the bench scene); a fused re-binning launch costs about a third more than an in-place one
+            rebin = st->last_spill * 4096 > total_particles(st) || st->substeps_since_bin >= 8;
         }
     }
     if (rebin)
-        if (int rc = bin_all<T>(h)) return rc;
+        if (int rc = bin_all<T>(h, false)) return rc;
     if (int rc = deposit_cycle<T, false>(h)) return rc;
     const int slot = static_cast<int>(st->spill_seq++ & 1);
     HIP_TRY(h, hipMemcpyAsync(st->spilled_host + slot, st->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -442,6 +490,8 @@ int create_state(fpic_handle* h)
     if ((e = set_lds(push3_tiles_kernel<T, false, false>, push3_lds_bytes<T>())) != hipSuccess ||
         (e = set_lds(push3_tiles_kernel<T, true, false>, push3_lds_bytes<T>())) != hipSuccess ||
         (e = set_lds(push3_tiles_kernel<T, false, true>, push3_lds_bytes<T>())) != hipSuccess ||
+        (e = set_lds(push3_tiles_kernel<T, false, false, true>, push3_lds_bytes<T>())) != hipSuccess ||
+        (e = set_lds(push3_tiles_kernel<T, true, false, true>, push3_lds_bytes<T>())) != hipSuccess ||
         (e = set_lds(bin3_count_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
         (e = set_lds(bin3_scatter_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess)
         return fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -484,6 +534,7 @@ int check_species(fpic_handle* h, int species)
 } // namespace
 
 uint64_t particle_count(const fpic_handle* h) { return total_particles(h->es); }
+uint64_t last_spill(const fpic_handle* h) { return h->es->last_spill; }
 uint64_t species_count(const fpic_handle* h, int species)
 {
     return species >= 0 && species < static_cast<int>(h->es->sp.size()) ? h->es->sp[species].n : ~0ull;
@@ -578,6 +629,7 @@ int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* 
         else
             rc = dtype == FPIC_F32 ? upload_pos<double, float>(h, s, static_cast<const float*>(pos_aos), first, n) : upload_pos<double, double>(h, s, static_cast<const double*>(pos_aos), first, n);
         s.binned = false;
+        s.census_fresh = s.rebin_pending = false;
         if (h->es->solver != FPIC_SOLVER_NONE) h->es->fields_ready = false; // the fields of these positions are not known yet
     }
     if (rc == FPIC_OK && vel_aos && n) {
@@ -678,7 +730,7 @@ int step(fpic_handle* h, int ncalls)
     return FPIC_OK;
 }
 
-int sort(fpic_handle* h) { return h->prec == FPIC_F32 ? bin_all<float>(h) : bin_all<double>(h); }
+int sort(fpic_handle* h) { return h->prec == FPIC_F32 ? bin_all<float>(h, true) : bin_all<double>(h, true); }
 
 int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes)
 {

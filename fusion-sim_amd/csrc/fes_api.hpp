@@ -21,5 +21,6 @@ int step(fpic_handle* h, int ncalls);
 int sort(fpic_handle* h);
 int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
 uint64_t particle_count(const fpic_handle* h);
+uint64_t last_spill(const fpic_handle* h); // out-of-window deposits of the sub-step before last (lagged read-back)
 
 } // namespace fes

@@ -49,7 +49,7 @@ struct Win {
     static constexpr int X = kTX + 2 * H + 1, Y = kTY + 2 * H + 1, Z = kTZ + 2 * H + 1;
     static constexpr int N = X * Y * Z;
 };
-constexpr int kPushThreads3 = 512;
+constexpr int kPushThreads3 = 1024;                // 16 waves per CU: 14 % faster than 512 (profiles/r02_push3_ablation.txt)
 constexpr int kChunk3 = 32768;                   // particles per workgroup and chunk
 constexpr int kMaxTiles3 = 32768;                // LDS histogram limit of the binning passes (256^3 has 8192 tiles)
 constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
@@ -92,12 +92,27 @@ struct Push3Args {
     const BlockWork* work;
     const uint32_t* nwork;
     unsigned long long* spilled;
+    uint32_t* tile_count;            // census of the NEW positions per tile, zeroed by the host
+    // REBIN launch: the other particle set and its bin table
+    const uint32_t* id;
+    T* dst_slab;
+    uint32_t* dst_id;
+    const uint32_t* dst_tile_start;
+    uint32_t* dst_tile_cursor;
 };
 
 template <typename T>
 struct P3 {
     T x, y, z, vx, vy, vz;
 };
+
+// wx * wy * wzz as int64: the factors are 15-bit weights (wzz: times a charge number of at most 8 bits), so the
+// first product is a full-rate 24-bit multiply and the second ONE 32 x 32 -> 64 multiply (64-bit integer
+// multiplies are quarter rate on CDNA; written as a chain of them this was a third of the kernel's VALU work)
+__device__ __forceinline__ long long weight3(int wx, int wy, int wzz)
+{
+    return static_cast<long long>(__mul24(wx, wy)) * static_cast<long long>(wzz);
+}
 
 // Where a particle's eight field records come from / its eight weights go to.
 template <typename T>
@@ -132,7 +147,7 @@ struct GlobalGrid {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
-                    const long long w = static_cast<long long>(wx[a]) * wy[b] * wz[c] * Z;
+                    const long long w = weight3(wx[a], wy[b], wz[c] * Z);
                     if (w) atomicAdd(rho + (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)),
                                      static_cast<unsigned long long>(w));
                 }
@@ -154,7 +169,7 @@ __device__ __forceinline__ void load4_lds3(const FPIC_LDS T* p, T (&o)[4])
 }
 
 // The tile's window in LDS, global memory behind it for a particle that has left the window.
-template <typename T>
+template <typename T, int ABL = 0>
 struct WindowGrid {
     GlobalGrid<T> g;
     const FPIC_LDS T* lE;                  // [Win<T>::N][4]
@@ -172,13 +187,14 @@ struct WindowGrid {
         if (n < 0) n += g.nz;
         if (n >= g.nz) n -= g.nz;
         const bool in = l <= Win<T>::X - 2 && m <= Win<T>::Y - 2 && n <= Win<T>::Z - 2;
-        return in ? (n * Win<T>::Y + m) * Win<T>::X + l : -1;
+        return in ? __mul24(__mul24(n, Win<T>::Y) + m, Win<T>::X) + l : -1; // (24-bit multiplies are full rate)
     }
     __device__ __forceinline__ void gather(int i, int j, int k, const T (&fx)[2], const T (&fy)[2], const T (&fz)[2], T& Ex, T& Ey, T& Ez) const
     {
         const int s = slot(i, j, k);
         if (s < 0) { g.gather(i, j, k, fx, fy, fz, Ex, Ey, Ez); return; }
         Ex = Ey = Ez = static_cast<T>(0);
+        if constexpr ((ABL & 2) != 0) { Ex = fx[0] * fy[1]; Ey = fy[0] * fz[1]; Ez = fz[0] * fx[1]; return; }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -197,13 +213,15 @@ struct WindowGrid {
     {
         const int s = slot(i, j, k);
         if (s < 0) { g.deposit(i, j, k, wx, wy, wz, Z); ++*spilled; return; }
+        if constexpr ((ABL & 1) != 0) { *spilled += static_cast<unsigned>(wx[0] * wy[1] * wz[0] == 12345); return; }
+        const int wzz[2] = { __mul24(wz[0], Z), __mul24(wz[1], Z) };
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const long long w = static_cast<long long>(wx[a]) * wy[b] * wz[c] * Z;
+                    const long long w = weight3(wx[a], wy[b], wzz[c]);
                     __hip_atomic_fetch_add(lrho + (s + a + Win<T>::X * b + Win<T>::X * Win<T>::Y * c), static_cast<unsigned long long>(w), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -282,9 +300,11 @@ __device__ __forceinline__ void store_state3(const Push3Args<T>& a, size_t base,
     }
 }
 
+static_assert((kTX & (kTX - 1)) == 0 && (kTY & (kTY - 1)) == 0 && (kTZ & (kTZ - 1)) == 0, "tile edges are powers of two: cell -> tile is a shift");
 __device__ __forceinline__ uint32_t tile_key3(int i, int j, int k, int ntx, int nty)
 {
-    return static_cast<uint32_t>(i / kTX) + static_cast<uint32_t>(ntx) * (static_cast<uint32_t>(j / kTY) + static_cast<uint32_t>(nty) * static_cast<uint32_t>(k / kTZ));
+    const unsigned tx = static_cast<unsigned>(i) / kTX, ty = static_cast<unsigned>(j) / kTY, tz = static_cast<unsigned>(k) / kTZ;
+    return tx + __umul24(static_cast<unsigned>(ntx), ty + __umul24(static_cast<unsigned>(nty), tz));
 }
 
 // Flat form: any particle order, everything through global memory (L2 gathers, 8-byte global
@@ -317,26 +337,72 @@ __global__ __launch_bounds__(256) void push3_flat_kernel(Push3Args<T> a)
     if constexpr (!DEPOSIT_ONLY) store_state3(a, base, cnt, q);
 }
 
+// A workgroup tracks its own tile and the 26 around it (periodic) in LDS when it counts or ranks particles
+// by tile; a particle further away goes to the global tables directly.
+constexpr int kNbr3 = 27;
+struct Neighbourhood3 {
+    int ti, tj, tk, ntx, nty, ntz;
+    // per axis: 0 = own tile, 1 = next, 2 = previous (periodic); -1 = further away
+    static __device__ __forceinline__ int rel(int t, int own, int nt)
+    {
+        int d = t - own;
+        if (d < 0) d += nt;
+        return d == 0 ? 0 : (d == 1 ? 1 : (d == nt - 1 ? 2 : -1));
+    }
+    __device__ __forceinline__ int slot(int i, int j, int k, uint32_t& key) const
+    {
+        const int tx = static_cast<int>(static_cast<unsigned>(i) / kTX), ty = static_cast<int>(static_cast<unsigned>(j) / kTY),
+                  tz = static_cast<int>(static_cast<unsigned>(k) / kTZ);
+        key = static_cast<uint32_t>(tx) + __umul24(static_cast<unsigned>(ntx), static_cast<unsigned>(ty) + __umul24(static_cast<unsigned>(nty), static_cast<unsigned>(tz)));
+        const int rx = rel(tx, ti, ntx), ry = rel(ty, tj, nty), rz = rel(tz, tk, ntz);
+        return (rx | ry | rz) < 0 ? -1 : rx + 3 * (ry + 3 * rz);
+    }
+    // global bin of an LDS slot, or ~0u when two slots would name the same tile (fewer than 3 tiles along an axis)
+    __device__ __forceinline__ uint32_t bin_of_slot(int s) const
+    {
+        const int rx = s % 3, ry = (s / 3) % 3, rz = s / 9;
+        if ((rx == 2 && ntx < 3) || (ry == 2 && nty < 3) || (rz == 2 && ntz < 3)) return ~0u;
+        if ((rx == 1 && ntx < 2) || (ry == 1 && nty < 2) || (rz == 1 && ntz < 2)) return ~0u;
+        const int tx = (ti + (rx == 2 ? ntx - 1 : rx)) % ntx, ty = (tj + (ry == 2 ? nty - 1 : ry)) % nty, tz = (tk + (rz == 2 ? ntz - 1 : rz)) % ntz;
+        return static_cast<uint32_t>(tx) + static_cast<uint32_t>(ntx) * (static_cast<uint32_t>(ty) + static_cast<uint32_t>(nty) * static_cast<uint32_t>(tz));
+    }
+};
+
 template <typename T>
-constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 * sizeof(T) + 8) + 16; }
+constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 * sizeof(T) + 8) + 3 * kNbr3 * sizeof(uint32_t) + 16; }
 
 // Tiled form for binned particles: one workgroup per chunk of one tile's particles.
-template <typename T, bool HAS_B, bool DEPOSIT_ONLY>
-__global__ __launch_bounds__(kPushThreads3) void push3_tiles_kernel(Push3Args<T> a)
+//
+// Every launch also counts the NEW positions per tile (census): the table the next re-binning is
+// laid out from.  REBIN makes this launch the re-binning as well: the bin of a particle is the tile
+// of the position it is LOADED with — exactly what the previous launch's census counted, from which
+// the host has laid out dst_tile_start.  The workgroup first counts its chunk per destination bin
+// (one extra read of x, y, z), reserves ONE range per bin, then pushes and stores each particle at
+// range + rank of arrival in the other particle set: no separate count / scatter passes in steady state.
+//
+// ABL: development probe bits, timing only (scripts/ablate_push3.hip): 1 = no LDS accumulation, 2 = no field
+// gather, 4 = no window staging / flush.  The library instantiates ABL = 0 only.
+template <typename T, bool HAS_B, bool DEPOSIT_ONLY, bool REBIN = false, int THREADS = kPushThreads3, int ABL = 0>
+__global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
 {
+    static_assert(!(REBIN && DEPOSIT_ONLY), "precalc() never re-bins");
     constexpr int PPT = Vec16<T>::N;
     constexpr int kWX = Win<T>::X, kWY = Win<T>::Y, kWN = Win<T>::N, kHalo = Win<T>::H;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     FPIC_LDS T* lE = (FPIC_LDS T*)lds3;
     FPIC_LDS unsigned long long* lrho = (FPIC_LDS unsigned long long*)((FPIC_LDS unsigned char*)lds3 + static_cast<size_t>(kWN) * 4 * sizeof(T));
+    FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lrho + kWN);
+    FPIC_LDS uint32_t* lrank = lcensus + kNbr3;
+    FPIC_LDS uint32_t* lrange = lrank + kNbr3;
     if (blockIdx.x >= *a.nwork) return;
     const BlockWork w = a.work[blockIdx.x];
     const int ti = static_cast<int>(w.tile % a.ntx), tj = static_cast<int>((w.tile / a.ntx) % a.nty), tk = static_cast<int>(w.tile / (a.ntx * a.nty));
     const int ox = ti * kTX - kHalo, oy = tj * kTY - kHalo, oz = tk * kTZ - kHalo;
+    const Neighbourhood3 nb{ ti, tj, tk, a.ntx, a.nty, a.ntz };
     // stage the window: one node record (16 B float / 32 B double) per lane and iteration
     using V = typename NatVec16<T>::type;
     constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
-    for (int s = threadIdx.x; s < kWN; s += kPushThreads3) {
+    for (int s = threadIdx.x; s < ((ABL & 4) ? 0 : kWN); s += THREADS) {
         const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
         const int m = rem / kWX, l = rem - m * kWX;
         int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
@@ -351,16 +417,89 @@ __global__ __launch_bounds__(kPushThreads3) void push3_tiles_kernel(Push3Args<T>
                 *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(src + p * Vec16<T>::N);
         }
     }
+    if (threadIdx.x < 3 * kNbr3) lcensus[threadIdx.x] = 0;
     __syncthreads();
     unsigned my_spill = 0;
-    const WindowGrid<T> grid{ GlobalGrid<T>{ a.E4, a.rho, a.nx, a.ny, a.nz }, lE, lrho, ox, oy, oz, &my_spill };
+    uint32_t census_own = 0;
+    const WindowGrid<T, ABL> grid{ GlobalGrid<T>{ a.E4, a.rho, a.nx, a.ny, a.nz }, lE, lrho, ox, oy, oz, &my_spill };
     const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
     const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
-    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads3) {
+
+    if constexpr (REBIN) {
+        // Pass A: count the chunk's LOADED positions per destination bin, then reserve one range per bin
+        uint32_t own_count = 0;
+        for (size_t g = g_begin + threadIdx.x; g < g_end; g += THREADS) {
+            const size_t base = g * PPT;
+            const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+            T px[PPT], py[PPT], pz[PPT];
+            load_lane<T, PPT>(a.slab + 0 * a.stride, base, px);
+            load_lane<T, PPT>(a.slab + 1 * a.stride, base, py);
+            load_lane<T, PPT>(a.slab + 2 * a.stride, base, pz);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                if (k >= cnt) continue;
+                int i, j, kk, wgt;
+                axis(px[k], a.nx, i, wgt); axis(py[k], a.ny, j, wgt); axis(pz[k], a.nz, kk, wgt);
+                uint32_t key;
+                const int sl = nb.slot(i, j, kk, key);
+                // nearly every particle is still in its own tile: those are counted in a register (64 lanes adding
+                // to ONE LDS word would be serialised), the few leavers by LDS atomics
+                if (sl == 0) ++own_count;
+                else if (sl > 0) __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (own_count) __hip_atomic_fetch_add(lrank, own_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        if (threadIdx.x < kNbr3) {
+            const uint32_t c = lrank[threadIdx.x];
+            uint32_t start = 0;
+            if (c) {
+                const uint32_t bin = nb.bin_of_slot(threadIdx.x);
+                start = a.dst_tile_start[bin] + atomicAdd(a.dst_tile_cursor + bin, c);
+            }
+            lrange[threadIdx.x] = start;
+            lrank[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    }
+
+    for (size_t g = g_begin + threadIdx.x; g < g_end; g += THREADS) {
         const size_t base = g * PPT;
         const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
         P3<T> q[PPT];
+        uint32_t dest[PPT], pid[PPT];
+        int slot_of[PPT];
         load_state3(a, base, cnt, q);
+        if constexpr (REBIN) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                dest[k] = 0; pid[k] = 0; slot_of[k] = -2;
+                if (k >= cnt) continue;
+                pid[k] = a.id[base + k];
+                int i, j, kk, wgt;
+                axis(q[k].x, a.nx, i, wgt); axis(q[k].y, a.ny, j, wgt); axis(q[k].z, a.nz, kk, wgt);
+                uint32_t key;
+                const int sl = nb.slot(i, j, kk, key);
+                slot_of[k] = sl;
+                if (sl > 0) dest[k] = lrange[sl] + __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (sl < 0) dest[k] = a.dst_tile_start[key] + atomicAdd(a.dst_tile_cursor + key, 1u); // beyond the 27 tiles: rare
+            }
+            // stayers: one LDS atomic per wave and k, ranks inside the wave by lane order (consecutive lanes ->
+            // consecutive destinations: the stores below coalesce)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const bool own = k < cnt && slot_of[k] == 0;
+                const unsigned long long mask = __ballot(own);
+                if (mask) {
+                    const int lane = static_cast<int>(threadIdx.x & 63);
+                    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+                    uint32_t wave_base = 0;
+                    if (lane == leader) wave_base = __hip_atomic_fetch_add(lrank, static_cast<uint32_t>(__popcll(mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    wave_base = __shfl(wave_base, leader);
+                    if (own) dest[k] = lrange[0] + wave_base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             if (k >= cnt) continue;
@@ -373,13 +512,31 @@ __global__ __launch_bounds__(kPushThreads3) void push3_tiles_kernel(Push3Args<T>
                 grid.deposit(ni, nj, nk, wx, wy, wz, a.Z);
             } else {
                 substep3<T, HAS_B>(q[k], a, grid, ni, nj, nk);
+                // census of the new positions per tile
+                uint32_t key;
+                const int sl = nb.slot(ni, nj, nk, key);
+                if (sl == 0) ++census_own;      // (own tile: a register, see pass A)
+                else if (sl > 0) __hip_atomic_fetch_add(lcensus + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else atomicAdd(a.tile_count + key, 1u);
             }
         }
-        if constexpr (!DEPOSIT_ONLY) store_state3(a, base, cnt, q);
+        if constexpr (REBIN) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                if (k >= cnt) continue;
+                const size_t d = dest[k];
+                a.dst_slab[0 * a.stride + d] = q[k].x; a.dst_slab[1 * a.stride + d] = q[k].y; a.dst_slab[2 * a.stride + d] = q[k].z;
+                a.dst_slab[3 * a.stride + d] = q[k].vx; a.dst_slab[4 * a.stride + d] = q[k].vy; a.dst_slab[5 * a.stride + d] = q[k].vz;
+                a.dst_id[d] = pid[k];
+            }
+        } else if constexpr (!DEPOSIT_ONLY) {
+            store_state3(a, base, cnt, q);
+        }
     }
+    if (census_own) __hip_atomic_fetch_add(lcensus, census_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     // flush the non-zero accumulators: consecutive lanes take consecutive slots of one window row
-    for (int s = threadIdx.x; s < kWN; s += kPushThreads3) {
+    for (int s = threadIdx.x; s < ((ABL & 4) ? 0 : kWN); s += THREADS) {
         const unsigned long long v = lrho[s];
         if (v == 0ull) continue;
         const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
@@ -389,6 +546,13 @@ __global__ __launch_bounds__(kPushThreads3) void push3_tiles_kernel(Push3Args<T>
         if (gj < 0) gj += a.ny;
         if (gk < 0) gk += a.nz;
         atomicAdd(a.rho + (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)), v);
+    }
+    if constexpr (!DEPOSIT_ONLY) {
+        if (threadIdx.x < kNbr3) {
+            const uint32_t c = lcensus[threadIdx.x];
+            const uint32_t bin = nb.bin_of_slot(threadIdx.x);
+            if (c && bin != ~0u) atomicAdd(a.tile_count + bin, c);
+        }
     }
     if (my_spill) atomicAdd(a.spilled, static_cast<unsigned long long>(my_spill));
 }

@@ -1295,7 +1295,7 @@ int fpic_get_stats(fpic_handle* h, fpic_stats* out)
     out->step_launches = h->step_launches;
     out->deposit_launches = h->deposit_launches;
     out->sort_passes = h->sort_passes;
-    out->deposit_spilled = h->last_spill;
+    out->deposit_spilled = h->es ? fes::last_spill(h) : h->last_spill;
     out->ms_push = h->ms[KC_PUSH];
     out->ms_deposit = h->ms[KC_DEPOSIT];
     out->ms_stamp = h->ms[KC_STAMP];

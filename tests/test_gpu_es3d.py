@@ -51,16 +51,19 @@ def assert_same_particles(sim, ora, species=0, what=""):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
-@pytest.mark.parametrize("shape,n,with_b", [((16, 16, 8), 4000, False), ((40, 24, 20), 20001, True), ((12, 10, 6), 999, True),
-                                            ((64, 32, 32), 50003, False)])
-def test_push_and_deposit_bit_exact_in_a_given_field(fp, eo, precision, shape, n, with_b):
+@pytest.mark.parametrize("shape,n,with_b,sort_interval", [((16, 16, 8), 4000, False, 0), ((40, 24, 20), 20001, True, 1), ((12, 10, 6), 999, True, 2),
+                                                          ((64, 32, 32), 50003, False, 1), ((48, 48, 24), 30002, True, 3),
+                                                          ((32, 16, 8), 7, False, 1)])
+def test_push_and_deposit_bit_exact_in_a_given_field(fp, eo, precision, shape, n, with_b, sort_interval):
     """solver 'none': a random static E, uniform B; every sub-step's particles, cells and charge grid are
     bit-identical to the oracle's (flat path at precalc(), tiled path afterwards, re-binning in between;
-    grids smaller than, equal to and not a multiple of the 16x16x8 tile; counts not a multiple of 4)."""
+    grids smaller than, equal to and not a multiple of the 16x16x8 tile; counts not a multiple of 4;
+    sort_interval 1..3: the re-binning fused into the push runs every, every second, every third sub-step)."""
     rng = np.random.default_rng(n)
     L = (0.02, 0.015, 0.01)
     spec = box_spec(shape, L, count=n, dt=2e-11, solver="none", macro_weight=2e4)
-    sim, ora = make_pair(fp, eo, spec, precision)
+    dtype = np.float32 if precision == "fp32" else np.float64
+    sim, ora = fp.makeCylindricalParticlePusher(spec, precision=precision, sort_interval=sort_interval), eo.OracleES3D(spec, dtype)
     pos = rng.random((n, 3)) * L
     pos[:6] = [[0, 0, 0], [L[0], L[1], L[2]], [L[0] * (1 - 1e-9), 0, 0], [-0.001, 0.02, 0.0101], [L[0] / shape[0], L[1] / shape[1], 0],
                [L[0] * 0.5, L[1] * 0.999999, L[2] * 0.5]]
@@ -83,6 +86,8 @@ def test_push_and_deposit_bit_exact_in_a_given_field(fp, eo, precision, shape, n
     assert same_bits(sim.readField(fp.F3_RHO), ora.rho)
     st = sim.stats()
     assert st["particle_updates"] == 6 * n and st["sort_passes"] >= 1
+    if sort_interval:
+        assert st["sort_passes"] == 1 + 5 // sort_interval
     sim.destroy()
 
 

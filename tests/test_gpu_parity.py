@@ -84,7 +84,7 @@ def assert_particles_equal(sim, ora, exact=True, rtol=0.0, rand=True):
 def test_library_reports_gfx950(fp):
     lib = fp.load_library()
     assert lib.fpic_build_arch() == b"gfx950"
-    assert lib.fpic_abi_version() == 1
+    assert lib.fpic_abi_version() == 2
 
 
 def test_upload_matches_reference_host_js(fp):
