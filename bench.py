@@ -324,6 +324,12 @@ def main():
                     help="reference = the reference's entropy-table generator (the drop-in, the headline); "
                          "counter = the Philox extension mode (SURVEY.md 8(d))")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: all-reduce on the pusher's stream, no overlap")
+    ap.add_argument("--total-particles", type=float, default=0,
+                    help="strong scaling: this many particles in total, split over the ranks by contiguous index ranges "
+                         "(fusionpic.multi.shard_bounds); default 0 = weak scaling with --side^2 particles per GPU")
+    ap.add_argument("--comm", choices=["lib", "torch"], default="lib",
+                    help="multi-GPU exchange: lib = the library's own RCCL communicator (fpic_comm_*, what a JavaScript host uses); "
+                         "torch = torch.distributed all-reduce on the buffer's device address (fusionpic.multi.ShardedPusher)")
     ap.add_argument("--c3-particles", type=int, default=500_000_000, help="extensions.c3: particles of the electrostatic box (BASELINE configs[2]: 5e8)")
     ap.add_argument("--c3-grid", type=int, default=256, help="extensions.c3: nodes per axis (BASELINE configs[2]: 256)")
     ap.add_argument("--only-c3", action="store_true", help="development: measure extensions.c3 alone and print it")
@@ -362,6 +368,12 @@ def main():
     spec = dict(radius=1.0, height=1.0, nr=args.grid, nz=args.grid, dt=2e-9, nparticles=args.side,
                 particle_mass=1.67e-27, particle_charge=1.602e-19)
     n_local = args.side * args.side
+    strong = args.total_particles > 0
+    if strong:  # a fixed population, sharded by contiguous index ranges
+        from fusionpic.multi import shard_bounds
+        lo, hi = shard_bounds(int(args.total_particles), rank, world)
+        n_local = hi - lo
+        spec["nparticles"] = 1
     # every rank draws its own shard of the global particle population
     pos, vel, entropy, rand = synthetic_inputs(n_local, spec, 0x5EEDF051 + 7919 * rank)
     if distributed:  # replicated tables must be identical on every rank
@@ -373,7 +385,7 @@ def main():
     def build(rng_mode):
         # counter mode: no gather hides the LDS atomics of the fused sums, so only the tile census and
         # the re-binning stay in the push there (spec.unfused_deposit = 2)
-        s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051,
+        s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051, count=n_local if strong else 0,
                                               fuse_deposit="census" if rng_mode == "counter" else True)
         s_.setStream(stream.cuda_stream)
         s_.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
@@ -387,18 +399,23 @@ def main():
     sim.sort()  # first binning of the randomly ordered upload belongs to setup, like the upload itself
 
     sharded = None
-    if distributed:
+    if distributed and args.comm == "lib":
+        # the library's own communicator: rank 0 draws the RCCL id, the host hands it round (here over the
+        # launcher's process group; a JavaScript host uses a file or its own channel), and density() then
+        # all-reduces the per-cell sums inside libfusionpic.so on a side stream, overlapped with the next push
+        box = [fp.commUniqueId() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        sim.commInit(box[0], rank, world, overlap=not args.no_overlap)
+    elif distributed:
         from fusionpic.multi import ShardedPusher, device_tensor_view
         ptr, nbytes = sim.deviceBuffer()
         sums = device_tensor_view(ptr, nbytes, torch.device("cuda", local_rank))
-        # density() = scatter, then on a side stream: RCCL all-reduce of a copy of the sums and the finish
-        # stage, overlapped with the next frame's push
         sharded = ShardedPusher(sim, sums, stream=stream, overlap=not args.no_overlap)
 
     def cycle():
         sim.precalc()
         sim.step()
-        if distributed:
+        if sharded is not None:
             sharded.density()
         else:
             sim.density()
@@ -430,7 +447,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        n_total = n_local * world
+        n_total = int(args.total_particles) if strong else n_local * world
         updates = 2.0 * n_total * args.steps
         push_ms = st["ms_push"] / max(1, st["step_launches"])
         achieved = ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (push_ms * 1e-3) / 1e9 if push_ms > 0 else 0.0
@@ -440,14 +457,16 @@ def main():
             "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "2D axisymmetric (r,z) %dx%d grid, %.0e particles per GPU, single species, reference stamp "
                             "(11x11) deposit, uniform Bz=0.01 T, one step = precalc()+step()[2 sub-steps]+density()"
                             % (spec["nr"], spec["nz"], n_local),
                 "particles_per_gpu": n_local, "grid": [spec["nr"], spec["nz"]],
-                "parallelism": "particle shards x%d, replicated grid, all-reduce of cell sums" % world,
+                "parallelism": "particle shards x%d (%s), replicated grid, one all-reduce of the per-cell sums per frame (%s)"
+                               % (world, "fixed total of %d" % n_total if strong else "fixed per GPU",
+                                  "library RCCL communicator" if args.comm == "lib" else "torch.distributed"),
             },
             "roofline": {
                 "bound": "hbm",

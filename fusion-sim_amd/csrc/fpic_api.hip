@@ -9,6 +9,7 @@
 #include "fpic_push.hpp"
 #include "fpic_injection.hpp"
 #include "fes_api.hpp"
+#include "fpic_comm.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -518,6 +519,7 @@ void release(fpic_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    fcomm::release(h);
     fes::release(h);
     for (int s = 0; s < 2; ++s) {
         if (h->slab[s]) (void)hipFree(h->slab[s]);
@@ -1070,9 +1072,38 @@ int fpic_density_finish_from(fpic_handle* h, const void* sums, void* hip_stream)
     return h->prec == FPIC_F32 ? launch_stamp_finish<float>(h, sums, on) : launch_stamp_finish<double>(h, sums, on);
 }
 
+// density() of a rank of a sharded run: scatter, all-reduce (sum) of the per-cell sums over the ranks, finish
+static int density_reduced(fpic_handle* h)
+{
+    fcomm::Comm* c = h->comm;
+    const fdyn::Rccl& rc = fdyn::rccl();
+    const size_t count = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1) * 4;
+    const ncclDataType_t dt = h->prec == FPIC_F32 ? ncclFloat : ncclDouble;
+    if (!c->overlap) {
+        if (int e = fcomm::check(h, rc.AllReduce(h->cell_sums, h->cell_sums, count, dt, ncclSum, c->nccl, h->stream), "ncclAllReduce")) return e;
+        return fpic_density_finish(h);
+    }
+    if (!c->buf) {
+        c->buf_bytes = count * h->esize;
+        HIP_TRY(h, hipMalloc(&c->buf, c->buf_bytes));
+    }
+    // the previous frame's finish stage still reads buf: the copy waits for it, nothing else on the handle's stream does
+    if (c->reduce_pending) HIP_TRY(h, hipStreamWaitEvent(h->stream, c->reduced, 0));
+    HIP_TRY(h, hipMemcpyAsync(c->buf, h->cell_sums, c->buf_bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipEventRecord(c->copied, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(c->side, c->copied, 0));
+    if (int e = fcomm::check(h, rc.AllReduce(c->buf, c->buf, count, dt, ncclSum, c->nccl, c->side), "ncclAllReduce")) return e;
+    const int rcode = h->prec == FPIC_F32 ? launch_stamp_finish<float>(h, c->buf, c->side) : launch_stamp_finish<double>(h, c->buf, c->side);
+    if (rcode) return rcode;
+    HIP_TRY(h, hipEventRecord(c->reduced, c->side));
+    c->reduce_pending = true;
+    return FPIC_OK;
+}
+
 int fpic_density(fpic_handle* h)
 {
     if (int rc = fpic_deposit(h)) return rc;
+    if (h->comm && !h->es) return density_reduced(h);
     return fpic_density_finish(h);
 }
 

@@ -40,6 +40,7 @@ ABI_FUNCTIONS = [
     "fpic_get_substep_counter", "fpic_set_substep_counter", "fpic_save_checkpoint", "fpic_load_checkpoint",
     "fpic_add_species", "fpic_set_particles_of", "fpic_get_particles_of", "fpic_get_cells_of", "fpic_add_b",
     "fpic_set_field3", "fpic_read_field3", "fpic_set_particles_range",
+    "fpic_comm_unique_id", "fpic_comm_init", "fpic_comm_destroy", "fpic_comm_info", "fpic_comm_set_overlap",
 ]
 
 
@@ -126,6 +127,11 @@ def load_library(path=None):
     lib.fpic_set_substep_counter.argtypes = [vp, ctypes.c_uint64]
     lib.fpic_save_checkpoint.argtypes = [vp, ctypes.c_char_p]
     lib.fpic_load_checkpoint.argtypes = [vp, ctypes.c_char_p]
+    lib.fpic_comm_unique_id.argtypes = [vp]
+    lib.fpic_comm_init.argtypes = [vp, vp, ci, ci]
+    lib.fpic_comm_destroy.argtypes = [vp]
+    lib.fpic_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.fpic_comm_set_overlap.argtypes = [vp, ci]
     lib.fpic_add_species.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.POINTER(ci)]
     lib.fpic_set_particles_of.argtypes = [vp, ci, vp, vp, ctypes.c_uint64, ci]
     lib.fpic_get_particles_of.argtypes = [vp, ci, vp, vp, ci]
@@ -350,6 +356,21 @@ class CylindricalParticlePusher:
     def sort(self):
         self._check(self._lib.fpic_sort(self._h))
 
+    # ---- multi-GPU: the library's own RCCL communicator (include/fusionpic.h, fpic_comm_*)
+    def commInit(self, unique_id, rank, world, overlap=True):
+        """unique_id: the 128 bytes rank 0 obtained from commUniqueId(), handed to every rank by the host"""
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.fpic_comm_init(self._h, buf, int(rank), int(world)))
+        self._check(self._lib.fpic_comm_set_overlap(self._h, 1 if overlap else 0))
+
+    def commDestroy(self):
+        self._check(self._lib.fpic_comm_destroy(self._h))
+
+    def commInfo(self):
+        r, w = ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.fpic_comm_info(self._h, ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
+
     def sync(self):
         self._check(self._lib.fpic_sync(self._h))
 
@@ -416,6 +437,9 @@ class ElectrostaticBoxPusher:
     density = CylindricalParticlePusher.density
     addBZ = CylindricalParticlePusher.addBZ
     deviceBuffer = CylindricalParticlePusher.deviceBuffer
+    commInit = CylindricalParticlePusher.commInit
+    commDestroy = CylindricalParticlePusher.commDestroy
+    commInfo = CylindricalParticlePusher.commInfo
 
     def addSpecies(self, mass, charge, count):
         idx = ctypes.c_int()
@@ -478,6 +502,16 @@ class ElectrostaticBoxPusher:
         out = np.empty(self.nodes * (4 if which == F3_E else 1), dtype=_np_dtype(code))
         self._check(self._lib.fpic_read_field3(self._h, which, out.ctypes.data, code))
         return out.reshape(self.nodes, 4) if which == F3_E else out
+
+
+def commUniqueId(library=None):
+    """ncclGetUniqueId through the library (rank 0); 128 bytes for commInit on every rank"""
+    lib = library or load_library()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.fpic_comm_unique_id(buf)
+    if rc != 0:
+        raise FusionPicError(rc, lib.fpic_last_error(None).decode())
+    return buf.raw
 
 
 def makeCylindricalParticlePusher(spec, **extensions):

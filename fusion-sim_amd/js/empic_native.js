@@ -26,6 +26,11 @@
  * (default true; 'census' keeps only the tile census and re-binning in step()), rng 'reference'|'counter' + seed (counter = Philox4x32-10 per particle
  * and sub-step instead of the reference's entropy-table generator; not the reference's
  * random stream).
+ * geometry 'cart3d' (+ ny, length_y, solver 'poisson_fft'|'none', macro_weight) selects the self-consistent
+ * electrostatic box — an extension with no reference counterpart (include/fusionpic.h): radius, height are
+ * then the box lengths along x and z, nr, nz the node counts; same method names, plus addSpecies, addB,
+ * readField.  Multi-GPU (one process per GPU): empic.commUniqueId() on rank 0, simulation.commInit(id,
+ * rank, world) on every rank; density() then sums the per-cell sums over the ranks inside the library (RCCL).
  */
 'use strict';
 const path = require('path');
@@ -113,13 +118,77 @@ function flattenParticles(value, n, name) {
     return out;
 }
 
+const FIELD3 = { E: 0, rho: 1, phi: 2, rho_fixed: 3 };
+
+// spec.geometry === 'cart3d': the electrostatic box behind the same method names
+function makeBox(spec, lib) {
+    validate_object(spec, { ny: 'number', length_y: 'number', solver: [, 'string'], macro_weight: [, 'number'] });
+    if (spec.solver !== undefined && spec.solver !== 'poisson_fft' && spec.solver !== 'none') throw new Error(".solver <- must be 'poisson_fft' or 'none'");
+    const fp64 = spec.precision === 'fp64';
+    const n0 = spec.count ? spec.count : spec.nparticles * spec.nparticles;
+    let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass, spec.particle_charge,
+        spec.count || 0, fp64 ? 1 : 0, spec.device || 0, 0, spec.sort_interval || 0, 0, 0, 0, 0,
+        1, spec.solver === 'none' ? 0 : 1, spec.ny, spec.length_y, spec.macro_weight === undefined ? 1 : spec.macro_weight);
+    const nx = spec.nr, ny = spec.ny, nz = spec.nz, nodes = nx * ny * nz;
+    const counts = [n0];
+    const Real = fp64 ? Float64Array : Float32Array;
+    const out = {};
+    out.addSpecies = function (mass, charge, count) { const s = lib.addSpecies(h, mass, charge, count); counts.push(count); return s; };
+    out.set = function (value, species) {                                      // empic.js:1157: position [N][3] m, velocity [N][3] in c
+        const sp = species || 0, n = counts[sp];
+        if (value.position) lib.setParticlesRange(h, sp, 0, flattenParticles(value.position, n, 'position'), null);
+        if (value.velocity) lib.setParticlesRange(h, sp, 0, null, flattenParticles(value.velocity, n, 'velocity'));
+        if (value.E) {
+            let e = value.E;
+            if (!isFloatArray(e)) {                                           // value[i][j][k][3]
+                e = new Float64Array(3 * nodes);
+                for (let i = 0; i < nx; i++) for (let j = 0; j < ny; j++) for (let k = 0; k < nz; k++)
+                    for (let c = 0; c < 3; c++) e[3 * ((i * ny + j) * nz + k) + c] = value.E[i][j][k][c];
+            }
+            lib.setField3(h, FIELD3.E, checkLength(e, 3 * nodes, 'E'), nx, ny, nz);
+        }
+    };
+    out.setRange = function (first, value, species) { lib.setParticlesRange(h, species || 0, first, value.position || null, value.velocity || null); };
+    out.addBZ = function (Bz) { lib.addBZ(h, Bz); };                           // empic.js:1391
+    out.addB = function (bx, by, bz) { lib.addB(h, bx, by, bz); };
+    out.precalc = function () { lib.precalc(h); };                             // empic.js:1413: fields <- particles (deposit + solve)
+    out.step = function (ncalls) { lib.step(h, ncalls === undefined ? 1 : ncalls); };  // empic.js:1436: 2 sub-steps
+    out.density = function () { lib.density(h); };                             // empic.js:1471: the charge density is always current
+    out.readField = function (name, buf) {
+        if (!(name in FIELD3)) throw new Error('.name <- unknown field ' + name);
+        const len = nodes * (name === 'E' ? 4 : 1);
+        const fresh = name === 'rho_fixed' ? new BigInt64Array(len) : new Real(len);
+        return lib.readField3(h, FIELD3[name], checkLength(buf, len, 'out') || fresh);
+    };
+    out.getParticles = function (into, species) {
+        const sp = species || 0, n = counts[sp];
+        const r = into || { position: new Real(3 * n), velocity: new Real(3 * n) };
+        checkLength(r.position, 3 * n, 'position'); checkLength(r.velocity, 3 * n, 'velocity');
+        lib.getParticlesOf(h, sp, r.position || null, r.velocity || null);
+        return r;
+    };
+    out.getCells = function (buf, species) { const n = counts[species || 0]; return lib.getCellsOf(h, species || 0, checkLength(buf, n, 'cells') || new Int32Array(n)); };
+    out.commInit = function (id, rank, world, overlap) { lib.commInit(h, id, rank, world, overlap === false ? 0 : 1); };
+    out.commDestroy = function () { lib.commDestroy(h); };
+    out.sort = function () { lib.sort(h); };
+    out.sync = function () { lib.sync(h); };
+    out.profile = function (on) { lib.profile(h, on ? 1 : 0); };
+    out.stats = function () { return lib.getStats(h); };
+    out.resetStats = function () { lib.resetStats(h); };
+    out.destroy = function () { if (h) { lib.destroy(h); h = null; } };
+    out.nparticles = n0;
+    return out;
+}
+
 exports.makeCylindricalParticlePusher = function (spec) {
     validate_object(spec, {           // empic.js:31-41
         radius: 'number', height: 'number', nr: 'number', nz: 'number', dt: 'number',
         nparticles: 'number', particle_mass: 'number', particle_charge: 'number',
         precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
-        sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'],
+        sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'], geometry: [, 'string'],
     });
+    if (spec.geometry !== undefined && spec.geometry !== 'cyl_rz' && spec.geometry !== 'cart3d') throw new Error(".geometry <- must be 'cyl_rz' or 'cart3d'");
+    if (spec.geometry === 'cart3d') return makeBox(spec, addon());
     // two admissible types: checked by hand, the reference's validator stops at the first alternative
     if (spec.fuse_deposit !== undefined && typeof spec.fuse_deposit !== 'boolean' && spec.fuse_deposit !== 'census') {
         throw new Error(".fuse_deposit <- must be true, false or 'census'");
@@ -137,7 +206,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass,
         spec.particle_charge, spec.count || 0, fp64 ? 1 : 0, spec.device || 0, spec.compat === false ? 1 : 0,
         spec.sort_interval || 0, spec.fuse_deposit === 'census' ? 2 : (spec.fuse_deposit === false ? 1 : 0), spec.rng === 'counter' ? 1 : 0,
-        seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296);
+        seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296, 0, 0, 0, 0, 0);
     const nr = spec.nr, nz = spec.nz;
     const Real = fp64 ? Float64Array : Float32Array;
     const out = {};
@@ -184,6 +253,8 @@ exports.makeCylindricalParticlePusher = function (spec) {
         const f32 = function (a) { return a === undefined || a === null ? null : (a instanceof Float32Array ? a : Float32Array.from(a)); };
         lib.setRandomState(h, checkLength(f32(state.entropy), 4 * 1024 * 1024, 'entropy'), checkLength(f32(state.rand), 4 * n, 'rand'));
     };
+    out.commInit = function (id, rank, world, overlap) { lib.commInit(h, id, rank, world, overlap === false ? 0 : 1); };
+    out.commDestroy = function () { lib.commDestroy(h); };
     out.saveCheckpoint = function (path) { lib.saveCheckpoint(h, String(path)); };
     out.loadCheckpoint = function (path) { lib.loadCheckpoint(h, String(path)); };
     out.sort = function () { lib.sort(h); };
@@ -199,3 +270,4 @@ exports.makeCylindricalParticlePusher = function (spec) {
 exports.validate_object = validate_object;
 exports._addon = addon; // shared with matrix_native.js
 exports.buildArch = function () { return addon().buildArch(); };
+exports.commUniqueId = function () { return addon().commUniqueId(); };   // rank 0; hand the 128 bytes to every rank

@@ -31,10 +31,15 @@
         }                                                                         \
     } while (0)
 
+#define MAX_SPECIES 16
 typedef struct {
     fpic_handle* h;
     size_t n;     /* particle count of the handle: every typed array is checked against the */
     size_t cells; /* size the ABI call will read or write before its pointer is passed on   */
+    /* CART3D extension: node count and the particle count of every species */
+    size_t nodes;
+    int nspecies;
+    size_t count[MAX_SPECIES];
 } box_t;
 
 static void box_finalize(napi_env env, void* data, void* hint)
@@ -131,13 +136,13 @@ static napi_value undefined(napi_env env)
 }
 
 /* create(radius, height, nr, nz, dt, nparticles, mass, charge, count, precision, device, physical_a,
- *        sort_interval, unfused_deposit, rng_mode, seed_lo, seed_hi) */
+ *        sort_interval, unfused_deposit, rng_mode, seed_lo, seed_hi, geometry, solver, ny, length_y, macro_weight) */
 static napi_value n_create(napi_env env, napi_callback_info info)
 {
-    napi_value argv[17];
-    if (!get_args(env, info, 17, argv, NULL)) return NULL;
-    double d[17];
-    for (int i = 0; i < 17; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
+    napi_value argv[22];
+    if (!get_args(env, info, 22, argv, NULL)) return NULL;
+    double d[22];
+    for (int i = 0; i < 22; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
     fpic_spec s;
     memset(&s, 0, sizeof s);
     s.radius = d[0]; s.height = d[1]; s.nr = (int32_t)d[2]; s.nz = (int32_t)d[3]; s.dt = d[4];
@@ -145,6 +150,7 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     s.count = (uint64_t)d[8]; s.precision = (int32_t)d[9]; s.device = (int32_t)d[10];
     s.physical_a = (int32_t)d[11]; s.sort_interval = (int32_t)d[12]; s.unfused_deposit = (int32_t)d[13];
     s.rng_mode = (int32_t)d[14]; s.rng_seed_lo = (uint32_t)d[15]; s.rng_seed_hi = (uint32_t)d[16];
+    s.geometry = (int32_t)d[17]; s.solver = (int32_t)d[18]; s.ny = (int32_t)d[19]; s.length_y = d[20]; s.macro_weight = d[21];
     fpic_handle* h = NULL;
     if (fpic_create(&s, &h) != FPIC_OK) return throw_fpic(env, NULL);
     box_t* b = (box_t*)malloc(sizeof *b);
@@ -152,6 +158,9 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     b->h = h;
     b->n = s.count ? (size_t)s.count : (size_t)s.nparticles * (size_t)s.nparticles;
     b->cells = (size_t)s.nr * (size_t)s.nz;
+    b->nodes = b->cells * (size_t)(s.ny > 0 ? s.ny : 1);
+    b->nspecies = 1;
+    b->count[0] = b->n;
     napi_value ext;
     if (napi_create_external(env, b, box_finalize, NULL, &ext) != napi_ok) {
         box_finalize(env, b, NULL);
@@ -373,6 +382,159 @@ static napi_value n_get_stats(napi_env env, napi_callback_info info)
     return o;
 }
 
+/* ---- CART3D extension (include/fusionpic.h, "extension: spec.geometry") ---- */
+static int get_species(napi_env env, napi_value v, int* sp)
+{
+    double d;
+    if (!get_double(env, v, &d)) return 0;
+    if (d < 0 || d >= g_box->nspecies) { napi_throw_range_error(env, NULL, ".species <- no such species"); return 0; }
+    *sp = (int)d;
+    return 1;
+}
+
+/* addSpecies(h, mass, charge, count) -> index */
+static napi_value n_add_species(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4]; fpic_handle* h; double m, q, c;
+    if (!get_args(env, info, 4, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &m) || !get_double(env, argv[2], &q) || !get_double(env, argv[3], &c)) return NULL;
+    if (g_box->nspecies >= MAX_SPECIES) { napi_throw_range_error(env, NULL, ".species <- too many species"); return NULL; }
+    int idx = 0;
+    if (fpic_add_species(h, m, q, (uint64_t)c, &idx) != FPIC_OK) return throw_fpic(env, h);
+    g_box->count[g_box->nspecies++] = (size_t)c;
+    napi_value out;
+    NAPI_OK(env, napi_create_int32(env, idx, &out));
+    return out;
+}
+
+/* setParticlesRange(h, species, first, position|null, velocity|null): the caller's particles [first, first + len/3) */
+static napi_value n_set_particles_range(napi_env env, napi_callback_info info)
+{
+    napi_value argv[5]; fpic_handle* h; int sp; double first;
+    if (!get_args(env, info, 5, argv, &h)) return NULL;
+    if (!get_species(env, argv[1], &sp) || !get_double(env, argv[2], &first)) return NULL;
+    napi_typedarray_type t[2]; void* p[2]; size_t len[2]; int dtype = -1;
+    for (int k = 0; k < 2; ++k) {
+        if (!get_typed(env, argv[3 + k], &t[k], &p[k], &len[k])) return NULL;
+        if (!p[k]) continue;
+        int d2;
+        if (!float_dtype(env, t[k], &d2)) return NULL;
+        if (dtype >= 0 && d2 != dtype) { napi_throw_type_error(env, NULL, "position and velocity must have the same element type"); return NULL; }
+        dtype = d2;
+        if (len[k] % 3) { napi_throw_range_error(env, NULL, ".position <- length must be a multiple of 3"); return NULL; }
+    }
+    if (dtype < 0) return undefined(env);
+    if (p[0] && p[1] && len[0] != len[1]) { napi_throw_range_error(env, NULL, ".velocity <- must be as long as .position"); return NULL; }
+    const size_t m = (p[0] ? len[0] : len[1]) / 3;
+    if (first < 0 || (size_t)first > g_box->count[sp] || m > g_box->count[sp] - (size_t)first) {
+        napi_throw_range_error(env, NULL, ".position <- range lies outside the species");
+        return NULL;
+    }
+    if (fpic_set_particles_range(h, sp, (uint64_t)first, m, p[0], p[1], dtype) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* getParticlesOf(h, species, position|null, velocity|null) */
+static napi_value n_get_particles_of(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4]; fpic_handle* h; int sp;
+    if (!get_args(env, info, 4, argv, &h)) return NULL;
+    if (!get_species(env, argv[1], &sp)) return NULL;
+    napi_typedarray_type t[2]; void* p[2]; size_t len[2]; int dtype = FPIC_F32, have = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (!get_typed(env, argv[2 + k], &t[k], &p[k], &len[k])) return NULL;
+        if (!p[k]) continue;
+        int d2;
+        if (!float_dtype(env, t[k], &d2)) return NULL;
+        if (have && d2 != dtype) { napi_throw_type_error(env, NULL, "position and velocity must have the same element type"); return NULL; }
+        dtype = d2; have = 1;
+        if (!check_len(env, k == 0 ? "position" : "velocity", len[k], 3 * g_box->count[sp])) return NULL;
+    }
+    if (fpic_get_particles_of(h, sp, p[0], p[1], dtype) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+static napi_value n_get_cells_of(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; fpic_handle* h; int sp;
+    if (!get_args(env, info, 3, argv, &h)) return NULL;
+    if (!get_species(env, argv[1], &sp)) return NULL;
+    napi_typedarray_type t; void* p; size_t len;
+    if (!get_typed(env, argv[2], &t, &p, &len)) return NULL;
+    if (!p || t != napi_int32_array) { napi_throw_type_error(env, NULL, "expected an Int32Array"); return NULL; }
+    if (!check_len(env, "cells", len, g_box->count[sp])) return NULL;
+    if (fpic_get_cells_of(h, sp, (int32_t*)p) != FPIC_OK) return throw_fpic(env, h);
+    return argv[2];
+}
+
+static napi_value n_add_b(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4]; fpic_handle* h; double x, y, z;
+    if (!get_args(env, info, 4, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &x) || !get_double(env, argv[2], &y) || !get_double(env, argv[3], &z)) return NULL;
+    if (fpic_add_b(h, x, y, z) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* setField3(h, which, data, nx, ny, nz) */
+static napi_value n_set_field3(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6]; fpic_handle* h; double which, nx, ny, nz;
+    if (!get_args(env, info, 6, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &which) || !get_double(env, argv[3], &nx) || !get_double(env, argv[4], &ny) || !get_double(env, argv[5], &nz)) return NULL;
+    napi_typedarray_type t; void* data; size_t len; int dtype;
+    if (!get_typed(env, argv[2], &t, &data, &len)) return NULL;
+    if (!data) { napi_throw_type_error(env, NULL, "expected a typed array"); return NULL; }
+    if (!float_dtype(env, t, &dtype)) return NULL;
+    if (!check_len(env, "E", len, (size_t)(nx * ny * nz * 3))) return NULL;
+    if (fpic_set_field3(h, (int)which, data, (int)nx, (int)ny, (int)nz, dtype) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* readField3(h, which, out): Float32Array / Float64Array, or BigInt64Array for the fixed-point charge grid */
+static napi_value n_read_field3(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; fpic_handle* h; double which;
+    if (!get_args(env, info, 3, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &which)) return NULL;
+    napi_typedarray_type t; void* data; size_t len; int dtype = FPIC_F32;
+    if (!get_typed(env, argv[2], &t, &data, &len)) return NULL;
+    if (!data) { napi_throw_type_error(env, NULL, "expected a typed array"); return NULL; }
+    if ((int)which == FPIC_F3_RHO_FIXED) {
+        if (t != napi_bigint64_array) { napi_throw_type_error(env, NULL, "expected a BigInt64Array"); return NULL; }
+    } else if (!float_dtype(env, t, &dtype)) return NULL;
+    if (!check_len(env, "out", len, g_box->nodes * ((int)which == FPIC_F3_E ? 4 : 1))) return NULL;
+    if (fpic_read_field3(h, (int)which, data, dtype) != FPIC_OK) return throw_fpic(env, h);
+    return argv[2];
+}
+
+/* ---- multi-GPU: the library's RCCL communicator ---- */
+static napi_value n_comm_unique_id(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    void* data = NULL; napi_value ab, out;
+    NAPI_OK(env, napi_create_arraybuffer(env, FPIC_UNIQUE_ID_BYTES, &data, &ab));
+    if (fpic_comm_unique_id(data) != FPIC_OK) return throw_fpic(env, NULL);
+    NAPI_OK(env, napi_create_typedarray(env, napi_uint8_array, FPIC_UNIQUE_ID_BYTES, ab, 0, &out));
+    return out;
+}
+
+/* commInit(h, id Uint8Array(128), rank, world, overlap) */
+static napi_value n_comm_init(napi_env env, napi_callback_info info)
+{
+    napi_value argv[5]; fpic_handle* h; double rank, world, overlap;
+    if (!get_args(env, info, 5, argv, &h)) return NULL;
+    napi_typedarray_type t; void* id; size_t len;
+    if (!get_typed(env, argv[1], &t, &id, &len)) return NULL;
+    if (!id || t != napi_uint8_array) { napi_throw_type_error(env, NULL, "expected a Uint8Array"); return NULL; }
+    if (!check_len(env, "id", len, FPIC_UNIQUE_ID_BYTES)) return NULL;
+    if (!get_double(env, argv[2], &rank) || !get_double(env, argv[3], &world) || !get_double(env, argv[4], &overlap)) return NULL;
+    if (fpic_comm_init(h, id, (int)rank, (int)world) != FPIC_OK) return throw_fpic(env, h);
+    if (fpic_comm_set_overlap(h, (int)overlap) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+SIMPLE_CALL(n_comm_destroy, fpic_comm_destroy)
+
 static napi_value n_build_arch(napi_env env, napi_callback_info info)
 {
     (void)info;
@@ -393,6 +555,9 @@ static napi_value init(napi_env env, napi_value exports)
         { "densityFinish", n_density_finish }, { "readGrid", n_read_grid }, { "getParticles", n_get_particles },
         { "getCells", n_get_cells }, { "sort", n_sort }, { "sync", n_sync }, { "profile", n_profile },
         { "getStats", n_get_stats }, { "saveCheckpoint", n_save_checkpoint }, { "loadCheckpoint", n_load_checkpoint }, { "resetStats", n_reset_stats }, { "buildArch", n_build_arch },
+        { "addSpecies", n_add_species }, { "setParticlesRange", n_set_particles_range }, { "getParticlesOf", n_get_particles_of },
+        { "getCellsOf", n_get_cells_of }, { "addB", n_add_b }, { "setField3", n_set_field3 }, { "readField3", n_read_field3 },
+        { "commUniqueId", n_comm_unique_id }, { "commInit", n_comm_init }, { "commDestroy", n_comm_destroy },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

@@ -277,6 +277,22 @@ int fpic_set_field3(fpic_handle* h, int which, const void* data, int nx, int ny,
 /* out: nodes (RHO, PHI), 4*nodes (E) of dtype, or nodes int64 (RHO_FIXED, dtype ignored) */
 int fpic_read_field3(fpic_handle* h, int which, void* out, int dtype);
 
+/* ---- multi-GPU inside the library (the reference has one WebGL context and no
+ * communication).  One process per GPU, one handle per process; the library binds RCCL at run time and
+ * issues the collectives itself, so the JavaScript host needs no other collective library.
+ *   rank 0: fpic_comm_unique_id(id); the host hands the 128 bytes to every rank (file, socket, env);
+ *   every rank: fpic_comm_init(h, id, rank, world).
+ * (r,z) pusher, reference-parity mode: each rank holds a shard of the particles (contiguous index range)
+ * and a replica of the grid tables; fpic_density then sums FPIC_BUF_CELL_SUMS over the ranks with ONE
+ * all-reduce between the scatter and the stamp stage — by default on a side stream, off the critical path
+ * of the next fpic_step (fpic_comm_set_overlap(h, 0) keeps it on the handle's stream). */
+#define FPIC_UNIQUE_ID_BYTES 128
+int fpic_comm_unique_id(void* id128);
+int fpic_comm_init(fpic_handle* h, const void* id128, int rank, int world);
+int fpic_comm_destroy(fpic_handle* h);
+int fpic_comm_info(fpic_handle* h, int* rank, int* world);
+int fpic_comm_set_overlap(fpic_handle* h, int enable);
+
 /* Counter-based RNG mode only: the global sub-step index (starts at 0, +2 per step() call);
  * settable so that a run can be resumed. */
 int fpic_get_substep_counter(fpic_handle* h, uint64_t* t);

@@ -1,7 +1,9 @@
 """N > 1 host logic on CPU: two gloo ranks each own a shard of the particles, scatter
 their shard, all-reduce the per-cell sums, and finish; the result must equal the
-single-rank result.  The oracle stands in for the per-rank compute (this is a test of
-the sharding + exchange logic in fusionpic.multi, which bench.py uses with RCCL)."""
+single-rank result.  The oracle stands in for the per-rank push; the deposit runs in the
+library's two stages and the exchanged buffer has the library's shape ((nr+1)(nz+1)*4 per-cell
+sums, then the stamp) — the sharding + exchange logic of fusionpic.multi and of fpic_density()
+under a communicator."""
 import os
 import socket
 
@@ -33,21 +35,47 @@ def test_shard_bounds_cover_everything():
 
 
 class OracleRank:
-    """Per-rank pusher for the CPU test: oracle compute, torch tensor as the exchanged buffer.
-    The stamped moments are linear in the particles, like the per-cell sums the GPU
-    path exchanges, so the same all-reduce applies."""
+    """Per-rank pusher for the CPU test: oracle compute for the push, and the deposit in the TWO STAGES the
+    HIP path uses: stage 1 forms the per-cell sums of the vertex colour 0.001*(vr,vtheta,vz,1)
+    on the (nr+1) x (nz+1) grid — the buffer a multi-GPU run all-reduces (FPIC_BUF_CELL_SUMS, same shape and
+    layout) — stage 2 applies the 11x11 stamp and the normalise / EMA passes.  `sums` is the exchanged tensor."""
 
     def __init__(self, po, begin, end, scene):
         pos, vel, entropy, rand, B, sink = scene
         self.sim = po.OracleSim(SPEC, dtype=np.float64, count=end - begin)
         self.sim.set(B=B, position=pos[begin:end], velocity=vel[begin:end], sink_mask=sink, source_pdf=sink)
         self.sim.set_random_state(entropy, rand[begin:end])
-        self.sums = torch.from_numpy(self.sim.moments)  # aliases the oracle's buffer
+        self.nr, self.nz = SPEC["nr"], SPEC["nz"]
+        self.cell_sums = np.zeros((self.nz + 1, self.nr + 1, 4))          # index 4*(i + (nr+1)*j) + c, as the library's buffer
+        self.sums = torch.from_numpy(self.cell_sums.reshape(-1))           # aliases it: what the all-reduce sees
+        assert self.sums.numel() == (self.nr + 1) * (self.nz + 1) * 4
 
     def precalc(self): self.sim.precalc()
     def step(self, n=1): self.sim.step(n)
-    def deposit(self): self.sim.deposit()
-    def densityFinish(self): self.sim.density_finish()
+
+    def deposit(self):
+        """stage 1: per-cell sums of this rank's shard (empic.js:1006 vertex colour, point-sprite cell)"""
+        cells = self.sim.deposit_cells()
+        p, v = self.sim.positions(), self.sim.velocities()
+        keep = cells >= 0
+        r = np.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2)
+        dx, dy = p[:, 0] / r, p[:, 1] / r
+        colour = 0.001 * np.stack([v[:, 0] * dx + v[:, 1] * dy, v[:, 1] * dx - v[:, 0] * dy, v[:, 2], np.ones_like(r)], axis=1)
+        flat = self.cell_sums.reshape(-1, 4)
+        flat[:] = 0
+        np.add.at(flat, cells[keep], colour[keep])
+
+    def densityFinish(self):
+        """stage 2: moments01 = stamp (*) cell sums cropped to the grid (empic.js:1473-1478), then K5/K6/K7"""
+        w = self.sim.stamp.reshape(11, 11).astype(np.float64)              # index [b][a] = a + 11*b
+        padded = np.zeros((self.nz + 1 + 10, self.nr + 1 + 10, 4))
+        padded[5:-5, 5:-5] = self.cell_sums
+        out = np.zeros((self.nz, self.nr, 4))
+        for b in range(11):
+            for a in range(11):
+                out += w[b, 10 - a] * padded[b:b + self.nz, a:a + self.nr]
+        self.sim.moments[:] = out.reshape(-1)
+        self.sim.density_finish()
 
 
 def make_scene():
@@ -91,8 +119,16 @@ def test_two_gloo_ranks_equal_one(tmp_path):
     assert np.array_equal(a0, a1), "every rank holds the same reduced grid"
     assert int(np.load(tmp_path / "count_0.npy")[0]) == N      # integer parity: shard sizes sum to N
     single = OracleRank(po, 0, N, make_scene())
-    single.precalc()
+    direct = po.OracleSim(SPEC, dtype=np.float64, count=N)         # the reference's own 121-tap scatter, one rank
+    pos, vel, entropy, rand, B, sink = make_scene()
+    direct.set(B=B, position=pos, velocity=vel, sink_mask=sink, source_pdf=sink)
+    direct.set_random_state(entropy, rand)
+    single.precalc(); direct.precalc()
     for _ in range(CYCLES):
         single.step(); single.deposit(); single.densityFinish()
+        direct.step(); direct.density()
     scale = np.abs(single.sim.avg_A).max()
     assert np.abs(a0 - single.sim.avg_A).max() <= 1e-12 * scale
+    # and the two-stage form equals the direct scatter (only the order of additions differs)
+    assert np.abs(single.sim.avg_A - direct.avg_A).max() <= 1e-10 * scale
+    assert np.abs(single.sim.moments - direct.moments).max() <= 1e-10 * np.abs(direct.moments).max()

@@ -818,6 +818,42 @@ simulation.destroy();
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-3)
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_library_communicator_world_of_one(fp, po, overlap):
+    """fpic_comm_*: the RCCL communicator inside the library (one rank: the same calls, collectives and
+    stream ordering as an N-GPU run).  density() under a communicator = scatter, all-reduce of the per-cell
+    sums (side stream when overlapped), finish; results equal the plain handle's bit for bit."""
+    spec = make_spec(48, 40, 70)
+    n = 4900
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=31, v_th=4e-3)
+    sims = [fp.makeCylindricalParticlePusher(spec) for _ in range(2)]
+    for s in sims:
+        s.set(position=pos, velocity=vel, sink_mask=frame_sink(48, 40), source_pdf=frame_sink(48, 40))
+        s.setRandomState(entropy, rand)
+        s.addBZ(0.05); s.precalc()
+    uid = fp.commUniqueId()
+    assert len(uid) == 128
+    sims[0].commInit(uid, 0, 1, overlap=overlap)
+    assert sims[0].commInfo() == (0, 1) and sims[1].commInfo() == (0, 1)
+    with pytest.raises(fp.FusionPicError):
+        sims[0].commInit(uid, 0, 1)                      # one communicator per handle
+    with pytest.raises(fp.FusionPicError):
+        sims[1].commInit(uid, 3, 2)                      # rank outside the world
+    for frame in range(6):
+        for s in sims:
+            s.step(); s.density()
+        if frame in (2, 5):
+            a, b = sims[0].readDensity(), sims[1].readDensity()
+            assert same_bits(a, b), frame
+            assert same_bits(sims[0].readMoments(), sims[1].readMoments()), frame
+    ga, gb = sims[0].getParticles(), sims[1].getParticles()
+    assert same_bits(ga["position"], gb["position"])
+    sims[0].commDestroy()
+    sims[0].step(); sims[0].density()                    # and the handle keeps running without it
+    for s in sims:
+        s.destroy()
+
+
 def test_node_addon_rejects_wrong_sized_buffers():
     """A typed array of the wrong length is a JavaScript RangeError in the shim AND in the addon
     (called directly, without the shim), never a native out-of-bounds access."""
@@ -844,7 +880,7 @@ tryit('getCells', () => sim.getCells(new Int32Array(3)));
 tryit('setRandomState', () => sim.setRandomState({rand: new Float32Array(4 * 24)}));
 // the addon itself, bypassing the shim (first argument = the native handle is private to the shim:
 // reach the same entry points through a second pusher's closure is impossible, so build one here)
-const h = lib.create(1, 1, 12, 10, 2e-9, 5, 1.67e-27, 1.6e-19, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+const h = lib.create(1, 1, 12, 10, 2e-9, 5, 1.67e-27, 1.6e-19, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
 tryit('addon_readGrid', () => lib.readGrid(h, 2, new Float32Array(12 * 10)));
 tryit('addon_getParticles', () => lib.getParticles(h, new Float32Array(3), null, null, null));
 tryit('addon_getCells', () => lib.getCells(h, new Int32Array(24)));
