@@ -822,7 +822,8 @@ simulation.destroy();
 def test_library_communicator_world_of_one(fp, po, overlap):
     """fpic_comm_*: the RCCL communicator inside the library (one rank: the same calls, collectives and
     stream ordering as an N-GPU run).  density() under a communicator = scatter, all-reduce of the per-cell
-    sums (side stream when overlapped), finish; results equal the plain handle's bit for bit."""
+    sums (side stream when overlapped), finish; the density equals the plain handle's to rounding, the particles
+    bit for bit."""
     spec = make_spec(48, 40, 70)
     n = 4900
     pos, vel, entropy, rand = uniform_plasma(n, spec, seed=31, v_th=4e-3)
@@ -843,9 +844,11 @@ def test_library_communicator_world_of_one(fp, po, overlap):
         for s in sims:
             s.step(); s.density()
         if frame in (2, 5):
-            a, b = sims[0].readDensity(), sims[1].readDensity()
-            assert same_bits(a, b), frame
-            assert same_bits(sims[0].readMoments(), sims[1].readMoments()), frame
+            # (the per-cell sums are flushed with float atomics: two runs agree to rounding, not to the bit)
+            a, b = sims[0].readDensity(np.float64), sims[1].readDensity(np.float64)
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), frame
+            a, b = sims[0].readMoments(np.float64), sims[1].readMoments(np.float64)
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), frame
     ga, gb = sims[0].getParticles(), sims[1].getParticles()
     assert same_bits(ga["position"], gb["position"])
     sims[0].commDestroy()
