@@ -11,6 +11,7 @@
 // (fpic_dyn.hpp); without it a handle with solver = POISSON_FFT cannot be created.
 #include "fes_api.hpp"
 #include "fes_kernels.hpp"
+#include "fpic_comm.hpp"
 #include "fpic_dyn.hpp"
 
 #include <algorithm>
@@ -26,7 +27,9 @@ namespace fes {
 struct Species {
     double mass = 0, charge = 0;
     int Z = 1;
-    size_t n = 0, n_pad = 0;
+    size_t n = 0;     // particles held now (a decomposed run gains and loses particles by migration)
+    size_t cap = 0;   // capacity of the arrays
+    size_t n_pad = 0;
     void* slab[2] = {};
     uint32_t* id[2] = {};
     int cur = 0;
@@ -64,6 +67,25 @@ struct State {
     int substeps_since_bin = 0;
     bool fields_ready = false;
     std::vector<Species> sp;
+    struct Domain* dom = nullptr; // z-slab decomposition over several GPUs (fpic_domain_init)
+};
+
+// Spatial decomposition: rank r of `world` owns the particles whose cell lies in the
+// planes [z0, z0 + nzl) and G ghost planes on either side, in which its particles may still sit and deposit
+// until the next migration.  Per sub-step: ghost-plane reduce of the int64 charge grid with the two
+// neighbours (exact), all-gather of the owned planes of rho, the field solve on every rank; every
+// `migrate_every` sub-steps the particles that left the slab move to the neighbour that owns them.
+struct Domain {
+    int rank = 0, world = 1, G = 2, nzl = 0, z0 = 0;
+    int migrate_every = 4;
+    int substeps_since_migration = 0;
+    long long* ghost_recv[2] = {};      // [0]: from the slab above (its lower ghost planes, G), [1]: from below (G + 1)
+    void* mig_send[2] = {};             // [0]: to the slab below, [1]: to the slab above
+    void* mig_recv[2] = {};             // [0]: from above, [1]: from below
+    unsigned mig_cap = 0;               // records per buffer
+    unsigned* counts_dev = nullptr;     // down, up, lost, overflow | received from above, from below
+    unsigned* counts_host = nullptr;    // pinned copy
+    uint64_t migrated = 0, lost = 0;
 };
 
 namespace {
@@ -83,14 +105,15 @@ template <typename T>
 int alloc_species(fpic_handle* h, Species& s)
 {
     State* st = h->es;
-    s.n_pad = (s.n + 1023) / 1024 * 1024;
+    if (s.cap < s.n) s.cap = s.n;
+    s.n_pad = (s.cap + 1023) / 1024 * 1024;
     for (int k = 0; k < 2; ++k) {
         if (int rc = dev_alloc(h, &s.slab[k], 6 * s.n_pad * sizeof(T), &h->bytes_particles)) return rc;
         if (int rc = dev_alloc(h, reinterpret_cast<void**>(&s.id[k]), s.n_pad * sizeof(uint32_t), &h->bytes_particles)) return rc;
         init3_kernel<T><<<blocks_for(s.n_pad), 256, 0, h->stream>>>(static_cast<T*>(s.slab[k]), s.n_pad, s.id[k]);
         HIP_TRY(h, hipGetLastError());
     }
-    s.work_cap = (s.n + kChunk3 - 1) / kChunk3 + st->ntiles;
+    s.work_cap = (s.cap + kChunk3 - 1) / kChunk3 + st->ntiles;
     uint64_t* acc = &h->bytes_grid;
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
@@ -246,14 +269,16 @@ int fft_status(fpic_handle* h, rocfft_status s, const char* what)
 
 // rho_fixed -> E4 (es3d_rho_real, es3d_poisson, es3d_gradient)
 template <typename T>
-int launch_solve(fpic_handle* h)
+int launch_solve(fpic_handle* h, bool convert = true)
 {
     State* st = h->es;
     timing_begin(h, KC_SOLVE);
-    const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
-    const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv); // q0 W / (2^42 dV)
-    rho_real_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(st->rho_fixed, st->nodes, scale, static_cast<T*>(st->rho));
-    HIP_TRY(h, hipGetLastError());
+    if (convert) { // (a decomposed run has converted its own planes and gathered the others)
+        const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
+        const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv); // q0 W / (2^42 dV)
+        rho_real_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(st->rho_fixed, st->nodes, scale, static_cast<T*>(st->rho));
+        HIP_TRY(h, hipGetLastError());
+    }
     if (st->solver == FPIC_SOLVER_POISSON_FFT) {
         const fdyn::RocFFT& ff = fdyn::rocfft();
         const int nxh = st->nx / 2 + 1;
@@ -535,6 +560,7 @@ int check_species(fpic_handle* h, int species)
 
 uint64_t particle_count(const fpic_handle* h) { return total_particles(h->es); }
 uint64_t last_spill(const fpic_handle* h) { return h->es->last_spill; }
+bool is_decomposed(const fpic_handle* h) { return h->es && h->es->dom != nullptr; }
 uint64_t species_count(const fpic_handle* h, int species)
 {
     return species >= 0 && species < static_cast<int>(h->es->sp.size()) ? h->es->sp[species].n : ~0ull;
@@ -579,6 +605,13 @@ void release(fpic_handle* h)
     State* st = h->es;
     if (!st) return;
     for (Species& s : st->sp) free_species(s);
+    if (Domain* d = st->dom) {
+        for (void* p : { static_cast<void*>(d->ghost_recv[0]), static_cast<void*>(d->ghost_recv[1]), d->mig_send[0], d->mig_send[1], d->mig_recv[0],
+                         d->mig_recv[1], static_cast<void*>(d->counts_dev) })
+            if (p) (void)hipFree(p);
+        if (d->counts_host) (void)hipHostFree(d->counts_host);
+        delete d;
+    }
     for (void* p : { static_cast<void*>(st->rho_fixed), st->rho, st->hat, st->phi, st->E4, static_cast<void*>(st->k2[0]), static_cast<void*>(st->k2[1]),
                      static_cast<void*>(st->k2[2]), st->work_f, st->work_i, static_cast<void*>(st->spilled) })
         if (p) (void)hipFree(p);
@@ -643,6 +676,7 @@ int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* 
 
 int get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype)
 {
+    if (h->es->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle holds a changing subset of the particles: read it with fpic_domain_get_particles");
     if (int rc = check_species(h, species)) return rc;
     const Species& s = h->es->sp[species];
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
@@ -661,6 +695,7 @@ int get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int
 
 int get_cells(fpic_handle* h, int species, int32_t* cells)
 {
+    if (h->es->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle holds a changing subset of the particles: read it with fpic_domain_get_particles");
     if (int rc = check_species(h, species)) return rc;
     if (!cells) return fail(h, FPIC_ERR_INVALID_ARG, ".cells <- Non-optional property is undefined!");
     const Species& s = h->es->sp[species];
@@ -711,8 +746,258 @@ int read_field3(fpic_handle* h, int which, void* out, int dtype)
     return dtype == FPIC_F32 ? download_grid<double, float>(h, dev, count, static_cast<float*>(out)) : download_grid<double, double>(h, dev, count, static_cast<double*>(out));
 }
 
+// ================================================================ spatial decomposition (z-slabs)
+
+namespace {
+
+struct Xfer {
+    int to, from;           // ranks
+    const void* send;
+    size_t send_bytes;
+    void* recv;
+    size_t recv_bytes;
+};
+enum Exchange { X_GHOST = 0, X_MIG_COUNTS, X_MIG_PAYLOAD };
+
+// The messages of one exchange, in an order every rank shares: [0] goes to the slab below and is met there by
+// what arrives from above, [1] goes up and is met by what arrives from below.  (RCCL matches the sends and
+// receives of a pair of ranks in the order they are issued; with two ranks both messages have the same peer.)
+template <typename T>
+void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
+{
+    State* st = h->es;
+    Domain& d = *st->dom;
+    const int down = (d.rank + d.world - 1) % d.world, up = (d.rank + 1) % d.world;
+    const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+    out.clear();
+    if (which == X_GHOST) {
+        const int lo = (d.z0 - d.G + st->nz) % st->nz, hi = (d.z0 + d.nzl) % st->nz;
+        out.push_back({ down, up, st->rho_fixed + lo * plane, d.G * plane * 8, d.ghost_recv[0], d.G * plane * 8 });
+        out.push_back({ up, down, st->rho_fixed + hi * plane, (d.G + 1) * plane * 8, d.ghost_recv[1], (d.G + 1) * plane * 8 });
+    } else if (which == X_MIG_COUNTS) {
+        out.push_back({ down, up, d.counts_dev + 0, 4, d.counts_dev + 4, 4 });
+        out.push_back({ up, down, d.counts_dev + 1, 4, d.counts_dev + 5, 4 });
+    } else {
+        const size_t rec = sizeof(MigRecord<T>);
+        out.push_back({ down, up, d.mig_send[0], d.counts_host[0] * rec, d.mig_recv[0], d.counts_host[4] * rec });
+        out.push_back({ up, down, d.mig_send[1], d.counts_host[1] * rec, d.mig_recv[1], d.counts_host[5] * rec });
+    }
+}
+
+// One rank per process over RCCL (hs.size() == 1), or every rank of a group inside this process (the
+// in-process stand-in for the exchange that lets one GPU run and test an N-rank decomposition).
+struct Ranks {
+    std::vector<fpic_handle*> hs;
+    bool rccl = false;
+};
+
+template <typename T>
+int exchange(Ranks& rk, int which)
+{
+    if (rk.rccl) {
+        fpic_handle* h = rk.hs[0];
+        const fdyn::Rccl& rc = fdyn::rccl();
+        std::vector<Xfer> x;
+        dom_xfers<T>(h, which, x);
+        if (int e = fcomm::check(h, rc.GroupStart(), "ncclGroupStart")) return e;
+        for (const Xfer& m : x) {
+            if (m.send_bytes)
+                if (int e = fcomm::check(h, rc.Send(m.send, m.send_bytes, ncclChar, m.to, h->comm->nccl, h->stream), "ncclSend")) return e;
+            if (m.recv_bytes)
+                if (int e = fcomm::check(h, rc.Recv(m.recv, m.recv_bytes, ncclChar, m.from, h->comm->nccl, h->stream), "ncclRecv")) return e;
+        }
+        return fcomm::check(h, rc.GroupEnd(), "ncclGroupEnd");
+    }
+    std::vector<std::vector<Xfer>> all(rk.hs.size());
+    for (size_t r = 0; r < rk.hs.size(); ++r) dom_xfers<T>(rk.hs[r], which, all[r]);
+    for (size_t r = 0; r < rk.hs.size(); ++r)
+        for (size_t i = 0; i < all[r].size(); ++i) {
+            const Xfer& m = all[r][i];
+            const Xfer& peer = all[m.to][i];
+            if (peer.recv_bytes != m.send_bytes || peer.from != static_cast<int>(r))
+                return fail(rk.hs[r], FPIC_ERR_STATE, "decomposition exchange %d: message %zu of rank %zu (%zu bytes) does not match rank %d's receive (%zu bytes)",
+                            which, i, r, m.send_bytes, m.to, peer.recv_bytes);
+            if (m.send_bytes) HIP_TRY(rk.hs[r], hipMemcpyAsync(peer.recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, rk.hs[0]->stream));
+        }
+    return FPIC_OK;
+}
+
+// every rank ends up with all owned planes of rho
+template <typename T>
+int allgather_rho(Ranks& rk)
+{
+    if (rk.rccl) {
+        fpic_handle* h = rk.hs[0];
+        State* st = h->es;
+        const size_t count = static_cast<size_t>(st->dom->nzl) * st->nx * st->ny;
+        T* rho = static_cast<T*>(st->rho);
+        return fcomm::check(h, fdyn::rccl().AllGather(rho + st->dom->rank * count, rho, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, h->comm->nccl, h->stream),
+                            "ncclAllGather");
+    }
+    for (fpic_handle* dst : rk.hs)
+        for (fpic_handle* src : rk.hs) {
+            if (src == dst) continue;
+            const State* ss = src->es;
+            const size_t count = static_cast<size_t>(ss->dom->nzl) * ss->nx * ss->ny, off = ss->dom->rank * count;
+            HIP_TRY(dst, hipMemcpyAsync(static_cast<T*>(dst->es->rho) + off, static_cast<const T*>(ss->rho) + off, count * sizeof(T), hipMemcpyDeviceToDevice,
+                                        rk.hs[0]->stream));
+        }
+    return FPIC_OK;
+}
+
+// particles that have left the slab move to the neighbour that owns them; then every species is re-binned
+template <typename T>
+int migrate(Ranks& rk)
+{
+    const size_t nsp = rk.hs[0]->es->sp.size();
+    for (fpic_handle* h : rk.hs) timing_begin(h, KC_SORT);
+    for (size_t sp = 0; sp < nsp; ++sp) {
+        for (fpic_handle* h : rk.hs) {
+            State* st = h->es;
+            Domain& d = *st->dom;
+            Species& s = st->sp[sp];
+            HIP_TRY(h, hipMemsetAsync(d.counts_dev, 0, 8 * sizeof(unsigned), h->stream));
+            if (s.n)
+                mig_pack_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
+                                                                          static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]),
+                                                                          d.mig_cap, d.counts_dev);
+            HIP_TRY(h, hipGetLastError());
+        }
+        if (int e = exchange<T>(rk, X_MIG_COUNTS)) return e;
+        for (fpic_handle* h : rk.hs) {
+            Domain& d = *h->es->dom;
+            HIP_TRY(h, hipMemcpyAsync(d.counts_host, d.counts_dev, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (d.counts_host[3])
+                return fail(h, FPIC_ERR_STATE, "migration: %u particles did not fit the message buffer of %u records: migrate more often", d.counts_host[3], d.mig_cap);
+            if (d.counts_host[4] > d.mig_cap || d.counts_host[5] > d.mig_cap) return fail(h, FPIC_ERR_STATE, "migration: incoming message exceeds the buffer");
+            d.lost += d.counts_host[2];
+            d.migrated += d.counts_host[0] + d.counts_host[1];
+        }
+        if (int e = exchange<T>(rk, X_MIG_PAYLOAD)) return e;
+        for (fpic_handle* h : rk.hs) {
+            State* st = h->es;
+            Domain& d = *st->dom;
+            Species& s = st->sp[sp];
+            const size_t in = static_cast<size_t>(d.counts_host[4]) + d.counts_host[5];
+            const size_t out = static_cast<size_t>(d.counts_host[0]) + d.counts_host[1];
+            if (s.n + in > s.n_pad || s.n - out + in > s.cap)
+                return fail(h, FPIC_ERR_STATE, "migration: rank %d would hold %zu particles of species %zu, capacity %zu", d.rank, s.n - out + in, sp, s.cap);
+            T* slab = static_cast<T*>(s.slab[s.cur]);
+            if (d.counts_host[4])
+                mig_append_kernel<T><<<blocks_for(d.counts_host[4]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[0]), d.counts_host[4], slab, s.n_pad,
+                                                                                        s.id[s.cur], s.n);
+            if (d.counts_host[5])
+                mig_append_kernel<T><<<blocks_for(d.counts_host[5]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[1]), d.counts_host[5], slab, s.n_pad,
+                                                                                        s.id[s.cur], s.n + d.counts_host[4]);
+            HIP_TRY(h, hipGetLastError());
+            // the binning runs over the old slots (dead ones skipped) and the arrivals, and leaves a compact array
+            const size_t slots = s.n + in;
+            s.n = slots;
+            if (int e = launch_bin<T>(h, s)) return e;
+            s.n = slots - out;
+        }
+    }
+    for (fpic_handle* h : rk.hs) {
+        timing_end(h);
+        State* st = h->es;
+        st->substeps_since_bin = 0;
+        st->dom->substeps_since_migration = 0;
+        h->sort_passes++;
+    }
+    return FPIC_OK;
+}
+
+template <typename T>
+int dom_fields(Ranks& rk)
+{
+    const bool multi = rk.hs[0]->es->dom->world > 1;
+    if (multi)
+        if (int e = exchange<T>(rk, X_GHOST)) return e;
+    for (fpic_handle* h : rk.hs) {
+        State* st = h->es;
+        Domain& d = *st->dom;
+        const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+        timing_begin(h, KC_SOLVE);
+        if (multi) {
+            // from above: the upper neighbour's lower ghost planes = my top G planes; from below: its G + 1 upper ghost planes = my first ones
+            ghost_add_kernel<<<blocks_for(d.G * plane), 256, 0, h->stream>>>(st->rho_fixed + (d.z0 + d.nzl - d.G) * plane, d.ghost_recv[0], d.G * plane);
+            ghost_add_kernel<<<blocks_for((d.G + 1) * plane), 256, 0, h->stream>>>(st->rho_fixed + d.z0 * plane, d.ghost_recv[1], (d.G + 1) * plane);
+        }
+        const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
+        const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
+        const size_t own = d.nzl * plane, off = d.z0 * plane;
+        rho_real_kernel<T><<<blocks_for(own), 256, 0, h->stream>>>(st->rho_fixed + off, own, scale, static_cast<T*>(st->rho) + off);
+        HIP_TRY(h, hipGetLastError());
+        timing_end(h);
+    }
+    if (multi)
+        if (int e = allgather_rho<T>(rk)) return e;
+    for (fpic_handle* h : rk.hs)
+        if (int e = launch_solve<T>(h, /*convert=*/false)) return e;
+    return FPIC_OK;
+}
+
+template <typename T>
+int dom_precalc(Ranks& rk)
+{
+    for (fpic_handle* h : rk.hs) {
+        if (int e = deposit_cycle<T, true>(h)) return e;
+        h->deposit_launches++;
+    }
+    if (int e = dom_fields<T>(rk)) return e;
+    for (fpic_handle* h : rk.hs) h->es->fields_ready = true;
+    return FPIC_OK;
+}
+
+template <typename T>
+int dom_substep(Ranks& rk)
+{
+    State* s0 = rk.hs[0]->es;
+    bool unbinned = false;
+    for (fpic_handle* h : rk.hs)
+        for (const Species& s : h->es->sp) unbinned |= !s.binned;
+    if (s0->dom->world > 1) {
+        if (unbinned || s0->dom->substeps_since_migration >= s0->dom->migrate_every)
+            if (int e = migrate<T>(rk)) return e;
+    } else if (unbinned || s0->substeps_since_bin >= 8) {
+        for (fpic_handle* h : rk.hs)
+            if (int e = bin_all<T>(h, false)) return e;
+    }
+    for (fpic_handle* h : rk.hs) {
+        if (int e = deposit_cycle<T, false>(h)) return e;
+        State* st = h->es;
+        st->substeps_since_bin++;
+        st->dom->substeps_since_migration++;
+        h->step_launches++;
+        h->particle_updates += total_particles(st);
+    }
+    return dom_fields<T>(rk);
+}
+
+int dom_ranks_of(fpic_handle* h, Ranks& rk)
+{
+    Domain& d = *h->es->dom;
+    rk.hs.assign(1, h);
+    rk.rccl = h->comm != nullptr;
+    if (rk.rccl) {
+        if (h->comm->world != d.world || h->comm->rank != d.rank)
+            return fail(h, FPIC_ERR_STATE, "the communicator (rank %d of %d) and the decomposition (rank %d of %d) disagree", h->comm->rank, h->comm->world, d.rank, d.world);
+    } else if (d.world > 1) {
+        return fail(h, FPIC_ERR_STATE, "a decomposed handle steps through its communicator (fpic_comm_init) or its in-process group (fpic_group_step)");
+    }
+    return FPIC_OK;
+}
+
+} // namespace
+
 int precalc(fpic_handle* h)
 {
+    if (h->es->dom) {
+        Ranks rk;
+        if (int e = dom_ranks_of(h, rk)) return e;
+        return h->prec == FPIC_F32 ? dom_precalc<float>(rk) : dom_precalc<double>(rk);
+    }
     int rc = h->prec == FPIC_F32 ? deposit_cycle<float, true>(h) : deposit_cycle<double, true>(h);
     if (rc) return rc;
     h->deposit_launches++;
@@ -725,6 +1010,13 @@ int step(fpic_handle* h, int ncalls)
 {
     if (!h->es->fields_ready)
         return fail(h, FPIC_ERR_STATE, "step() before precalc(): the fields of the current particle positions have not been computed");
+    if (h->es->dom) {
+        Ranks rk;
+        if (int e = dom_ranks_of(h, rk)) return e;
+        for (int k = 0; k < 2 * ncalls; ++k)
+            if (int rc = h->prec == FPIC_F32 ? dom_substep<float>(rk) : dom_substep<double>(rk)) return rc;
+        return FPIC_OK;
+    }
     for (int k = 0; k < 2 * ncalls; ++k)
         if (int rc = h->prec == FPIC_F32 ? substep<float>(h) : substep<double>(h)) return rc;
     return FPIC_OK;
@@ -737,6 +1029,133 @@ int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes)
     if (which != FPIC_BUF_RHO_FIXED) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown buffer %d", which);
     if (dptr) *dptr = h->es->rho_fixed;
     if (bytes) *bytes = h->es->nodes * sizeof(long long);
+    return FPIC_OK;
+}
+
+// ---- decomposition entry points (fpic_domain_*, fpic_group_*)
+
+int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every)
+{
+    State* st = h->es;
+    if (st->dom) return fail(h, FPIC_ERR_STATE, "the handle is already decomposed");
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, FPIC_ERR_INVALID_ARG, ".rank <- %d is outside a world of %d", rank, world);
+    if (st->nz % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d planes along z do not divide into %d slabs", st->nz, world);
+    const int nzl = st->nz / world;
+    if (ghost_planes < 1 || ghost_planes >= nzl) return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- must lie in [1, %d)", nzl);
+    if (migrate_every < 1) return fail(h, FPIC_ERR_INVALID_ARG, ".migrate_every <- must be at least 1");
+    Domain* d = new (std::nothrow) Domain();
+    if (!d) return fail(h, FPIC_ERR_OOM, "host allocation failed");
+    st->dom = d;
+    d->rank = rank; d->world = world; d->G = ghost_planes; d->nzl = nzl; d->z0 = rank * nzl; d->migrate_every = migrate_every;
+    const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+    const size_t rec = h->prec == FPIC_F32 ? sizeof(MigRecord<float>) : sizeof(MigRecord<double>);
+    size_t cap = 0;
+    for (const Species& s : st->sp) cap = std::max(cap, s.cap);
+    d->mig_cap = static_cast<unsigned>(std::min<size_t>(std::max<size_t>(cap / 4, 4096), 0x7FFFFFFFu));
+    uint64_t* acc = &h->bytes_grid;
+    int rc;
+    if ((rc = dev_alloc(h, reinterpret_cast<void**>(&d->ghost_recv[0]), ghost_planes * plane * 8, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&d->ghost_recv[1]), (ghost_planes + 1) * plane * 8, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&d->counts_dev), 8 * sizeof(unsigned), acc)))
+        return rc;
+    for (int k = 0; k < 2; ++k)
+        if ((rc = dev_alloc(h, &d->mig_send[k], d->mig_cap * rec, acc)) || (rc = dev_alloc(h, &d->mig_recv[k], d->mig_cap * rec, acc))) return rc;
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&d->counts_host), 8 * sizeof(unsigned)));
+    std::memset(d->counts_host, 0, 8 * sizeof(unsigned));
+    for (Species& s : st->sp) s.n = 0; // the rank's particles arrive through domain_set_particles
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FPIC_OK;
+}
+
+int domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype)
+{
+    if (!h->es->dom) return fail(h, FPIC_ERR_STATE, "fpic_domain_set_particles needs fpic_domain_init first");
+    if (int rc = check_species(h, species)) return rc;
+    Species& s = h->es->sp[species];
+    if (n > s.cap) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- %llu particles exceed the species' capacity of %zu on this rank", static_cast<unsigned long long>(n), s.cap);
+    if (!pos_aos || !vel_aos) return fail(h, FPIC_ERR_INVALID_ARG, ".position <- position and velocity are both needed");
+    s.n = static_cast<size_t>(n);
+    for (int k = 0; k < 2; ++k) { // slot order = upload order in both sets; the ids carry the caller's global index
+        if (n) iota3_kernel<<<blocks_for(s.n), 256, 0, h->stream>>>(s.id[k], s.n, 0u);
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (int rc = set_particles(h, species, pos_aos, vel_aos, 0, n, dtype)) return rc;
+    if (n) iota3_kernel<<<blocks_for(s.n), 256, 0, h->stream>>>(s.id[s.cur], s.n, first_id);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FPIC_OK;
+}
+
+template <typename T, typename Out>
+static int download_plain(fpic_handle* h, const Species& s, Out* host, int first)
+{
+    Out* stage = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), s.n * 3 * sizeof(Out)));
+    const T* a = static_cast<const T*>(s.slab[s.cur]);
+    get_plain3_kernel<T, Out><<<blocks_for(s.n), 256, 0, h->stream>>>(a + first * s.n_pad, a + (first + 1) * s.n_pad, a + (first + 2) * s.n_pad, s.n, stage);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host, stage, s.n * 3 * sizeof(Out), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) return fail(h, FPIC_ERR_HIP, "particle read-back failed: %s", hipGetErrorString(e));
+    return FPIC_OK;
+}
+
+int domain_get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, uint32_t* ids, uint64_t capacity, uint64_t* n_out, int dtype)
+{
+    if (!h->es->dom) return fail(h, FPIC_ERR_STATE, "fpic_domain_get_particles needs a decomposed handle");
+    if (int rc = check_species(h, species)) return rc;
+    const Species& s = h->es->sp[species];
+    if (n_out) *n_out = s.n;
+    if (!pos_aos && !vel_aos && !ids) return FPIC_OK;
+    if (capacity < s.n) return fail(h, FPIC_ERR_INVALID_ARG, ".capacity <- the rank holds %zu particles", s.n);
+    if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
+    if (!s.n) return FPIC_OK;
+    for (int pass = 0; pass < 2; ++pass) {
+        void* dst = pass == 0 ? pos_aos : vel_aos;
+        if (!dst) continue;
+        int rc;
+        if (h->prec == FPIC_F32)
+            rc = dtype == FPIC_F32 ? download_plain<float, float>(h, s, static_cast<float*>(dst), 3 * pass) : download_plain<float, double>(h, s, static_cast<double*>(dst), 3 * pass);
+        else
+            rc = dtype == FPIC_F32 ? download_plain<double, float>(h, s, static_cast<float*>(dst), 3 * pass) : download_plain<double, double>(h, s, static_cast<double*>(dst), 3 * pass);
+        if (rc) return rc;
+    }
+    if (ids) {
+        HIP_TRY(h, hipMemcpyAsync(ids, s.id[s.cur], s.n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return FPIC_OK;
+}
+
+int domain_stats(fpic_handle* h, uint64_t* migrated, uint64_t* lost)
+{
+    if (!h->es->dom) return fail(h, FPIC_ERR_STATE, "the handle is not decomposed");
+    if (migrated) *migrated = h->es->dom->migrated;
+    if (lost) *lost = h->es->dom->lost;
+    return FPIC_OK;
+}
+
+int group_run(fpic_handle** hs, int n, int what, int ncalls)
+{
+    Ranks rk;
+    rk.hs.assign(hs, hs + n);
+    rk.rccl = false;
+    fpic_handle* h0 = hs[0];
+    for (int r = 0; r < n; ++r) {
+        fpic_handle* h = hs[r];
+        if (!h || !h->es || !h->es->dom) return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d is not a decomposed CART3D handle", r);
+        const Domain& d = *h->es->dom;
+        if (d.world != n || d.rank != r) return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d is rank %d of %d, the group has %d members", r, d.rank, d.world, n);
+        if (h->prec != h0->prec || h->es->nodes != h0->es->nodes || h->device != h0->device || h->es->sp.size() != h0->es->sp.size())
+            return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d differs in precision, grid, device or species", r);
+        if (h->comm) return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d has a communicator; a group is the in-process exchange", r);
+        if (what != 0 && !h->es->fields_ready) return fail(h0, FPIC_ERR_STATE, "step() before precalc()");
+        h->stream = h0->stream; // one queue for the whole group: the copies between members need no further ordering
+    }
+    if (what == 0) return h0->prec == FPIC_F32 ? dom_precalc<float>(rk) : dom_precalc<double>(rk);
+    for (int k = 0; k < 2 * ncalls; ++k)
+        if (int rc = h0->prec == FPIC_F32 ? dom_substep<float>(rk) : dom_substep<double>(rk)) return rc;
     return FPIC_OK;
 }
 

@@ -685,7 +685,8 @@ __global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ s
     const size_t base = static_cast<size_t>(blockIdx.x) * (256 * kBinPer3);
     for (int k = 0; k < kBinPer3; ++k) {
         const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&hist3[key_of(slab[i], slab[stride + i], slab[2 * stride + i], nx, ny, nz, ntx, nty)], 1u);
+        if (i < n && !(slab[i] < static_cast<T>(0))) // (x < 0 marks a slot whose particle has migrated to another rank)
+            atomicAdd(&hist3[key_of(slab[i], slab[stride + i], slab[2 * stride + i], nx, ny, nz, ntx, nty)], 1u);
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < ntiles; t += 256)
@@ -705,8 +706,8 @@ __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < kBinPer3; ++k) {
         const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
-        key[k] = 0; rank[k] = 0;
-        if (i < n) {
+        key[k] = ~0u; rank[k] = 0;
+        if (i < n && !(src[i] < static_cast<T>(0))) {
             key[k] = key_of(src[i], src[stride + i], src[2 * stride + i], nx, ny, nz, ntx, nty);
             rank[k] = atomicAdd(&hist3[key[k]], 1u);
         }
@@ -720,12 +721,88 @@ __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < kBinPer3; ++k) {
         const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
-        if (i >= n) continue;
+        if (i >= n || key[k] == ~0u) continue;
         const size_t d = static_cast<size_t>(hist3[key[k]]) + rank[k];
 #pragma unroll
         for (int f = 0; f < 6; ++f) dst[f * stride + d] = src[f * stride + i];
         dst_id[d] = src_id[i];
     }
+}
+
+
+// ------------------------------------------------------------------ spatial decomposition (z-slabs), SURVEY.md 8(e) row 2
+
+// One migrating particle on the wire: the six coordinates and the caller's (global) index.
+template <typename T>
+struct MigRecord {
+    T v[6];
+    uint32_t id;
+    uint32_t pad;
+};
+
+// Particles whose cell has left this rank's slab [z0, z0 + nzl) are appended to the send buffer of the
+// neighbour that owns it (0: the slab below, 1: the slab above) and their slot is marked dead (x = -1);
+// the re-binning that follows drops dead slots.  A particle further than `reach` planes from the slab has
+// outrun the ghost planes (its charge was lost from the exchange): counted in lost.
+template <typename T>
+__global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, const uint32_t* __restrict__ id, size_t n, int nz, int z0, int nzl,
+                                                       int reach, int world, MigRecord<T>* down, MigRecord<T>* up, unsigned cap,
+                                                       unsigned* __restrict__ counts /* down, up, lost, overflow */)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const T x = slab[s];
+    if (x < static_cast<T>(0)) return;
+    int k, w;
+    axis(slab[2 * stride + s], nz, k, w);
+    int d = k - z0;                     // planes above the slab's first, periodic
+    if (d < 0) d += nz;
+    if (d < nzl) return;                // still at home
+    const int above = d - nzl, below = nz - d - 1; // cells beyond the upper / lower face
+    const bool go_up = world == 2 ? true : above <= below;
+    if ((above <= below ? above : below) >= reach) atomicAdd(counts + 2, 1u);
+    const unsigned slot = atomicAdd(counts + (go_up ? 1 : 0), 1u);
+    if (slot >= cap) { atomicAdd(counts + 3, 1u); return; } // stays (and is reported): no room in the message
+    MigRecord<T> r;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) r.v[f] = slab[f * stride + s];
+    r.id = id[s];
+    r.pad = 0;
+    (go_up ? up : down)[slot] = r;
+    slab[s] = static_cast<T>(-1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mig_append_kernel(const MigRecord<T>* __restrict__ in, unsigned count, T* slab, size_t stride, uint32_t* id, size_t first)
+{
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const MigRecord<T> m = in[r];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) slab[f * stride + first + r] = m.v[f];
+    id[first + r] = m.id;
+}
+
+// ghost planes received from a neighbour, added onto this rank's own planes (exact: int64)
+static __global__ __launch_bounds__(256) void ghost_add_kernel(long long* __restrict__ dst, const long long* __restrict__ src, size_t count)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < count) dst[c] += src[c];
+}
+
+// ids of a freshly uploaded population: first + slot
+static __global__ __launch_bounds__(256) void iota3_kernel(uint32_t* id, size_t n, uint32_t first)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) id[i] = first + static_cast<uint32_t>(i);
+}
+
+template <typename T, typename Out>
+__global__ __launch_bounds__(256) void get_plain3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, size_t n, Out* __restrict__ aos)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    aos[3 * s] = static_cast<Out>(a[s]); aos[3 * s + 1] = static_cast<Out>(b[s]); aos[3 * s + 2] = static_cast<Out>(c[s]);
 }
 
 } // namespace fes

@@ -1261,7 +1261,47 @@ int fpic_set_particles_range(fpic_handle* h, int species, uint64_t first, uint64
 {
     CHECK_HANDLE(h);
     BOX_ONLY(h, "fpic_set_particles_range");
+    if (fes::is_decomposed(h)) return fail(h, FPIC_ERR_STATE, "a decomposed handle takes its particles through fpic_domain_set_particles");
     return fes::set_particles(h, species, pos_aos, vel_aos, first, n, dtype);
+}
+
+// ---- CART3D spatial decomposition (z-slabs)
+int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_domain_init");
+    return fes::domain_init(h, rank, world, ghost_planes, migrate_every);
+}
+int fpic_domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_domain_set_particles");
+    return fes::domain_set_particles(h, species, n, pos_aos, vel_aos, first_id, dtype);
+}
+int fpic_domain_get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, uint32_t* ids, uint64_t capacity, uint64_t* n, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_domain_get_particles");
+    return fes::domain_get_particles(h, species, pos_aos, vel_aos, ids, capacity, n, dtype);
+}
+int fpic_domain_stats(fpic_handle* h, uint64_t* migrated, uint64_t* lost)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_domain_stats");
+    return fes::domain_stats(h, migrated, lost);
+}
+int fpic_group_precalc(fpic_handle** handles, int n)
+{
+    if (!handles || n < 1 || !handles[0]) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".handles <- Non-optional property is undefined!");
+    CHECK_HANDLE(handles[0]);
+    return fes::group_run(handles, n, 0, 0);
+}
+int fpic_group_step(fpic_handle** handles, int n, int ncalls)
+{
+    if (!handles || n < 1 || !handles[0]) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".handles <- Non-optional property is undefined!");
+    CHECK_HANDLE(handles[0]);
+    if (ncalls < 0 || ncalls > (1 << 29)) return fail(handles[0], FPIC_ERR_INVALID_ARG, ".ncalls <- out of range");
+    return fes::group_run(handles, n, 1, ncalls);
 }
 int fpic_get_particles_of(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype)
 {

@@ -67,6 +67,7 @@ const Rccl& rccl()
         ok &= bind(lib, "ncclCommInitRank", r.CommInitRank, r.why);
         ok &= bind(lib, "ncclCommDestroy", r.CommDestroy, r.why);
         ok &= bind(lib, "ncclAllReduce", r.AllReduce, r.why);
+        ok &= bind(lib, "ncclAllGather", r.AllGather, r.why);
         ok &= bind(lib, "ncclSend", r.Send, r.why);
         ok &= bind(lib, "ncclRecv", r.Recv, r.why);
         ok &= bind(lib, "ncclGroupStart", r.GroupStart, r.why);

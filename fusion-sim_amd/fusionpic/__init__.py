@@ -41,6 +41,8 @@ ABI_FUNCTIONS = [
     "fpic_add_species", "fpic_set_particles_of", "fpic_get_particles_of", "fpic_get_cells_of", "fpic_add_b",
     "fpic_set_field3", "fpic_read_field3", "fpic_set_particles_range",
     "fpic_comm_unique_id", "fpic_comm_init", "fpic_comm_destroy", "fpic_comm_info", "fpic_comm_set_overlap",
+    "fpic_domain_init", "fpic_domain_set_particles", "fpic_domain_get_particles", "fpic_domain_stats",
+    "fpic_group_precalc", "fpic_group_step",
 ]
 
 
@@ -132,6 +134,12 @@ def load_library(path=None):
     lib.fpic_comm_destroy.argtypes = [vp]
     lib.fpic_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.fpic_comm_set_overlap.argtypes = [vp, ci]
+    lib.fpic_domain_init.argtypes = [vp, ci, ci, ci, ci]
+    lib.fpic_domain_set_particles.argtypes = [vp, ci, ctypes.c_uint64, vp, vp, ctypes.c_uint32, ci]
+    lib.fpic_domain_get_particles.argtypes = [vp, ci, vp, vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ci]
+    lib.fpic_domain_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.fpic_group_precalc.argtypes = [ctypes.POINTER(vp), ci]
+    lib.fpic_group_step.argtypes = [ctypes.POINTER(vp), ci, ci]
     lib.fpic_add_species.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.POINTER(ci)]
     lib.fpic_set_particles_of.argtypes = [vp, ci, vp, vp, ctypes.c_uint64, ci]
     lib.fpic_get_particles_of.argtypes = [vp, ci, vp, vp, ci]
@@ -479,6 +487,33 @@ class ElectrostaticBoxPusher:
         ptr = lambda a: None if a is None else a.ctypes.data
         self._check(self._lib.fpic_set_particles_range(self._h, species, int(first), m, ptr(arrs[0]), ptr(arrs[1]), codes.pop()))
 
+    # ---- spatial decomposition (z-slabs; include/fusionpic.h, fpic_domain_*)
+    def domainInit(self, rank, world, ghost_planes=2, migrate_every=4):
+        self._check(self._lib.fpic_domain_init(self._h, int(rank), int(world), int(ghost_planes), int(migrate_every)))
+
+    def domainSet(self, position, velocity, first_id, species=0):
+        p, v = _as_float_array(position), _as_float_array(velocity)
+        if p.shape != v.shape or p.ndim != 2 or p.shape[1] != 3 or p.dtype != v.dtype:
+            raise FusionPicError(-1, ".position <- position and velocity must be [n][3] of one element type")
+        self._check(self._lib.fpic_domain_set_particles(self._h, species, p.shape[0], p.ctypes.data, v.ctypes.data, int(first_id), _code(p)))
+
+    def domainGet(self, dtype=None, species=0):
+        """{position, velocity, ids} of the particles this rank holds now (no particular order)"""
+        code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
+        n = ctypes.c_uint64()
+        self._check(self._lib.fpic_domain_get_particles(self._h, species, None, None, None, 0, ctypes.byref(n), code))
+        m = n.value
+        out = {"position": np.empty((m, 3), dtype=_np_dtype(code)), "velocity": np.empty((m, 3), dtype=_np_dtype(code)),
+               "ids": np.empty(m, dtype=np.uint32)}
+        self._check(self._lib.fpic_domain_get_particles(self._h, species, out["position"].ctypes.data, out["velocity"].ctypes.data,
+                                                        out["ids"].ctypes.data, m, ctypes.byref(n), code))
+        return out
+
+    def domainStats(self):
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.fpic_domain_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return {"migrated": a.value, "lost": b.value}
+
     def getParticles(self, dtype=None, species=0):
         code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
         n = self.counts[species]
@@ -502,6 +537,26 @@ class ElectrostaticBoxPusher:
         out = np.empty(self.nodes * (4 if which == F3_E else 1), dtype=_np_dtype(code))
         self._check(self._lib.fpic_read_field3(self._h, which, out.ctypes.data, code))
         return out.reshape(self.nodes, 4) if which == F3_E else out
+
+
+class BoxGroup:
+    """All ranks of a z-slab decomposition as handles of this process on one GPU (fpic_group_*): the in-process
+    stand-in for the RCCL exchange."""
+
+    def __init__(self, sims):
+        self.sims = list(sims)
+        self._lib = self.sims[0]._lib
+        self._arr = (ctypes.c_void_p * len(self.sims))(*[s._h for s in self.sims])
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FusionPicError(rc, self._lib.fpic_last_error(self.sims[0]._h).decode())
+
+    def precalc(self):
+        self._check(self._lib.fpic_group_precalc(self._arr, len(self.sims)))
+
+    def step(self, ncalls=1):
+        self._check(self._lib.fpic_group_step(self._arr, len(self.sims), int(ncalls)))
 
 
 def commUniqueId(library=None):

@@ -293,6 +293,27 @@ int fpic_comm_destroy(fpic_handle* h);
 int fpic_comm_info(fpic_handle* h, int* rank, int* world);
 int fpic_comm_set_overlap(fpic_handle* h, int enable);
 
+/* ---- CART3D spatial decomposition: z-slabs.  spec describes the GLOBAL box and grid on
+ * every rank; spec.count is the rank's CAPACITY per species.  Rank r of `world` owns the particles whose cell lies
+ * in the planes [r nz/world, (r+1) nz/world); they may sit up to ghost_planes planes outside it between two
+ * migrations (every migrate_every sub-steps).  Per sub-step the ranks exchange: the ghost planes of the int64
+ * charge grid with their two neighbours (added exactly), then an all-gather of the owned planes of rho; every rank
+ * then solves the fields.  At a migration: two counts and two particle messages (6 scalars + the caller's global
+ * index) per neighbour, grouped ncclSend/ncclRecv.  Because the charge grid is an integer grid, an N-rank run
+ * reproduces the one-GPU run bit for bit.
+ *   with a communicator (fpic_comm_init, one process per GPU): fpic_precalc / fpic_step exchange over RCCL;
+ *   fpic_group_precalc / fpic_group_step: all `n` ranks are handles of THIS process on one device and the exchange
+ *   is device-to-device copies — the stand-in that lets one GPU run and test an N-rank decomposition. */
+int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every);
+/* the rank's initial particles (positions anywhere in its slab +- ghost planes); their global indices are first_id, first_id+1, ... */
+int fpic_domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype);
+/* the particles the rank holds now, in no particular order, with their global indices; *n receives the count
+ * (pass NULL buffers to query it) */
+int fpic_domain_get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, uint32_t* ids, uint64_t capacity, uint64_t* n, int dtype);
+int fpic_domain_stats(fpic_handle* h, uint64_t* migrated, uint64_t* lost);
+int fpic_group_precalc(fpic_handle** handles, int n);
+int fpic_group_step(fpic_handle** handles, int n, int ncalls);
+
 /* Counter-based RNG mode only: the global sub-step index (starts at 0, +2 per step() call);
  * settable so that a run can be resumed. */
 int fpic_get_substep_counter(fpic_handle* h, uint64_t* t);

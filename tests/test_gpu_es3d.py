@@ -325,3 +325,84 @@ sim.destroy();
         assert d.max() <= 1e-4
     assert np.mean(dec("cells", np.int32) == ora.cells(0)) > 0.995
     assert out["err"] == "RangeError" and out["updates"] == 6 * (n + ni)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape,with_b", [(2, (16, 16, 16), False), (4, (24, 16, 32), True), (8, (16, 16, 64), False)])
+def test_slab_decomposition_reproduces_one_gpu_bit_for_bit(fp, eo, precision, world, shape, with_b):
+    """`world` ranks, each a handle owning a z-slab (+ ghost planes), stepped as an in-process group
+    (the exchange = device-to-device copies; over RCCL it is grouped ncclSend/ncclRecv of the same buffers).  Ghost-plane
+    reduce of the int64 charge grid, all-gather of rho, migration every 2 sub-steps.  Against ONE handle holding
+    everything: the charge grid, the fields and every particle (matched by its global index) are bit-identical,
+    the particle count is conserved, particles did migrate and none outran the ghost planes."""
+    rng = np.random.default_rng(world)
+    n = 30000
+    L = (0.016, 0.016, 0.001 * shape[2])
+    dens = 1e15
+    spec = box_spec(shape, L, count=n, dt=5e-12, macro_weight=dens * np.prod(L) / n)
+    pos = rng.random((n, 3)) * L
+    vel = rng.normal(0, 0.02, (n, 3))            # ~0.15 cell per sub-step along z: steady traffic across the slab faces
+    ion_n = 5000
+    pion, vion = rng.random((ion_n, 3)) * L, rng.normal(0, 1e-3, (ion_n, 3))
+
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.addSpecies(MP, -QE, ion_n)
+    one.set(position=pos, velocity=vel); one.set(position=pion, velocity=vion, species=1)
+
+    nzl = shape[2] // world
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=n), precision=precision)      # capacity: everything could end up here
+        s.addSpecies(MP, -QE, ion_n)
+        s.domainInit(r, world, ghost_planes=2, migrate_every=2)
+        for sp, (p, v) in enumerate(((pos, vel), (pion, vion))):
+            own = np.floor(p[:, 2] / L[2] * shape[2]).astype(int) // nzl == r
+            ids = np.nonzero(own)[0]
+            s._pending = getattr(s, "_pending", {})
+            s._pending[sp] = ids
+        ranks.append(s)
+    # global indices must be contiguous per rank and species: permute the population so that they are
+    order = [np.concatenate([r._pending[sp] for r in ranks]) for sp in (0, 1)]
+    pos, vel, pion, vion = pos[order[0]], vel[order[0]], pion[order[1]], vion[order[1]]
+    one.set(position=pos, velocity=vel); one.set(position=pion, velocity=vion, species=1)
+    for sp, (p, v) in enumerate(((pos, vel), (pion, vion))):
+        first = 0
+        for r in ranks:
+            m = len(r._pending[sp])
+            r.domainSet(p[first:first + m], v[first:first + m], first_id=first, species=sp)
+            first += m
+    if with_b:
+        one.addB(0.02, 0.0, 0.05)
+        for r in ranks:
+            r.addB(0.02, 0.0, 0.05)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+
+    def compare(tag):
+        f1 = one.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+        for r, s in enumerate(ranks):       # every rank's OWN planes hold the complete charge
+            fr = s.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+            assert np.array_equal(fr[r * nzl:(r + 1) * nzl], f1[r * nzl:(r + 1) * nzl]), (tag, r)
+            assert same_bits(s.readField(fp.F3_RHO), one.readField(fp.F3_RHO)), (tag, r)
+            assert same_bits(s.readField(fp.F3_E), one.readField(fp.F3_E)), (tag, r)
+        for sp, total in ((0, n), (1, ion_n)):
+            parts = [s.domainGet(species=sp) for s in ranks]
+            ids = np.concatenate([p["ids"] for p in parts])
+            assert len(ids) == total and np.array_equal(np.sort(ids), np.arange(total)), (tag, sp)
+            got_p = np.concatenate([p["position"] for p in parts])[np.argsort(ids)]
+            got_v = np.concatenate([p["velocity"] for p in parts])[np.argsort(ids)]
+            ref = one.getParticles(species=sp)
+            assert same_bits(got_p, ref["position"]) and same_bits(got_v, ref["velocity"]), (tag, sp)
+
+    compare("precalc")
+    for frame in range(4):
+        one.step(); group.step()
+        compare("frame %d" % frame)
+    stats = [s.domainStats() for s in ranks]
+    assert sum(s["migrated"] for s in stats) > 0 and all(s["lost"] == 0 for s in stats)
+    with pytest.raises(fp.FusionPicError):
+        ranks[0].step()                        # a rank of a multi-rank decomposition cannot step alone
+    with pytest.raises(fp.FusionPicError):
+        ranks[0].getParticles()
+    for s in ranks + [one]:
+        s.destroy()
