@@ -382,11 +382,11 @@ def main():
 
     stream = torch.cuda.Stream(device=local_rank)
 
-    def build(rng_mode):
+    def build(rng_mode, shape="ref11"):
         # counter mode: no gather hides the LDS atomics of the fused sums, so only the tile census and
         # the re-binning stay in the push there (spec.unfused_deposit = 2)
         s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051, count=n_local if strong else 0,
-                                              fuse_deposit="census" if rng_mode == "counter" else True)
+                                              fuse_deposit="census" if (rng_mode == "counter" or shape == "cic") else True, shape=shape)
         s_.setStream(stream.cuda_stream)
         s_.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
         if rng_mode == "reference":
@@ -533,6 +533,26 @@ def main():
             "streamed_bytes_per_launch": 50.0 * n_local,
         }}
         ext.destroy()
+        # "C2 with both cic and ref11 reported": the same frame with the bilinear deposit (extension key shape:'cic')
+        cic = build("reference", shape="cic")
+        cic.precalc(); cic.sort()
+        for _ in range(args.warmup):
+            cic.precalc(); cic.step(); cic.density()
+        cic.sync(); torch.cuda.synchronize()
+        cic.resetStats(); cic.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cic.precalc(); cic.step(); cic.density()
+        cic.sync(); torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        cs = cic.stats()
+        out["extensions"]["c2_cic"] = {
+            "what": "spec.shape = 1 (extension, no reference counterpart): density() deposits bilinearly on the four nearest cell centres "
+                    "(16 LDS atomics per particle in a separate pass) instead of the reference's 11x11 sprite (4, fused into the push)",
+            "value": 2.0 * n_local * args.steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / args.steps,
+            "push_avg_launch_ms": cs["ms_push"] / max(1, cs["step_launches"]),
+            "cic_sums_avg_launch_ms": cs["ms_deposit"] / max(1, cs["deposit_launches"]), "rebinning_launches": cs["sort_passes"]}
+        cic.destroy()
         out["extensions"]["dense_sor"] = dense_sor_line(local_rank)
         out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, stream=stream,
                                             cpu=not args.no_cpu_baseline)

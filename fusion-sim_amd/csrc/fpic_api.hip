@@ -240,7 +240,7 @@ int launch_push(fpic_handle* h, int nsub)
     // launch, writes the sorted order itself; float state with unfused_deposit == 0 forms the per-cell
     // sums as well (for double the coefficient window alone fills the LDS, so the sums stay separate)
     const bool fuse = h->binned && h->spec.unfused_deposit != 1;
-    const bool sums = fuse && sizeof(T) == 4 && h->spec.unfused_deposit == 0;
+    const bool sums = fuse && sizeof(T) == 4 && h->spec.unfused_deposit == 0 && h->spec.shape == FPIC_SHAPE_REF11; // the fused sums are the sprite's
     const bool scatter = fuse && h->scatter_pending;
     TileArgs<T> t{};
     t.ntx = h->ntx; t.ntz = h->ntz; t.ntiles = h->ntiles;
@@ -340,8 +340,12 @@ int launch_cell_sums(fpic_handle* h)
     timing_begin(h, KC_DEPOSIT);
     HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color [0,0,0,0] (empic.js:1476)
     HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
-    cell_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), kSumsThreads, kSumsLdsBytes, h->stream>>>(
-        arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work2[h->wl], h->nwork2[h->wl], static_cast<T*>(h->cell_sums), h->spilled);
+    if (h->spec.shape == FPIC_SHAPE_CIC)
+        cic_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), kSumsThreads, kSumsLdsBytes, h->stream>>>(
+            arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work2[h->wl], h->nwork2[h->wl], static_cast<T*>(h->cell_sums), h->spilled);
+    else
+        cell_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), kSumsThreads, kSumsLdsBytes, h->stream>>>(
+            arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work2[h->wl], h->nwork2[h->wl], static_cast<T*>(h->cell_sums), h->spilled);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     return record_spill(h);
@@ -486,6 +490,10 @@ int create_state(fpic_handle* h)
 
     float w[kStampCells];
     build_stamp(w);
+    if (h->spec.shape == FPIC_SHAPE_CIC) { // the bilinear sums are the moments already: a one-cell stamp
+        for (float& v : w) v = 0.0f;
+        w[kStampCells / 2] = 1.0f;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->stamp, w, sizeof w, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
 
@@ -740,6 +748,7 @@ int validate_spec(const fpic_spec* s)
     if (s->precision != FPIC_F32 && s->precision != FPIC_F64) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".precision <- must be 0 (f32) or 1 (f64)");
     if (s->rng_mode != 0 && s->rng_mode != 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".rng_mode <- must be 0 (reference) or 1 (counter)");
     if (s->unfused_deposit < 0 || s->unfused_deposit > 2) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".unfused_deposit <- must be 0, 1 or 2");
+    if (s->shape != FPIC_SHAPE_REF11 && s->shape != FPIC_SHAPE_CIC) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".shape <- must be 0 (ref11) or 1 (cic)");
     if (s->geometry != FPIC_GEOM_CYL_RZ && s->geometry != FPIC_GEOM_CART3D) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".geometry <- must be 0 (cyl_rz) or 1 (cart3d)");
     return FPIC_OK;
 }
@@ -818,7 +827,9 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     rc = (h->prec == FPIC_F32) ? create_state<float>(h) : create_state<double>(h);
     if (rc) return bail(rc);
     // the scatter's LDS image (72 KiB of double accumulators) exceeds the 64 KiB static limit
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(cic_sums_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(cic_sums_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_sums_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSumsLdsBytes))) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<float, false, false, false>, push_tiles_lds_bytes<float, false>())) != hipSuccess ||
         (e = set_lds(push_tiles_kernel<float, false, false, true>, push_tiles_lds_bytes<float, false>())) != hipSuccess ||

@@ -209,6 +209,92 @@ __global__ __launch_bounds__(kSumsThreads) void cell_sums_kernel(ParticleArrays<
     if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
 }
 
+// EXTENSION spec.shape = 1 (SURVEY.md 8(b) key shape:'cic'; no reference counterpart): the vertex colour spread
+// bilinearly over the four cell centres around the point (oracle: orc_*_deposit_cic).  Same workgroup, window
+// and flush as cell_sums_kernel; the per-cell grid then IS the moments grid (the finish stage runs with a
+// one-cell stamp).  16 LDS atomics per particle against 4 for the reference's shape.
+template <typename T>
+__global__ __launch_bounds__(kSumsThreads) void cic_sums_kernel(ParticleArrays<T> p, int nr, int nz, int ntx,
+                                                                const BlockWork* __restrict__ work,
+                                                                const uint32_t* __restrict__ nwork,
+                                                                T* __restrict__ cell_sums, unsigned long long* spilled)
+{
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int LW = kTileLds;
+    constexpr int BS = kSumsThreads;
+    extern __shared__ double tile[];
+    if (blockIdx.x >= *nwork) return;
+    const BlockWork w = work[blockIdx.x];
+    const int i0 = static_cast<int>(w.tile % ntx) * kTileSide - kTileHalo;
+    const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kTileHalo;
+    for (int k = threadIdx.x; k < LW * LW * 4; k += BS) tile[k] = 0.0;
+    __syncthreads();
+    const size_t gw = static_cast<size_t>(nr) + 1;
+    unsigned int my_spill = 0;
+    const size_t first = (static_cast<size_t>(w.begin) / PPT) * PPT;
+    for (size_t base = first + static_cast<size_t>(threadIdx.x) * PPT; base < w.end; base += BS * PPT) {
+        T x[PPT], y[PPT], z[PPT], vx[PPT], vy[PPT], vz[PPT];
+        load_lane<T, PPT>(p.x, base, x);
+        load_lane<T, PPT>(p.y, base, y);
+        load_lane<T, PPT>(p.z, base, z);
+        load_lane<T, PPT>(p.vx, base, vx);
+        load_lane<T, PPT>(p.vy, base, vy);
+        load_lane<T, PPT>(p.vz, base, vz);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const size_t i = base + k;
+            if (i < w.begin || i >= w.end) continue;
+            T r;
+            int ic, jc;
+            if (!deposit_cell(x[k], y[k], z[k], nr, nz, r, ic, jc)) continue;
+            const T dx = x[k] / r, dy = y[k] / r;
+            const T col[4] = { static_cast<T>(0.001) * (vx[k] * dx + vy[k] * dy), static_cast<T>(0.001) * (vy[k] * dx - vx[k] * dy),
+                               static_cast<T>(0.001) * vz[k], static_cast<T>(0.001) * static_cast<T>(1) };
+            const T gi = r * static_cast<T>(nr) - static_cast<T>(0.5), gj = z[k] * static_cast<T>(nz) - static_cast<T>(0.5);
+            const T fi0 = sizeof(T) == 4 ? floorf(gi) : floor(gi), fj0 = sizeof(T) == 4 ? floorf(gj) : floor(gj);
+            const int ci0 = static_cast<int>(fi0), cj0 = static_cast<int>(fj0);
+            T wr[2], wz[2];
+            wr[1] = gi - fi0; wr[0] = static_cast<T>(1) - wr[1];
+            wz[1] = gj - fj0; wz[0] = static_cast<T>(1) - wz[1];
+            bool spilled_here = false;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int j = cj0 + b;
+                if (j < 0 || j >= nz) continue;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int ii = ci0 + a;
+                    if (ii < 0 || ii >= nr) continue;
+                    const T wgt = wr[a] * wz[b];
+                    const int li = ii - i0, lj = j - j0;
+                    if (li >= 0 && li < LW && lj >= 0 && lj < LW) {
+                        double* t = tile + 4 * (lj * LW + li);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) atomicAdd(t + c, static_cast<double>(col[c] * wgt));
+                    } else {
+                        T* g = cell_sums + 4 * (static_cast<size_t>(ii) + gw * j);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) atomicAdd(g + c, col[c] * wgt);
+                        spilled_here = true;
+                    }
+                }
+            }
+            if (spilled_here) ++my_spill;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < LW * LW * 4; k += BS) {
+        const double v = tile[k];
+        if (v == 0.0) continue;
+        const int lj = k / (LW * 4);
+        const int rem = k - lj * (LW * 4);
+        const int gi = i0 + (rem >> 2), gj = j0 + lj;
+        if (gi < 0 || gi > nr || gj < 0 || gj > nz) continue;
+        atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(v));
+    }
+    if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
+}
+
 // ------------------------------------------------------------------ scatter stage 2 + K5 + K6 + K7
 //
 // moments01 = stamp (*) cell_sums, cropped at the grid's edges (empic.js:1473-1478);

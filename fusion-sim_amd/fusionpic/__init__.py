@@ -184,7 +184,7 @@ class CylindricalParticlePusher:
     """Object returned by makeCylindricalParticlePusher (empic.js:1528)."""
 
     def __init__(self, spec, precision="fp32", device=0, count=0, compat=True, sort_interval=0, fuse_deposit=True,
-                 rng="reference", seed=0, library=None):
+                 rng="reference", seed=0, library=None, shape="ref11"):
         _validate_spec(spec)
         self._lib = library or load_library()
         self.spec = dict(spec)
@@ -200,6 +200,7 @@ class CylindricalParticlePusher:
         # keeps the census and the re-binning, the per-cell sums are a separate pass
         s.unfused_deposit = 2 if fuse_deposit == "census" else (0 if fuse_deposit else 1)
         s.rng_mode = {"reference": 0, "counter": 1}[rng]
+        s.shape = {"ref11": 0, "cic": 1}[spec.get("shape", shape)]   # SURVEY 8(b) extension key
         s.rng_seed_lo, s.rng_seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
         self.precision = s.precision
         self.nr, self.nz = int(spec["nr"]), int(spec["nz"])

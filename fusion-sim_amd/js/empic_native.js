@@ -26,6 +26,7 @@
  * (default true; 'census' keeps only the tile census and re-binning in step()), rng 'reference'|'counter' + seed (counter = Philox4x32-10 per particle
  * and sub-step instead of the reference's entropy-table generator; not the reference's
  * random stream).
+ * shape 'cic' replaces density()'s 11x11 sprite by a bilinear deposit on the four nearest cell centres (extension).
  * geometry 'cart3d' (+ ny, length_y, solver 'poisson_fft'|'none', macro_weight) selects the self-consistent
  * electrostatic box — an extension with no reference counterpart (include/fusionpic.h): radius, height are
  * then the box lengths along x and z, nr, nz the node counts; same method names, plus addSpecies, addB,
@@ -128,7 +129,7 @@ function makeBox(spec, lib) {
     const n0 = spec.count ? spec.count : spec.nparticles * spec.nparticles;
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass, spec.particle_charge,
         spec.count || 0, fp64 ? 1 : 0, spec.device || 0, 0, spec.sort_interval || 0, 0, 0, 0, 0,
-        1, spec.solver === 'none' ? 0 : 1, spec.ny, spec.length_y, spec.macro_weight === undefined ? 1 : spec.macro_weight);
+        1, spec.solver === 'none' ? 0 : 1, spec.ny, spec.length_y, spec.macro_weight === undefined ? 1 : spec.macro_weight, 0);
     const nx = spec.nr, ny = spec.ny, nz = spec.nz, nodes = nx * ny * nz;
     const counts = [n0];
     const Real = fp64 ? Float64Array : Float32Array;
@@ -185,9 +186,10 @@ exports.makeCylindricalParticlePusher = function (spec) {
         radius: 'number', height: 'number', nr: 'number', nz: 'number', dt: 'number',
         nparticles: 'number', particle_mass: 'number', particle_charge: 'number',
         precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
-        sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'], geometry: [, 'string'],
+        sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'], geometry: [, 'string'], shape: [, 'string'],
     });
     if (spec.geometry !== undefined && spec.geometry !== 'cyl_rz' && spec.geometry !== 'cart3d') throw new Error(".geometry <- must be 'cyl_rz' or 'cart3d'");
+    if (spec.shape !== undefined && spec.shape !== 'ref11' && spec.shape !== 'cic') throw new Error(".shape <- must be 'ref11' or 'cic'");
     if (spec.geometry === 'cart3d') return makeBox(spec, addon());
     // two admissible types: checked by hand, the reference's validator stops at the first alternative
     if (spec.fuse_deposit !== undefined && typeof spec.fuse_deposit !== 'boolean' && spec.fuse_deposit !== 'census') {
@@ -206,7 +208,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass,
         spec.particle_charge, spec.count || 0, fp64 ? 1 : 0, spec.device || 0, spec.compat === false ? 1 : 0,
         spec.sort_interval || 0, spec.fuse_deposit === 'census' ? 2 : (spec.fuse_deposit === false ? 1 : 0), spec.rng === 'counter' ? 1 : 0,
-        seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296, 0, 0, 0, 0, 0);
+        seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296, 0, 0, 0, 0, 0, spec.shape === 'cic' ? 1 : 0);
     const nr = spec.nr, nz = spec.nz;
     const Real = fp64 ? Float64Array : Float32Array;
     const out = {};

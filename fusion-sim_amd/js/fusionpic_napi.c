@@ -136,13 +136,13 @@ static napi_value undefined(napi_env env)
 }
 
 /* create(radius, height, nr, nz, dt, nparticles, mass, charge, count, precision, device, physical_a,
- *        sort_interval, unfused_deposit, rng_mode, seed_lo, seed_hi, geometry, solver, ny, length_y, macro_weight) */
+ *        sort_interval, unfused_deposit, rng_mode, seed_lo, seed_hi, geometry, solver, ny, length_y, macro_weight, shape) */
 static napi_value n_create(napi_env env, napi_callback_info info)
 {
-    napi_value argv[22];
-    if (!get_args(env, info, 22, argv, NULL)) return NULL;
-    double d[22];
-    for (int i = 0; i < 22; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
+    napi_value argv[23];
+    if (!get_args(env, info, 23, argv, NULL)) return NULL;
+    double d[23];
+    for (int i = 0; i < 23; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
     fpic_spec s;
     memset(&s, 0, sizeof s);
     s.radius = d[0]; s.height = d[1]; s.nr = (int32_t)d[2]; s.nz = (int32_t)d[3]; s.dt = d[4];
@@ -150,7 +150,7 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     s.count = (uint64_t)d[8]; s.precision = (int32_t)d[9]; s.device = (int32_t)d[10];
     s.physical_a = (int32_t)d[11]; s.sort_interval = (int32_t)d[12]; s.unfused_deposit = (int32_t)d[13];
     s.rng_mode = (int32_t)d[14]; s.rng_seed_lo = (uint32_t)d[15]; s.rng_seed_hi = (uint32_t)d[16];
-    s.geometry = (int32_t)d[17]; s.solver = (int32_t)d[18]; s.ny = (int32_t)d[19]; s.length_y = d[20]; s.macro_weight = d[21];
+    s.geometry = (int32_t)d[17]; s.solver = (int32_t)d[18]; s.ny = (int32_t)d[19]; s.length_y = d[20]; s.macro_weight = d[21]; s.shape = (int32_t)d[22];
     fpic_handle* h = NULL;
     if (fpic_create(&s, &h) != FPIC_OK) return throw_fpic(env, NULL);
     box_t* b = (box_t*)malloc(sizeof *b);

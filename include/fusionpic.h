@@ -103,6 +103,12 @@ typedef enum fpic_solver {
     FPIC_SOLVER_POISSON_FFT = 1  /* rocFFT forward/inverse around a hand-written k-space kernel */
 } fpic_solver;
 
+/* spec.shape: the deposit of density() on the (r,z) grid (SURVEY.md 8(b) key shape:'ref11'|'cic'). */
+typedef enum fpic_shape {
+    FPIC_SHAPE_REF11 = 0, /* the reference's 11x11 cos^2 point sprite (empic.js:949-1035) */
+    FPIC_SHAPE_CIC = 1    /* extension, no reference counterpart: bilinear over the four nearest cell centres */
+} fpic_shape;
+
 /* CART3D grids, node index i + nr*(j + ny*k) (i fastest, as the reference's texel index
  * 4*(i + j*nr), empic.js:1162). */
 typedef enum fpic_field3 {
@@ -154,7 +160,7 @@ typedef struct fpic_spec {
     int32_t geometry;       /* fpic_geometry; 0 = the reference's (r,z) pusher */
     int32_t solver;         /* fpic_solver (CART3D) */
     int32_t ny;             /* CART3D: nodes along y (nr along x, nz along z) */
-    int32_t shape;          /* reserved for the deposit shape on the (r,z) grid; 0 = the reference's 11x11 stamp */
+    int32_t shape;          /* fpic_shape of density() on the (r,z) grid; CART3D always deposits CIC */
     double length_y;        /* CART3D: box is radius (x) x length_y x height (z) metres */
     double macro_weight;    /* CART3D: real particles per macro-particle (charge density scale); 0 = 1 */
     double reserved[6];

@@ -129,18 +129,22 @@ void orc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 #define FN(x) orc_f32_##x
 #define SQRT sqrtf
 #define COS cosf
+#define FLOOR floorf
 #include "pic_oracle_impl.h"
 #undef REAL
 #undef FN
 #undef SQRT
 #undef COS
+#undef FLOOR
 
 #define REAL double
 #define FN(x) orc_f64_##x
 #define SQRT sqrt
 #define COS cos
+#define FLOOR floor
 #include "pic_oracle_impl.h"
 #undef REAL
 #undef FN
 #undef SQRT
 #undef COS
+#undef FLOOR

@@ -77,6 +77,7 @@ void orc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
                     int physical_a);                                                                   \
     void P##deposit(const REAL* pos, const REAL* vel, size_t n, const float* stamp, int nr, int nz,    \
                     REAL* moments);                                                                    \
+    void P##deposit_cic(const REAL* pos, const REAL* vel, size_t n, int nr, int nz, REAL* moments);    \
     void P##deposit_cells(const REAL* pos, size_t n, int nr, int nz, int32_t* cells);                  \
     void P##normalise(const REAL* moments, int nr, int nz, REAL* norm);                                \
     void P##avg(const REAL* next, REAL* avg_B, REAL* avg_A, REAL ratio, size_t ncell);                 \

@@ -101,7 +101,8 @@ def inv_cdf(pdf):
 class OracleSim:
     """CPU twin of empic.makeCylindricalParticlePusher(spec) (empic.js:30)."""
 
-    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None, rng="reference", seed=0, threads=1):
+    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None, rng="reference", seed=0, threads=1, shape="ref11"):
+        self.shape = shape  # "ref11": the reference's 11x11 stamp; "cic": the bilinear extension
         # threads > 1: the OpenMP build (timing only: the threaded deposit sums in another order)
         self.threads = int(threads)
         self._lib = lib_omp() if self.threads > 1 else lib()
@@ -223,6 +224,9 @@ class OracleSim:
 
     # ---- out.density (empic.js:1471-1495)
     def deposit(self):
+        if self.shape == "cic":   # extension: bilinear deposit on the four nearest cell centres
+            self._f("deposit_cic")(_p(self.pos_A), _p(self.vel_A), ctypes.c_size_t(self.n), self.nr, self.nz, _p(self.moments))
+            return
         self._f("deposit_threads" if self.threads > 1 else "deposit")(
             _p(self.pos_A), _p(self.vel_A), ctypes.c_size_t(self.n), _p(self.stamp), self.nr, self.nz, _p(self.moments))
 

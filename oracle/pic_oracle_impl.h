@@ -237,6 +237,48 @@ void FN(deposit)(const REAL* pos, const REAL* vel, size_t n, const float* stamp,
     }
 }
 
+/* EXTENSION (SURVEY.md 8(b) key shape:'cic'; no reference counterpart, parity unpinned): the same vertex colour
+ * spread bilinearly over the four cell CENTRES around the point instead of the 11x11 stamp.  With the window
+ * coordinates (gi, gj) = (r*nr, z*nz) of empic.js:997-999: i0 = floor(gi - 0.5), f = gi - 0.5 - i0, weights
+ * (1-f, f) on cells i0, i0+1 (same along z), w = wr*wz, colour*w accumulated in particle order.  Clipping of
+ * points outside [0,1]^2 and cropping at the grid's edges as for the sprite. */
+void FN(deposit_cic)(const REAL* pos, const REAL* vel, size_t n, int nr, int nz, REAL* moments)
+{
+    size_t ncell = (size_t)nr * nz;
+    for (size_t c = 0; c < 4 * ncell; ++c) moments[c] = (REAL)0;
+    for (size_t p = 0; p < n; ++p) {
+        const REAL* P = pos + 4 * p;
+        const REAL* V = vel + 4 * p;
+        REAL r = SQRT(P[0] * P[0] + P[1] * P[1]);
+        REAL z = P[2];
+        if (!(r >= (REAL)0 && r <= (REAL)1 && z >= (REAL)0 && z <= (REAL)1)) continue;
+        REAL dx = P[0] / r, dy = P[1] / r;
+        REAL vr = V[0] * dx + V[1] * dy;
+        REAL va = V[1] * dx - V[0] * dy;
+        REAL col[4] = { (REAL)0.001 * vr, (REAL)0.001 * va, (REAL)0.001 * V[2], (REAL)0.001 * (REAL)1 };
+        REAL gi = r * (REAL)nr - (REAL)0.5, gj = z * (REAL)nz - (REAL)0.5;
+        REAL fi0 = FLOOR(gi), fj0 = FLOOR(gj);
+        int i0 = (int)fi0, j0 = (int)fj0;
+        REAL wr[2], wz[2];
+        wr[1] = gi - fi0; wr[0] = (REAL)1 - wr[1];
+        wz[1] = gj - fj0; wz[0] = (REAL)1 - wz[1];
+        for (int b = 0; b < 2; ++b) {
+            int j = j0 + b;
+            if (j < 0 || j >= nz) continue;
+            for (int a = 0; a < 2; ++a) {
+                int i = i0 + a;
+                if (i < 0 || i >= nr) continue;
+                REAL w = wr[a] * wz[b];
+                REAL* m = moments + 4 * ((size_t)i + (size_t)nr * j);
+                m[0] += col[0] * w;
+                m[1] += col[1] * w;
+                m[2] += col[2] * w;
+                m[3] += col[3] * w;
+            }
+        }
+    }
+}
+
 #ifdef _OPENMP
 /* Timing variant for bench.py's all-cores baseline (built only into libpic_oracle_omp.so):
  * the same per-particle arithmetic as deposit(), particles split into contiguous ranges, one

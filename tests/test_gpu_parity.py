@@ -857,6 +857,39 @@ def test_library_communicator_world_of_one(fp, po, overlap):
         s.destroy()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_cic_shape_matches_oracle(fp, po, precision):
+    """SURVEY 8(b) extension key shape:'cic' (no reference counterpart): density() spreads the vertex colour over
+    the four nearest cell centres; moments, normalised moments and the EMA within 1e-3 / 1e-6 of the oracle's,
+    the push untouched (bit-exact)."""
+    dtype = np.float32 if precision == "fp32" else np.float64
+    spec = make_spec(70, 45, 120, radius=0.8, height=0.5)
+    n = 14400
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=41, v_th=6e-3)
+    sim = fp.makeCylindricalParticlePusher(spec, precision=precision, shape="cic")
+    ora = po.OracleSim(spec, dtype=dtype, shape="cic")
+    for s in (sim, ora):
+        s.set(position=pos, velocity=vel, sink_mask=frame_sink(70, 45), source_pdf=frame_sink(70, 45))
+    sim.setRandomState(entropy, rand); ora.set_random_state(entropy, rand)
+    sim.addBZ(0.1); ora.add_bz(0.1)
+    sim.precalc(); ora.precalc()
+    tol = RTOL32 if precision == "fp32" else RTOL64
+    for frame in range(5):
+        sim.step(); ora.step()
+        sim.density(); ora.density()
+        got, want = sim.readMoments(np.float64).reshape(-1, 4), ora.moments.astype(np.float64).reshape(-1, 4)
+        np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=tol, atol=tol * want[:, 3].max() * 1e-3)
+        assert np.abs(got[:, :3] - want[:, :3]).max() <= tol * np.abs(want[:, :3]).max()
+        assert np.array_equal(got[:, 3] > 0, want[:, 3] > 0)            # the same cells are touched
+    g = sim.getParticles()
+    assert same_bits(g["position"], ora.positions()) and same_bits(g["velocity"], ora.velocities())
+    a, b = sim.readDensity(np.float64).reshape(-1, 4), ora.avg_A.astype(np.float64).reshape(-1, 4)
+    assert np.abs(a - b).max() <= 2 * tol * np.abs(b).max()
+    # the count channel sums to 0.001 x the number of unclipped, uncropped particles
+    assert abs(got[:, 3].sum() - want[:, 3].sum()) <= tol * want[:, 3].sum()
+    sim.destroy()
+
+
 def test_node_addon_rejects_wrong_sized_buffers():
     """A typed array of the wrong length is a JavaScript RangeError in the shim AND in the addon
     (called directly, without the shim), never a native out-of-bounds access."""
@@ -883,7 +916,7 @@ tryit('getCells', () => sim.getCells(new Int32Array(3)));
 tryit('setRandomState', () => sim.setRandomState({rand: new Float32Array(4 * 24)}));
 // the addon itself, bypassing the shim (first argument = the native handle is private to the shim:
 // reach the same entry points through a second pusher's closure is impossible, so build one here)
-const h = lib.create(1, 1, 12, 10, 2e-9, 5, 1.67e-27, 1.6e-19, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+const h = lib.create(1, 1, 12, 10, 2e-9, 5, 1.67e-27, 1.6e-19, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
 tryit('addon_readGrid', () => lib.readGrid(h, 2, new Float32Array(12 * 10)));
 tryit('addon_getParticles', () => lib.getParticles(h, new Float32Array(3), null, null, null));
 tryit('addon_getCells', () => lib.getCells(h, new Int32Array(24)));

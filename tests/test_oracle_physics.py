@@ -290,3 +290,27 @@ def test_current_loop_on_axis_field():
     bz_axis = B[50, 0, 2]
     want = 1.25663706e-6 * I / (2 * R) / (2 * np.pi)
     assert abs(bz_axis - want) / want < 0.01
+
+
+def test_cic_deposit_is_bilinear_and_conserves_the_count():
+    """extension shape:'cic' (no reference counterpart): weights are linear in the offset from the cell centres,
+    sum to one away from the edges, are cropped at the edges like the reference's sprite"""
+    import pic_oracle as po
+    from helpers import make_spec
+    spec = make_spec(16, 12, 1, radius=1.0, height=1.0)
+    sim = po.OracleSim(spec, dtype=np.float64, count=1, shape="cic")
+    for r, z in ((0.40625, 0.5), (0.42, 0.37), (0.5 / 16 * 0.3, 0.5), (0.999, 0.999)):
+        sim.set(position=[[r, 0.0, z]], velocity=[[1e-3, 2e-3, 3e-3]])
+        sim.deposit()
+        m = sim.moments.reshape(12, 16, 4)
+        gi, gj = r * 16 - 0.5, z * 12 - 0.5
+        i0, j0 = int(np.floor(gi)), int(np.floor(gj))
+        want = np.zeros((12, 16))
+        for b, wz in ((0, 1 - (gj - j0)), (1, gj - j0)):
+            for a, wr in ((0, 1 - (gi - i0)), (1, gi - i0)):
+                if 0 <= i0 + a < 16 and 0 <= j0 + b < 12:
+                    want[j0 + b, i0 + a] = wr * wz
+        assert np.allclose(m[..., 3], 0.001 * want, rtol=1e-12, atol=1e-18)
+        assert np.allclose(m[..., 0], 0.001 * 1e-3 * want, rtol=1e-12, atol=1e-20)      # v_r = v_x on the plane y = 0
+    interior = want.sum()
+    assert interior < 1.0                                                              # the last point is cropped at the corner
