@@ -381,7 +381,8 @@ int launch_stamp_finish(fpic_handle* h, const void* sums = nullptr, hipStream_t 
     }
     stamp_finish_kernel<T><<<grid, 256, 0, external ? on : h->stream>>>(static_cast<const T*>(sums ? sums : h->cell_sums), h->nr, h->nz,
                                                                       h->stamp, static_cast<T*>(h->moments), static_cast<T*>(h->norm),
-                                                                      static_cast<T*>(h->avg), static_cast<T>(0.01)); // u_ratio (empic.js:1083)
+                                                                      static_cast<T*>(h->avg), static_cast<T>(0.01), // u_ratio (empic.js:1083)
+                                                                      h->spec.shape == FPIC_SHAPE_CIC ? 1 : 0);
     if (!external) timing_end(h);
     HIP_TRY(h, hipGetLastError());
     if (external) {

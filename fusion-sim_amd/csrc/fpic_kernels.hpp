@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kSumsThreads) void cic_sums_kernel(ParticleArrays<T
 template <typename T>
 __global__ __launch_bounds__(256) void stamp_finish_kernel(const T* __restrict__ cell_sums, int nr, int nz,
                                                            const float* __restrict__ stamp, T* __restrict__ moments,
-                                                           T* __restrict__ norm, T* __restrict__ avg, T ratio)
+                                                           T* __restrict__ norm, T* __restrict__ avg, T ratio, int identity = 0)
 {
     constexpr int OT = 32;                      // output tile edge
     constexpr int LW = OT + 2 * kStampReach;    // staged cell_sums tile edge
@@ -330,7 +330,11 @@ __global__ __launch_bounds__(256) void stamp_finish_kernel(const T* __restrict__
         const int i = i0 + tx, j = j0 + lj;
         if (i >= nr || j >= nz) continue;
         T acc[4] = { 0, 0, 0, 0 };
-        for (int b = 0; b < kStampSide; ++b) {
+        if (identity) { // shape 'cic': the per-cell grid is the moments grid (and 0 x NaN of a neighbour must not leak in)
+            const T* s = g + 4 * ((lj + kStampReach) * LW + (tx + kStampReach));
+            acc[0] = s[0]; acc[1] = s[1]; acc[2] = s[2]; acc[3] = s[3];
+        }
+        for (int b = 0; b < (identity ? 0 : kStampSide); ++b) {
 #pragma unroll
             for (int a = 0; a < kStampSide; ++a) {
                 // source cell (i - di, j - dj) with di = 5 - a, dj = 5 - b

@@ -879,12 +879,16 @@ def test_cic_shape_matches_oracle(fp, po, precision):
         sim.density(); ora.density()
         got, want = sim.readMoments(np.float64).reshape(-1, 4), ora.moments.astype(np.float64).reshape(-1, 4)
         np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=tol, atol=tol * want[:, 3].max() * 1e-3)
-        assert np.abs(got[:, :3] - want[:, :3]).max() <= tol * np.abs(want[:, :3]).max()
+        # (a particle re-injected exactly at r = 0 has no direction: its velocity moments are NaN in the
+        # cell on the axis, quirk Q2 — on both sides, and only there)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.nanmax(np.abs(got[:, :3] - want[:, :3])) <= tol * np.nanmax(np.abs(want[:, :3]))
         assert np.array_equal(got[:, 3] > 0, want[:, 3] > 0)            # the same cells are touched
     g = sim.getParticles()
     assert same_bits(g["position"], ora.positions()) and same_bits(g["velocity"], ora.velocities())
     a, b = sim.readDensity(np.float64).reshape(-1, 4), ora.avg_A.astype(np.float64).reshape(-1, 4)
-    assert np.abs(a - b).max() <= 2 * tol * np.abs(b).max()
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.nanmax(np.abs(a - b)) <= 2 * tol * np.nanmax(np.abs(b))
     # the count channel sums to 0.001 x the number of unclipped, uncropped particles
     assert abs(got[:, 3].sum() - want[:, 3].sum()) <= tol * want[:, 3].sum()
     sim.destroy()
