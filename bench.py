@@ -266,6 +266,14 @@ def es3d_line(device, n, grid, steps, warmup, stream=None, cpu=True):
                   "note": "SURVEY 8(d): algorithmic = read rho + write phi; rocFFT's passes, the int64 conversion and the gradient move more"},
         "cycle_bytes_per_update": 48.0 + 8.0 * nodes / n,
     }
+    tr = measured_traffic({"workload": "c3", "particles": n, "grid": grid, "dtype": "f32"})
+    if tr:
+        out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+        out["roofline"]["traffic_source"] = "%s: %s" % (tr.get("file"), tr.get("source"))
+        if push_ms > 0:
+            out["roofline"]["traffic_rate_GBs"] = tr["bytes_per_launch"] / (push_ms * 1e-3) / 1e9
+    else:
+        out["roofline"]["traffic_source"] = "no committed PMC pass for this configuration (profiles/r*_c3_traffic.json)"
     if cpu:
         try:
             out["cpu_port"] = es3d_cpu_port()
