@@ -13,6 +13,11 @@
  *   - dot(a,b) sums left to right, length(v) = sqrt(dot(v,v)), sqrt and divide are IEEE,
  *     cos is Math.cos rounded to float32;
  *   - texture2D is NEAREST + CLAMP_TO_EDGE: texel = clamp(floor(u*W), 0, W-1), NaN -> 0.
+ * A SECOND convention set, setConvention('gpu'), makes the other common choices of a GPU's GLSL compiler
+ * — a*b + c and a*b - c contracted into one fused multiply-add, dot() as a chain of them, x / y as
+ * x * (1 / y) with a rounded reciprocal, the viewport transform of a point in float32 (swgl.js) — so that
+ * running the reference under both gives an honest error bar on "matches the reference" for a real browser
+ * GPU (tests/golden/conventions.json, tests/test_oracle_conventions.py).  Neither set is "the" GPU.
  *
  * Supported: precision / uniform / varying / attribute declarations; void main(); float,
  * vec2-4 locals; = and += ; if / else; for (float i = a; i < b; i++); ternaries; + - * / ;
@@ -22,6 +27,15 @@
 'use strict';
 
 const f = Math.fround;
+
+let CONVENTION = 'ieee';
+function setConvention(name) {
+    if (name !== 'ieee' && name !== 'gpu') throw new Error('glsl: unknown convention ' + name);
+    CONVENTION = name;
+}
+// a*b + c with one rounding: the product of two float32 is exact in a double; the sum is rounded to double
+// and then to float32 (the double rounding differs from a true fma in rare ties only)
+function fma(a, b, c) { return f(a * b + c); }
 
 // ------------------------------------------------------------------ tokenizer
 function tokenize(src) {
@@ -175,9 +189,23 @@ function map2(a, b, fn) {
 }
 const OPS = {
     '+': function (x, y) { return f(x + y); }, '-': function (x, y) { return f(x - y); },
-    '*': function (x, y) { return f(x * y); }, '/': function (x, y) { return f(x / y); },
+    '*': function (x, y) { return f(x * y); },
+    '/': function (x, y) { return CONVENTION === 'gpu' ? f(x * f(1 / y)) : f(x / y); },
 };
-function dot(a, b) { let s = f(a[0] * b[0]); for (let i = 1; i < a.length; i++) s = f(s + f(a[i] * b[i])); return s; }
+function dot(a, b) {
+    let s = f(a[0] * b[0]);
+    for (let i = 1; i < a.length; i++) s = CONVENTION === 'gpu' ? fma(a[i], b[i], s) : f(s + f(a[i] * b[i]));
+    return s;
+}
+// element-wise a*b + sign*c (or c + sign*a*b) over scalars and vectors
+function map3(a, b, c, fn) {
+    const n = Math.max(isVec(a) ? a.length : 0, isVec(b) ? b.length : 0, isVec(c) ? c.length : 0);
+    if (n === 0) return fn(a, b, c);
+    const at = function (v, i) { return isVec(v) ? v[i] : v; };
+    const out = [];
+    for (let i = 0; i < n; i++) out.push(fn(at(a, i), at(b, i), at(c, i)));
+    return out;
+}
 
 function sample(tex, uv) {
     const W = tex.width, H = tex.height;
@@ -249,6 +277,18 @@ function run(ast, env) {
         case 'bin': {
             if (n.op === '||') return ev(n.a) || ev(n.b);
             if (n.op === '&&') return ev(n.a) && ev(n.b);
+            if (CONVENTION === 'gpu' && (n.op === '+' || n.op === '-')) {
+                // contraction: a product feeding an add or a subtract becomes one fused multiply-add
+                const isMul = function (x) { return x.k === 'bin' && x.op === '*'; };
+                if (isMul(n.a)) {
+                    const c = ev(n.b);
+                    return map3(ev(n.a.a), ev(n.a.b), c, function (x, y, z) { return fma(x, y, n.op === '+' ? z : -z); });
+                }
+                if (isMul(n.b)) {
+                    const c = ev(n.a);
+                    return map3(ev(n.b.a), ev(n.b.b), c, function (x, y, z) { return fma(n.op === '+' ? x : -x, y, z); });
+                }
+            }
             const a = ev(n.a), b = ev(n.b);
             switch (n.op) {
             case '<': return a < b; case '>': return a > b; case '<=': return a <= b; case '>=': return a >= b;
@@ -287,4 +327,4 @@ function run(ast, env) {
     return env;
 }
 
-module.exports = { parse: parse, run: run, fround: f };
+module.exports = { parse: parse, run: run, fround: f, setConvention: setConvention, convention: function () { return CONVENTION; } };

@@ -302,7 +302,7 @@ writeJson('stamp.json', { nshape: 11, red: stamp });
 })();
 
 // (8) the reference's shaders evaluated in software: small scenes, every pass
-function swglScene(name, cfg) {
+function swglScene(name, cfg, keepOnly) {
     lcg = cfg.seed;
     const spec = cfg.spec;
     const ref = makeReference(true);
@@ -350,6 +350,12 @@ function swglScene(name, cfg) {
         sim.density();
         snap('density' + k, ['moments01', 'moments01_norm', 'moments01_avgA', 'moments01_avgB']);
     }
+    if (keepOnly) { // convention study (section 10): hand the snapshots back, write nothing
+        const all = new Float32Array(Buffer.concat(chunks).buffer.slice(0));
+        const out = {};
+        Object.keys(index).forEach(function (k) { out[k] = all.subarray(index[k][0], index[k][0] + index[k][1]); });
+        return out;
+    }
     fs.writeFileSync(path.join(outDir, name + '.f32.gz'), zlib.gzipSync(Buffer.concat(chunks), { level: 9 }));
     writeJson(name + '.json', {
         what: "outputs of the reference's own host code and shader strings evaluated by oracle/swgl.js + glsl_eval.js (float32 per operation); pins transcription, not GPU arithmetic",
@@ -362,23 +368,80 @@ function swglScene(name, cfg) {
 }
 
 // electrons in a squat cylinder, sink frame, block source: deaths and re-injection every frame
-swglScene('swgl_scene', {
+const SCENES = {};
+SCENES.swgl_scene = {
     seed: 0x5EED0008, input_seed: 99, frames: 6, r_max: 0.94, v: 0.3, E: 2e5, B: 0.02,
     spec: { radius: 0.35, height: 0.2, nr: 24, nz: 16, dt: 5e-10, nparticles: 12, particle_mass: 9.109e-31, particle_charge: -1.602e-19 },
     sink: function (i, j) { return (i === 23 || j === 0 || j === 15) ? 0 : 1; },
     pdf: function (i, j, rnd) { return (i < 6 && j >= 5 && j < 11) ? 0.5 + rnd() : 0.0; },
     painters: [['addCurrentLoop', 0.2, 0.1, 4e4], ['addCurrentZ', 3e3], ['addBZ', 0.01], ['addBTheta', -0.005]],
-});
+};
+swglScene('swgl_scene', SCENES.swgl_scene);
 // protons in the demo's 1 x 2 m proportions (factor_r != factor_z), no sink on the outer walls so
 // particles leave the unit square (clamped lookups, whole-point clipping in the deposit), an
 // absorbing slab inside, and a source with empty rows (NaN sites of the inverse CDF, quirk Q3)
-swglScene('swgl_tall', {
+SCENES.swgl_tall = {
     seed: 0x5EED0009, input_seed: 4242, frames: 5, r_max: 0.99, v: 0.25, E: 3e6, B: 1.5,
     spec: { radius: 1, height: 2, nr: 20, nz: 40, dt: 2e-9, nparticles: 10, particle_mass: 1.67e-27, particle_charge: 1.602e-19 },
     sink: function (i, j) { return (i >= 8 && i < 12 && j >= 10 && j < 30) ? 0 : 1; },
     pdf: function (i, j, rnd) { return (i % 3 === 1 || j < 4) ? 0.0 : 0.25 + rnd(); },
     painters: [['addCurrentLoop', 0.8, 2.0, -1e7], ['addCurrentLoop', 0.8, 0.0, 1e7], ['addBZ', 0.3]],
-});
+};
+swglScene('swgl_tall', SCENES.swgl_tall);
+
+// (10) how far the results move under the OTHER plausible arithmetic conventions of a GPU's GLSL compiler
+// (glsl_eval.js setConvention('gpu'): contracted multiply-adds, dot as an fma chain, division through a rounded
+// reciprocal, float32 viewport transform).  Both runs execute the reference's own shader text; the numbers are the
+// honest error bar on "matches the reference within 1e-3" for a real browser GPU, which no test here can reach.
+(function conventionStudy() {
+    const glslEval = require('./glsl_eval.js');
+    const report = { what: "the reference's own host code and shader strings evaluated under two arithmetic conventions (oracle/glsl_eval.js): " +
+        "'ieee' = one float32 rounding per operation, no contraction (the convention of the restatement and of the HIP kernels); 'gpu' = a*b+-c " +
+        "contracted to fused multiply-adds, dot() as an fma chain, x/y as x*(1/y) with a rounded reciprocal, float32 viewport transform of point " +
+        "sprites.  Per stage: largest difference relative to the largest magnitude of the stage's texture, NGP cells and alive flags that differ.",
+        scenes: {} };
+    Object.keys(SCENES).forEach(function (name) {
+        const cfg = SCENES[name], spec = cfg.spec, n = spec.nparticles * spec.nparticles;
+        glslEval.setConvention('ieee');
+        const a = swglScene(name, cfg, true);
+        glslEval.setConvention('gpu');
+        const b = swglScene(name, cfg, true);
+        glslEval.setConvention('ieee');
+        const stages = {};
+        const rel = function (x, y) {
+            let d = 0, m = 0, nan = 0;
+            for (let i = 0; i < x.length; i++) {
+                if (Number.isNaN(x[i]) || Number.isNaN(y[i])) { if (Number.isNaN(x[i]) !== Number.isNaN(y[i])) nan++; continue; }
+                d = Math.max(d, Math.abs(x[i] - y[i])); m = Math.max(m, Math.abs(x[i]));
+            }
+            return { max_rel: m > 0 ? d / m : 0, nan_mismatch: nan };
+        };
+        const cell = function (p, i) {
+            const r = Math.fround(Math.sqrt(Math.fround(Math.fround(p[4 * i] * p[4 * i]) + Math.fround(p[4 * i + 1] * p[4 * i + 1]))));
+            const c = function (u, W) { const t = Math.fround(u * W); return !(t >= 0) ? 0 : (t >= W ? W - 1 : Math.floor(t)); };
+            return c(r, spec.nr) + spec.nr * c(p[4 * i + 2], spec.nz);
+        };
+        Object.keys(a).forEach(function (key) {
+            const st = rel(a[key], b[key]);
+            if (/position_A$/.test(key)) {
+                let cells = 0, alive = 0;
+                for (let i = 0; i < n; i++) {
+                    if (cell(a[key], i) !== cell(b[key], i)) cells++;
+                    if ((a[key][4 * i + 3] > 0.5) !== (b[key][4 * i + 3] > 0.5)) alive++;
+                }
+                st.cells_differ = cells; st.alive_differ = alive; st.particles = n;
+            }
+            if (/moments01$/.test(key)) {
+                let touched = 0;
+                for (let i = 3; i < a[key].length; i += 4) if ((a[key][i] > 0) !== (b[key][i] > 0)) touched++;
+                st.touched_cells_differ = touched;
+            }
+            stages[key] = st;
+        });
+        report.scenes[name] = { spec: spec, frames: cfg.frames, stages: stages };
+    });
+    writeJson('conventions.json', report);
+})();
 
 // (9) the reference's dense iterative solver (matrix_webgl.js, SURVEY 8(f) next-4), evaluated in
 // software the same way as section 8.  Inputs are float32-representable and stored in the blob.

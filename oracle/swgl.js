@@ -143,7 +143,11 @@ function makeSoftwareGL(names) {
                     const p = e.gl_Position, size = e.gl_PointSize;
                     const w = p[3];
                     if (!(p[0] >= -w && p[0] <= w && p[1] >= -w && p[1] <= w && p[2] >= -w && p[2] <= w)) continue;
-                    const xw = (p[0] / w + 1) * 0.5 * W, yw = (p[1] / w + 1) * 0.5 * H;
+                    // viewport transform: exact here; in float32, step by step, under the 'gpu' convention (where a
+                    // point within an ulp of a pixel edge can land in the neighbouring cell)
+                    const gpu = glsl.convention() === 'gpu';
+                    const xw = gpu ? f(f(f(p[0] / w) + 1) * f(0.5 * W)) : (p[0] / w + 1) * 0.5 * W;
+                    const yw = gpu ? f(f(f(p[1] / w) + 1) * f(0.5 * H)) : (p[1] / w + 1) * 0.5 * H;
                     const varyings = {};
                     varyingNames.forEach(function (name) { varyings[name] = e[name]; });
                     // pixel centres with xw - size/2 < c <= xw + size/2 (ties: see header)
