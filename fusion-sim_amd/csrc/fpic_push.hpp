@@ -123,6 +123,7 @@ constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
 constexpr int kPushThreads = 512;
 constexpr int kNbr = 5;                                // tile neighbourhood tracked in LDS when binning
 constexpr int kNbrSlots = kNbr * kNbr + 1;             // + the bin of clipped particles
+constexpr int kOwnSlot = (kNbr / 2) * kNbr + kNbr / 2; // the workgroup's own tile
 
 // LDS pointers carry their address space in the type: through a generic pointer the
 // compiler emits flat_load instead of ds_read_b128.  (HIP's float4/double2 classes
@@ -154,7 +155,7 @@ struct WindowTables {
     {
         const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
         const bool in = li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds);
-        const FPIC_LDS T* cf = lcoef + 12u * (in ? lj * kPushLds + li : 0u);
+        const FPIC_LDS T* cf = lcoef + __umul24(12u, in ? __umul24(lj, kPushLds) + li : 0u); // (24-bit multiplies are full rate)
         load4_lds(cf, R1);
         load4_lds(cf + 4, R2);
         load4_lds(cf + 8, R3);
@@ -164,7 +165,7 @@ struct WindowTables {
     {
         const unsigned li = static_cast<unsigned>(ci - i0), lj = static_cast<unsigned>(cj - j0);
         const bool in = li < static_cast<unsigned>(kPushLds) && lj < static_cast<unsigned>(kPushLds);
-        bool k = lsink[in ? lj * kPushLds + li : 0u] != 0;
+        bool k = lsink[in ? __umul24(lj, kPushLds) + li : 0u] != 0;
         if (!in) k = g.keep(ci, cj);
         return k;
     }
@@ -294,13 +295,17 @@ struct WindowSums {
     T* cell_sums;                // global (nr+1) x (nz+1) x 4
     uint32_t* tile_count;        // global census
     unsigned* spilled;           // lane-local count of particles outside the window
+    unsigned* own_census;        // lane-local count of final states in the workgroup's own tile
     __device__ __forceinline__ void add(const Particle<T>& q, int nr, int nz) const
     {
         int ic = 0, jc = 0;
         const bool visible = sprite_cell(q, nr, nz, ic, jc);
         uint32_t key;
         const int s = nb.slot(visible, ic, jc, key);
-        if (s >= 0) __hip_atomic_fetch_add(lcensus + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // nearly every particle is still in the workgroup's own tile: those are counted in a register (64 lanes
+        // adding to ONE LDS word are serialised), the others by LDS atomics
+        if (s == kOwnSlot) ++*own_census;
+        else if (s >= 0) __hip_atomic_fetch_add(lcensus + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAdd(tile_count + key, 1u);
         if (!SUMS || !visible) return;
         const T dx = q.x / q.r, dy = q.y / q.r;
@@ -309,7 +314,7 @@ struct WindowSums {
         const T c2 = static_cast<T>(0.001) * q.vz;
         const unsigned li = static_cast<unsigned>(ic - i0), lj = static_cast<unsigned>(jc - j0);
         if (li < static_cast<unsigned>(kTileLds) && lj < static_cast<unsigned>(kTileLds)) {
-            FPIC_LDS double* t = lsums + 4u * (lj * kTileLds + li);
+            FPIC_LDS double* t = lsums + 4u * (__umul24(lj, kTileLds) + li);
             __hip_atomic_fetch_add(t, static_cast<double>(c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(t + 1, static_cast<double>(c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(t + 2, static_cast<double>(c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
     __syncthreads();
     const WindowTables<T> tab{ GlobalTables<T>{ a.coef, a.sink_alive, a.nr }, lcoef, lsink, i0, j0 };
     const TileNeighbourhood nb{ ti, tj, t.ntx, t.ntz, t.ntiles - 1 };
-    unsigned my_spill = 0;
+    unsigned my_spill = 0, my_own = 0;
     const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
     const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
 
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             Particle<T> q[PPT];
             load_state<T, CTR>(a, base, cnt, q);
             if constexpr (FUSE)
-                advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+                advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill, &my_own }, cnt, q);
             else
                 advance_state<T, CTR>(a, tab, NoSums{}, cnt, q);
             store_state<T, CTR>(a, base, cnt, q);
@@ -531,6 +536,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         // workgroup writes into a bin is then one contiguous run (ranks are handed out by
         // LDS atomics in lane order), so cache lines are completed by a single L2 instead of
         // being written piecemeal by many workgroups on several XCDs.
+        uint32_t own_count = 0;
         for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
             const size_t base = g * PPT;
             const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
@@ -548,10 +554,12 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
                     const bool visible = sprite_cell(p, a.nr, a.nz, ic, jc);
                     uint32_t key;
                     const int sl = nb.slot(visible, ic, jc, key);
-                    if (sl >= 0) __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (sl == kOwnSlot) ++own_count;
+                    else if (sl >= 0) __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
+        if (own_count) __hip_atomic_fetch_add(lrank + kOwnSlot, own_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         if (threadIdx.x < kNbrSlots) {
             const uint32_t c = lrank[threadIdx.x];
@@ -570,21 +578,38 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
             Particle<T> q[PPT];
             uint32_t dest[PPT], pid[PPT];
+            int slot_of[PPT];
             load_state<T, CTR>(a, base, cnt, q);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                dest[k] = 0; pid[k] = 0;
+                dest[k] = 0; pid[k] = 0; slot_of[k] = -2;
                 if (k < cnt) {
                     pid[k] = t.id[base + k];
                     int ic = 0, jc = 0;
                     const bool visible = sprite_cell(q[k], a.nr, a.nz, ic, jc);
                     uint32_t key;
                     const int sl = nb.slot(visible, ic, jc, key);
-                    if (sl >= 0) dest[k] = lrange[sl] + __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else dest[k] = t.dst_tile_start[key] + atomicAdd(t.dst_tile_cursor + key, 1u); // beyond the 5x5 tiles: rare
+                    slot_of[k] = sl;
+                    if (sl >= 0 && sl != kOwnSlot) dest[k] = lrange[sl] + __hip_atomic_fetch_add(lrank + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else if (sl < 0) dest[k] = t.dst_tile_start[key] + atomicAdd(t.dst_tile_cursor + key, 1u); // beyond the 5x5 tiles: rare
                 }
             }
-            advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill }, cnt, q);
+            // stayers: one LDS atomic per wave and k, ranks inside the wave in lane order (consecutive lanes store
+            // to consecutive slots)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const bool own = k < cnt && slot_of[k] == kOwnSlot;
+                const unsigned long long mask = __ballot(own);
+                if (mask) {
+                    const int lane = static_cast<int>(threadIdx.x & 63);
+                    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+                    uint32_t wave_base = 0;
+                    if (lane == leader) wave_base = __hip_atomic_fetch_add(lrank + kOwnSlot, static_cast<uint32_t>(__popcll(mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    wave_base = __shfl(wave_base, leader);
+                    if (own) dest[k] = lrange[kOwnSlot] + wave_base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+                }
+            }
+            advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill, &my_own }, cnt, q);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 if (k < cnt) {
@@ -604,6 +629,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
 
 
     if constexpr (FUSE) {
+        if (my_own) __hip_atomic_fetch_add(lcensus + kOwnSlot, my_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
         // global addresses, so a wave's atomic is one 256-byte piece
