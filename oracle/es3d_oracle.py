@@ -52,6 +52,13 @@ class OracleES3D:
         self.E4 = np.zeros(4 * self.nodes, dtype=self.dtype)
         self.B0 = np.zeros(3)
         self.t = 0
+        # full EM (solver 'yee'): staggered fields 4 T per node, node-centred copies, integer current grid
+        if self.solver == "yee":
+            self.Ey = np.zeros(4 * self.nodes, dtype=self.dtype)
+            self.By = np.zeros(4 * self.nodes, dtype=self.dtype)
+            self.B4n = np.zeros(4 * self.nodes, dtype=self.dtype)
+            self.J4 = np.zeros(4 * self.nodes, dtype=self.dtype)
+            self.J_fixed = np.zeros(3 * self.nodes, dtype=np.int64)
 
     def _fn(self, name):
         return getattr(self.lib, name + self.suf)
@@ -122,7 +129,83 @@ class OracleES3D:
     def precalc(self):
         """fields <- particles: deposit and solve (the stage the reference's precalc() stands for, empic.js:1413)."""
         self.deposit()
+        if self.solver == "yee":
+            # initial condition of the EM run: the electrostatic field of the charge on the Yee edges (the lattice's
+            # Gauss law holds exactly and the charge-conserving current keeps it), B = the uniform external field
+            d = ctypes.c_double
+            self._fn("es3d_rho_real")(_ptr(self.rho_fixed), ctypes.c_size_t(self.nodes), d(self.rho_scale()), _ptr(self.rho))
+            self._fn("es3d_poisson")(_ptr(self.rho), self.nx, self.ny, self.nz, d(self.lx), d(self.ly), d(self.lz), _ptr(self.phi))
+            self._fn("em_edge_gradient")(_ptr(self.phi), self.nx, self.ny, self.nz, d(self.lx), d(self.ly), d(self.lz), _ptr(self.Ey))
+            b = self.By.reshape(-1, 4)
+            b[:, :3] = self.B0.astype(self.dtype)
+            self._fn("em_nodes")(_ptr(self.Ey), _ptr(self.By), self.nx, self.ny, self.nz, _ptr(self.E4), _ptr(self.B4n))
+            return
         self.solve()
+
+    # ---- full EM
+    def em_constants(self):
+        dt = self.dt
+        d = (self.lx / self.nx, self.ly / self.ny, self.lz / self.nz)
+        cb = np.array([dt / (2 * d[0]), dt / (2 * d[1]), dt / (2 * d[2])]).astype(self.dtype)
+        c2 = SPEED_OF_LIGHT ** 2
+        ce = np.array([c2 * dt / d[0], c2 * dt / d[1], c2 * dt / d[2]]).astype(self.dtype)
+        je = self.dtype.type(dt / EPS0)
+        # J = q0 W / (96 * 2^42 dt) * flux / (area of the dual face)
+        base = self.q0 * self.W / (96.0 * FIXED_ONE * dt)
+        jscale = np.array([base / (d[1] * d[2]), base / (d[0] * d[2]), base / (d[0] * d[1])])
+        return cb, ce, je, jscale
+
+    def em_substep(self):
+        cb, ce, je, jscale = self.em_constants()
+        self._fn("em_nodes")(_ptr(self.Ey), _ptr(self.By), self.nx, self.ny, self.nz, _ptr(self.E4), _ptr(self.B4n))
+        self.J_fixed[:] = 0
+        for s, sp in enumerate(self.species):
+            h = sp.charge * self.dt / (2 * sp.mass)
+            step = self.dt * SPEED_OF_LIGHT
+            par = np.array([h, SPEED_OF_LIGHT, step / self.lx, step / self.ly, step / self.lz]).astype(self.dtype)
+            ox, oy, oz = (np.empty_like(sp.x) for _ in range(3))
+            self._fn("em_push")(_ptr(sp.x), _ptr(sp.y), _ptr(sp.z), _ptr(sp.vx), _ptr(sp.vy), _ptr(sp.vz), _ptr(ox), _ptr(oy), _ptr(oz),
+                                ctypes.c_size_t(sp.n), _ptr(self.E4), _ptr(self.B4n), self.nx, self.ny, self.nz, _ptr(par))
+            self._fn("em_current")(_ptr(ox), _ptr(oy), _ptr(oz), _ptr(sp.x), _ptr(sp.y), _ptr(sp.z), ctypes.c_size_t(sp.n), self.nx, self.ny,
+                                   self.nz, self.charge_number(s), _ptr(self.J_fixed))
+        self._fn("em_j_real")(_ptr(self.J_fixed), ctypes.c_size_t(self.nodes), _ptr(jscale), _ptr(self.J4))
+        self._fn("em_update_b")(_ptr(self.By), _ptr(self.Ey), self.nx, self.ny, self.nz, _ptr(cb))
+        self._fn("em_update_e")(_ptr(self.Ey), _ptr(self.By), _ptr(self.J4), self.nx, self.ny, self.nz, _ptr(ce), ctypes.c_float(je) if self.dtype == np.float32 else ctypes.c_double(je))
+        self._fn("em_update_b")(_ptr(self.By), _ptr(self.Ey), self.nx, self.ny, self.nz, _ptr(cb))
+        self.t += 1
+
+    def set_lattice(self, E=None, B=None):
+        """the Yee lattice's own arrays, value[i][j][k][3]: E on the edges (Ex at (i+1/2,j,k), ...), B on the faces"""
+        for src, dst in ((E, self.Ey), (B, self.By)):
+            if src is not None:
+                a = np.asarray(src, dtype=np.float64)
+                assert a.shape == (self.nx, self.ny, self.nz, 3)
+                dst.reshape(self.nz, self.ny, self.nx, 4)[..., :3] = a.transpose(2, 1, 0, 3).astype(self.dtype)
+        self._fn("em_nodes")(_ptr(self.Ey), _ptr(self.By), self.nx, self.ny, self.nz, _ptr(self.E4), _ptr(self.B4n))
+
+    def gauss_residual(self):
+        """div E on the lattice minus (rho - mean rho) / eps0, per node (rho of the CURRENT positions is deposited here;
+        the mean is the neutralising background: the Poisson solve drops the mean mode)"""
+        self.deposit()
+        e = self.Ey.reshape(self.nz, self.ny, self.nx, 4).astype(np.float64)
+        d = (self.lx / self.nx, self.ly / self.ny, self.lz / self.nz)
+        div = ((e[..., 0] - np.roll(e[..., 0], 1, axis=2)) / d[0] + (e[..., 1] - np.roll(e[..., 1], 1, axis=1)) / d[1]
+               + (e[..., 2] - np.roll(e[..., 2], 1, axis=0)) / d[2])
+        rho = self.rho_fixed.reshape(self.nz, self.ny, self.nx).astype(np.float64) * self.rho_scale()
+        return div - (rho - rho.mean()) / EPS0, np.abs(rho).max() / EPS0
+
+    def em_field_energy(self):
+        dv = (self.lx / self.nx) * (self.ly / self.ny) * (self.lz / self.nz)
+        e = self.Ey.reshape(-1, 4)[:, :3].astype(np.float64)
+        b = self.By.reshape(-1, 4)[:, :3].astype(np.float64)
+        mu0 = 1.0 / (EPS0 * SPEED_OF_LIGHT ** 2)
+        return 0.5 * EPS0 * float((e ** 2).sum()) * dv + 0.5 / mu0 * float((b ** 2).sum()) * dv
+
+    def lattice_fields(self):
+        """(E, B) on the Yee lattice as [nx][ny][nz][3]"""
+        e = self.Ey.reshape(self.nz, self.ny, self.nx, 4)[..., :3].transpose(2, 1, 0, 3).copy()
+        b = self.By.reshape(self.nz, self.ny, self.nx, 4)[..., :3].transpose(2, 1, 0, 3).copy()
+        return e, b
 
     def push(self):
         for s, sp in enumerate(self.species):
@@ -131,6 +214,9 @@ class OracleES3D:
                                   _ptr(self.E4), self.nx, self.ny, self.nz, _ptr(par), int(has_b))
 
     def substep(self):
+        if self.solver == "yee":
+            self.em_substep()
+            return
         self.push()
         self.deposit()
         self.solve()

@@ -191,6 +191,172 @@ void FN(es3d_push)(REAL* x, REAL* y, REAL* z, REAL* vx, REAL* vy, REAL* vz, size
     }
 }
 
+
+/* ================================================================ full EM (Yee FDTD), BASELINE configs[4]
+ *
+ * PARITY UNPINNED (no reference counterpart).  Fields live on the Yee lattice, stored 4 T per node:
+ *   Ey[node] = (Ex(i+1/2,j,k), Ey(i,j+1/2,k), Ez(i,j,k+1/2), 0),  By[node] = (Bx(i,j+1/2,k+1/2), By(i+1/2,j,k+1/2), Bz(i+1/2,j+1/2,k), 0).
+ * One sub-step (E^n, B^n, x^n, v^(n-1/2) -> n+1):
+ *   nodes:  E4n, B4n = the lattice values averaged to the nodes (2 resp. 4 neighbours, periodic)
+ *   push:   CIC gather of E4n and B4n, Boris with the particle's own t = hB, s = 2t/(1+t^2), drift, wrap
+ *   J:      charge-conserving zigzag deposit in integers (es3d_current)
+ *   B^(n+1/2) = B^n - dt/2 curl E^n;  E^(n+1) = E^n + dt (c^2 curl B^(n+1/2) - J/eps0);  B^(n+1) = B^(n+1/2) - dt/2 curl E^(n+1)
+ */
+
+/* node-centred copies of the staggered fields */
+void FN(em_nodes)(const REAL* Ey, const REAL* By, int nx, int ny, int nz, REAL* E4n, REAL* B4n)
+{
+    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const size_t im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
+                const size_t c = i + sy * j + sz * k;
+#define AT(A, ii, jj, kk, comp) A[4 * ((size_t)(ii) + sy * (size_t)(jj) + sz * (size_t)(kk)) + (comp)]
+                E4n[4 * c] = (REAL)0.5 * (AT(Ey, im, j, k, 0) + AT(Ey, i, j, k, 0));
+                E4n[4 * c + 1] = (REAL)0.5 * (AT(Ey, i, jm, k, 1) + AT(Ey, i, j, k, 1));
+                E4n[4 * c + 2] = (REAL)0.5 * (AT(Ey, i, j, km, 2) + AT(Ey, i, j, k, 2));
+                E4n[4 * c + 3] = (REAL)0;
+                B4n[4 * c] = (REAL)0.25 * (((AT(By, i, jm, km, 0) + AT(By, i, j, km, 0)) + AT(By, i, jm, k, 0)) + AT(By, i, j, k, 0));
+                B4n[4 * c + 1] = (REAL)0.25 * (((AT(By, im, j, km, 1) + AT(By, i, j, km, 1)) + AT(By, im, j, k, 1)) + AT(By, i, j, k, 1));
+                B4n[4 * c + 2] = (REAL)0.25 * (((AT(By, im, jm, k, 2) + AT(By, i, jm, k, 2)) + AT(By, im, j, k, 2)) + AT(By, i, j, k, 2));
+                B4n[4 * c + 3] = (REAL)0;
+            }
+}
+
+/* one sub-step of every particle in the node-centred fields; the old positions are kept in ox, oy, oz for the
+ * current deposit.  par = { h (not /c), c, dt c / lx, dt c / ly, dt c / lz }: E in V/m, B in T, v in units of c */
+void FN(em_push)(REAL* x, REAL* y, REAL* z, REAL* vx, REAL* vy, REAL* vz, REAL* ox, REAL* oy, REAL* oz, size_t n, const REAL* E4n,
+                 const REAL* B4n, int nx, int ny, int nz, const REAL* par)
+{
+    const REAL h = par[0], hc = par[0] / par[1], dx = par[2], dy = par[3], dz = par[4];
+    const REAL q14 = (REAL)(1.0 / 16384.0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (size_t p = 0; p < n; ++p) {
+        int i, j, k, w1;
+        REAL fx[2], fy[2], fz[2];
+        FN(es3d_axis)(x[p], nx, &i, &w1); fx[1] = (REAL)w1 * q14; fx[0] = (REAL)(16384 - w1) * q14;
+        FN(es3d_axis)(y[p], ny, &j, &w1); fy[1] = (REAL)w1 * q14; fy[0] = (REAL)(16384 - w1) * q14;
+        FN(es3d_axis)(z[p], nz, &k, &w1); fz[1] = (REAL)w1 * q14; fz[0] = (REAL)(16384 - w1) * q14;
+        REAL E[3] = { 0, 0, 0 }, B[3] = { 0, 0, 0 };
+        for (int c = 0; c < 2; ++c)
+            for (int b = 0; b < 2; ++b)
+                for (int a = 0; a < 2; ++a) {
+                    const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
+                    const size_t node = (size_t)ii + (size_t)nx * ((size_t)jj + (size_t)ny * kk);
+                    const REAL w = (fx[a] * fy[b]) * fz[c];
+                    for (int m = 0; m < 3; ++m) {
+                        E[m] = E[m] + w * E4n[4 * node + m];
+                        B[m] = B[m] + w * B4n[4 * node + m];
+                    }
+                }
+        const REAL ax = hc * E[0], ay = hc * E[1], az = hc * E[2];
+        const REAL tx = h * B[0], ty = h * B[1], tz = h * B[2];
+        const REAL f = (REAL)2 / ((REAL)1 + ((tx * tx + ty * ty) + tz * tz));
+        const REAL sx = f * tx, sy = f * ty, sz = f * tz;
+        const REAL ux = vx[p] + ax, uy = vy[p] + ay, uz = vz[p] + az;
+        const REAL px = ux + (uy * tz - uz * ty);
+        const REAL py = uy + (uz * tx - ux * tz);
+        const REAL pz = uz + (ux * ty - uy * tx);
+        const REAL qx = ux + (py * sz - pz * sy);
+        const REAL qy = uy + (pz * sx - px * sz);
+        const REAL qz = uz + (px * sy - py * sx);
+        const REAL nvx = qx + ax, nvy = qy + ay, nvz = qz + az;
+        vx[p] = nvx; vy[p] = nvy; vz[p] = nvz;
+        ox[p] = x[p]; oy[p] = y[p]; oz[p] = z[p];
+        x[p] = FN(es3d_wrap)(x[p] + dx * nvx);
+        y[p] = FN(es3d_wrap)(y[p] + dy * nvy);
+        z[p] = FN(es3d_wrap)(z[p] + dz * nvz);
+    }
+}
+
+/* doubled fixed-point lattice coordinate of a normalised coordinate: 2 * (cell * 2^14 + w1) in [0, n * 2^15) */
+static inline int64_t FN(em_coord)(REAL u, int n)
+{
+    int i, w1;
+    FN(es3d_axis)(u, n, &i, &w1);
+    return 2 * ((int64_t)i * 16384 + w1);
+}
+
+/* charge-conserving current of the moves (ox,oy,oz) -> (x,y,z), accumulated into Jfix (3 int64 per node, see es3d_current) */
+void FN(em_current)(const REAL* ox, const REAL* oy, const REAL* oz, const REAL* x, const REAL* y, const REAL* z, size_t n, int nx, int ny,
+                    int nz, int Z, int64_t* Jfix)
+{
+    for (size_t p = 0; p < n; ++p) {
+        const int64_t a[3] = { FN(em_coord)(ox[p], nx), FN(em_coord)(oy[p], ny), FN(em_coord)(oz[p], nz) };
+        const int64_t b[3] = { FN(em_coord)(x[p], nx), FN(em_coord)(y[p], ny), FN(em_coord)(z[p], nz) };
+        es3d_current(a, b, nx, ny, nz, Z, Jfix);
+    }
+}
+
+/* J (A/m^2, 4 T per node: Jx on the x-edge, ...) from the integer grid: T((double)fixed * scale[comp]) */
+void FN(em_j_real)(const int64_t* Jfix, size_t nodes, const double* scale3, REAL* J4)
+{
+    for (size_t c = 0; c < nodes; ++c) {
+        for (int m = 0; m < 3; ++m) J4[4 * c + m] = (REAL)((double)Jfix[3 * c + m] * scale3[m]);
+        J4[4 * c + 3] = (REAL)0;
+    }
+}
+
+/* B -= coef * curl E on the Yee lattice (coef = dt/2 over the spacings: cb = { dt/2dx, dt/2dy, dt/2dz }) */
+void FN(em_update_b)(REAL* By, const REAL* Ey, int nx, int ny, int nz, const REAL* cb)
+{
+    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const size_t ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1, kp = (k + 1 == nz) ? 0 : k + 1;
+                const size_t c = i + sy * j + sz * k;
+                /* (curl E)_x at (i, j+1/2, k+1/2) = dEz/dy - dEy/dz */
+                const REAL cx = (AT(Ey, i, jp, k, 2) - AT(Ey, i, j, k, 2)) * cb[1] - (AT(Ey, i, j, kp, 1) - AT(Ey, i, j, k, 1)) * cb[2];
+                const REAL cy = (AT(Ey, i, j, kp, 0) - AT(Ey, i, j, k, 0)) * cb[2] - (AT(Ey, ip, j, k, 2) - AT(Ey, i, j, k, 2)) * cb[0];
+                const REAL cz = (AT(Ey, ip, j, k, 1) - AT(Ey, i, j, k, 1)) * cb[0] - (AT(Ey, i, jp, k, 0) - AT(Ey, i, j, k, 0)) * cb[1];
+                By[4 * c] = By[4 * c] - cx;
+                By[4 * c + 1] = By[4 * c + 1] - cy;
+                By[4 * c + 2] = By[4 * c + 2] - cz;
+            }
+}
+
+/* E += ce * curl B - je * J  (ce = { c^2 dt/dx, c^2 dt/dy, c^2 dt/dz }, je = dt/eps0) */
+void FN(em_update_e)(REAL* Ey, const REAL* By, const REAL* J4, int nx, int ny, int nz, const REAL* ce, REAL je)
+{
+    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const size_t im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
+                const size_t c = i + sy * j + sz * k;
+                /* (curl B)_x at (i+1/2, j, k) = dBz/dy - dBy/dz */
+                const REAL cx = (AT(By, i, j, k, 2) - AT(By, i, jm, k, 2)) * ce[1] - (AT(By, i, j, k, 1) - AT(By, i, j, km, 1)) * ce[2];
+                const REAL cy = (AT(By, i, j, k, 0) - AT(By, i, j, km, 0)) * ce[2] - (AT(By, i, j, k, 2) - AT(By, im, j, k, 2)) * ce[0];
+                const REAL cz = (AT(By, i, j, k, 1) - AT(By, im, j, k, 1)) * ce[0] - (AT(By, i, j, k, 0) - AT(By, i, jm, k, 0)) * ce[1];
+                Ey[4 * c] = (Ey[4 * c] + cx) - je * J4[4 * c];
+                Ey[4 * c + 1] = (Ey[4 * c + 1] + cy) - je * J4[4 * c + 1];
+                Ey[4 * c + 2] = (Ey[4 * c + 2] + cz) - je * J4[4 * c + 2];
+            }
+}
+#undef AT
+
+/* E on the Yee edges from phi: Ex(i+1/2) = (phi[i] - phi[i+1]) / dx: with the 3-point Laplacian of es3d_poisson this
+ * satisfies the lattice's Gauss law exactly (div E = rho / eps0), the state a charge-conserving run keeps */
+void FN(em_edge_gradient)(const REAL* phi, int nx, int ny, int nz, double lx, double ly, double lz, REAL* Ey)
+{
+    const REAL hx = (REAL)(1.0 / (lx / nx)), hy = (REAL)(1.0 / (ly / ny)), hz = (REAL)(1.0 / (lz / nz));
+    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const size_t ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1, kp = (k + 1 == nz) ? 0 : k + 1;
+                const size_t c = i + sy * j + sz * k;
+                Ey[4 * c] = (phi[c] - phi[ip + sy * j + sz * k]) * hx;
+                Ey[4 * c + 1] = (phi[c] - phi[i + sy * jp + sz * k]) * hy;
+                Ey[4 * c + 2] = (phi[c] - phi[i + sy * j + sz * kp]) * hz;
+                Ey[4 * c + 3] = (REAL)0;
+            }
+}
+
 #undef FN
 #undef CAT
 #undef CAT_
