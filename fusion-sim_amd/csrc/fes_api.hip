@@ -54,6 +54,9 @@ struct State {
     uint32_t ntiles = 0; // + 1 always-empty bin (the scan kernel's clipped bin)
     long long* rho_fixed = nullptr;
     void *rho = nullptr, *hat = nullptr, *phi = nullptr, *E4 = nullptr;
+    // full EM (solver = YEE): the lattice's E and B, the node-centred B (E4 holds the node-centred E), the integer current grid
+    void *Ey = nullptr, *By = nullptr, *B4n = nullptr;
+    long long* Jfix = nullptr;
     double* k2[3] = {};
     rocfft_plan fwd = nullptr, inv = nullptr;
     rocfft_execution_info info_f = nullptr, info_i = nullptr;
@@ -279,7 +282,7 @@ int launch_solve(fpic_handle* h, bool convert = true)
         rho_real_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(st->rho_fixed, st->nodes, scale, static_cast<T*>(st->rho));
         HIP_TRY(h, hipGetLastError());
     }
-    if (st->solver == FPIC_SOLVER_POISSON_FFT) {
+    if (st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE) {
         const fdyn::RocFFT& ff = fdyn::rocfft();
         const int nxh = st->nx / 2 + 1;
         if (int rc = fft_status(h, ff.execution_info_set_stream(st->info_f, h->stream), "rocfft_execution_info_set_stream")) return rc;
@@ -294,9 +297,14 @@ int launch_solve(fpic_handle* h, bool convert = true)
         void* in_i[1] = { st->hat };
         void* out_i[1] = { st->phi };
         if (int rc = fft_status(h, ff.execute(st->inv, in_i, out_i, st->info_i), "rocfft_execute (inverse)")) return rc;
-        gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(
-            static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
-            static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4));
+        if (st->solver == FPIC_SOLVER_YEE) // the field on the lattice's edges: Gauss's law holds exactly there
+            em_edge_gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
+                                                                                   static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
+                                                                                   static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey));
+        else
+            gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(
+                static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
+                static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4));
         HIP_TRY(h, hipGetLastError());
     }
     timing_end(h);
@@ -352,6 +360,78 @@ int substep(fpic_handle* h)
     h->step_launches++;
     h->particle_updates += total_particles(st);
     return launch_solve<T>(h);
+}
+
+// ---- full EM (solver = YEE): em_nodes, em_push + em_current, B half, E, B half (oracle: em_substep)
+template <typename T>
+int em_nodes(fpic_handle* h)
+{
+    State* st = h->es;
+    em_nodes_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->Ey), static_cast<const T*>(st->By), st->nx, st->ny, st->nz,
+                                                                   static_cast<T*>(st->E4), static_cast<T*>(st->B4n));
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int em_precalc(fpic_handle* h)
+{
+    State* st = h->es;
+    if (int rc = deposit_cycle<T, true>(h)) return rc;
+    h->deposit_launches++;
+    if (int rc = launch_solve<T>(h)) return rc; // rho -> phi -> E on the edges
+    fill4_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), st->nodes, static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
+                                                                static_cast<T>(st->B0[2]));
+    HIP_TRY(h, hipGetLastError());
+    return em_nodes<T>(h);
+}
+
+template <typename T>
+int em_substep(fpic_handle* h)
+{
+    State* st = h->es;
+    bool unbinned = false;
+    for (const Species& s : st->sp) unbinned |= !s.binned;
+    if (unbinned || st->substeps_since_bin >= 8) // tile order keeps the L2 gathers and the current's atomics local
+        if (int rc = bin_all<T>(h, true)) return rc;
+    if (int rc = em_nodes<T>(h)) return rc;
+    const double dt = h->spec.dt;
+    const double d[3] = { st->lx / st->nx, st->ly / st->ny, st->lz / st->nz };
+    timing_begin(h, KC_PUSH);
+    HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, st->nodes * 3 * sizeof(long long), h->stream));
+    for (Species& s : st->sp) {
+        if (!s.n) continue;
+        EmPushArgs<T> a{};
+        a.slab = static_cast<T*>(s.slab[s.cur]); a.stride = s.n_pad; a.n = s.n;
+        a.E4n = static_cast<const T*>(st->E4); a.B4n = static_cast<const T*>(st->B4n);
+        a.Jfix = reinterpret_cast<unsigned long long*>(st->Jfix);
+        a.nx = st->nx; a.ny = st->ny; a.nz = st->nz;
+        const double hh = s.charge * dt / (2 * s.mass), step = dt * kSpeedOfLight;
+        a.h = static_cast<T>(hh);
+        a.hc = static_cast<T>(hh) / static_cast<T>(kSpeedOfLight); // in T, as the oracle forms it
+        a.dx = static_cast<T>(step / st->lx); a.dy = static_cast<T>(step / st->ly); a.dz = static_cast<T>(step / st->lz);
+        a.Z = s.Z;
+        em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
+        HIP_TRY(h, hipGetLastError());
+    }
+    timing_end(h);
+    timing_begin(h, KC_SOLVE);
+    const T cb[3] = { static_cast<T>(dt / (2 * d[0])), static_cast<T>(dt / (2 * d[1])), static_cast<T>(dt / (2 * d[2])) };
+    const double c2 = kSpeedOfLight * kSpeedOfLight;
+    const T ce[3] = { static_cast<T>(c2 * dt / d[0]), static_cast<T>(c2 * dt / d[1]), static_cast<T>(c2 * dt / d[2]) };
+    const double base = h->spec.particle_charge * st->W / (96.0 * 4398046511104.0 * dt);
+    em_update_b_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), static_cast<const T*>(st->Ey), st->nx, st->ny, st->nz, cb[0], cb[1], cb[2]);
+    em_update_e_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(st->By), st->Jfix, st->nx, st->ny, st->nz, ce[0],
+                                                                      ce[1], ce[2], static_cast<T>(dt / kEps0), base / (d[1] * d[2]), base / (d[0] * d[2]),
+                                                                      base / (d[0] * d[1]));
+    em_update_b_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), static_cast<const T*>(st->Ey), st->nx, st->ny, st->nz, cb[0], cb[1], cb[2]);
+    HIP_TRY(h, hipGetLastError());
+    timing_end(h);
+    st->substeps_since_bin++;
+    h->step_launches++;
+    h->solve_launches++;
+    h->particle_updates += total_particles(st);
+    return FPIC_OK;
 }
 
 // host holds the caller's particles [first, first + count)
@@ -442,7 +522,7 @@ int download_cells(fpic_handle* h, const Species& s, int32_t* cells)
 }
 
 template <typename T, typename In>
-int upload_field(fpic_handle* h, const In* host)
+int upload_field(fpic_handle* h, const In* host, void* target)
 {
     State* st = h->es;
     In* stage = nullptr;
@@ -450,7 +530,7 @@ int upload_field(fpic_handle* h, const In* host)
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), bytes));
     hipError_t e = hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
-        pack_field3_kernel<T, In><<<blocks_for(st->nodes), 256, 0, h->stream>>>(stage, st->nx, st->ny, st->nz, static_cast<T*>(st->E4));
+        pack_field3_kernel<T, In><<<blocks_for(st->nodes), 256, 0, h->stream>>>(stage, st->nx, st->ny, st->nz, static_cast<T*>(target));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -521,7 +601,13 @@ int create_state(fpic_handle* h)
         (e = set_lds(bin3_scatter_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess)
         return fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
 
-    if (st->solver == FPIC_SOLVER_POISSON_FFT) {
+    if (st->solver == FPIC_SOLVER_YEE) {
+        if ((rc = dev_alloc(h, &st->Ey, st->nodes * 4 * sizeof(T), acc)) || (rc = dev_alloc(h, &st->By, st->nodes * 4 * sizeof(T), acc)) ||
+            (rc = dev_alloc(h, &st->B4n, st->nodes * 4 * sizeof(T), acc)) ||
+            (rc = dev_alloc(h, reinterpret_cast<void**>(&st->Jfix), st->nodes * 3 * sizeof(long long), acc)))
+            return rc;
+    }
+    if (st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE) { // (YEE: the initial field is the Poisson field)
         const fdyn::RocFFT& ff = fdyn::rocfft();
         if (!ff.ok) return fail(h, FPIC_ERR_STATE, ".solver <- rocFFT is not available (%s); there is no other Poisson solver and no CPU fallback", ff.why.c_str());
         const size_t lengths[3] = { static_cast<size_t>(st->nx), static_cast<size_t>(st->ny), static_cast<size_t>(st->nz) };
@@ -571,7 +657,8 @@ int create(fpic_handle* h)
     const fpic_spec& sp = h->spec;
     if (sp.ny < 1) return fail(h, FPIC_ERR_INVALID_ARG, ".ny <- must be a positive integer");
     if (!(sp.length_y > 0) || !std::isfinite(sp.length_y)) return fail(h, FPIC_ERR_INVALID_ARG, ".length_y <- must be positive");
-    if (sp.solver != FPIC_SOLVER_NONE && sp.solver != FPIC_SOLVER_POISSON_FFT) return fail(h, FPIC_ERR_INVALID_ARG, ".solver <- must be 0 (none) or 1 (poisson_fft)");
+    if (sp.solver != FPIC_SOLVER_NONE && sp.solver != FPIC_SOLVER_POISSON_FFT && sp.solver != FPIC_SOLVER_YEE)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".solver <- must be 0 (none), 1 (poisson_fft) or 2 (yee)");
     if (sp.macro_weight < 0 || !std::isfinite(sp.macro_weight)) return fail(h, FPIC_ERR_INVALID_ARG, ".macro_weight <- must be positive");
     if (sp.particle_charge == 0) return fail(h, FPIC_ERR_INVALID_ARG, ".particle_charge <- must not be zero: it is the unit of the charge grid");
     if (sp.rng_mode != 0) return fail(h, FPIC_ERR_INVALID_ARG, ".rng <- the periodic box has no re-injection and no generator");
@@ -612,6 +699,8 @@ void release(fpic_handle* h)
         if (d->counts_host) (void)hipHostFree(d->counts_host);
         delete d;
     }
+    for (void* p : { st->Ey, st->By, st->B4n, static_cast<void*>(st->Jfix) })
+        if (p) (void)hipFree(p);
     for (void* p : { static_cast<void*>(st->rho_fixed), st->rho, st->hat, st->phi, st->E4, static_cast<void*>(st->k2[0]), static_cast<void*>(st->k2[1]),
                      static_cast<void*>(st->k2[2]), st->work_f, st->work_i, static_cast<void*>(st->spilled) })
         if (p) (void)hipFree(p);
@@ -714,21 +803,30 @@ int set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int 
 {
     State* st = h->es;
     if (!data) return fail(h, FPIC_ERR_INVALID_ARG, ".data <- Non-optional property is undefined!");
-    if (which != FPIC_F3_E) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- only E (0) can be uploaded");
+    const bool lattice = which == FPIC_F3_EDGE_E || which == FPIC_F3_FACE_B;
+    if (which != FPIC_F3_E && !lattice) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- only E (0), EDGE_E (5) and FACE_B (6) can be uploaded");
+    if (lattice && st->solver != FPIC_SOLVER_YEE) return fail(h, FPIC_ERR_STATE, ".which <- the lattice fields exist in the full-EM mode only (spec.solver = 2)");
     if (nx != st->nx || ny != st->ny || nz != st->nz) return fail(h, FPIC_ERR_INVALID_ARG, ".grid <- expected %d x %d x %d, got %d x %d x %d", st->nx, st->ny, st->nz, nx, ny, nz);
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
     st->fields_ready = true;
+    void* target = which == FPIC_F3_E ? st->E4 : (which == FPIC_F3_EDGE_E ? st->Ey : st->By);
+    int rc;
     if (h->prec == FPIC_F32)
-        return dtype == FPIC_F32 ? upload_field<float, float>(h, static_cast<const float*>(data)) : upload_field<float, double>(h, static_cast<const double*>(data));
-    return dtype == FPIC_F32 ? upload_field<double, float>(h, static_cast<const float*>(data)) : upload_field<double, double>(h, static_cast<const double*>(data));
+        rc = dtype == FPIC_F32 ? upload_field<float, float>(h, static_cast<const float*>(data), target) : upload_field<float, double>(h, static_cast<const double*>(data), target);
+    else
+        rc = dtype == FPIC_F32 ? upload_field<double, float>(h, static_cast<const float*>(data), target) : upload_field<double, double>(h, static_cast<const double*>(data), target);
+    if (rc == FPIC_OK && lattice) rc = h->prec == FPIC_F32 ? em_nodes<float>(h) : em_nodes<double>(h);
+    return rc;
 }
 
 int read_field3(fpic_handle* h, int which, void* out, int dtype)
 {
     State* st = h->es;
     if (!out) return fail(h, FPIC_ERR_INVALID_ARG, ".out <- Non-optional property is undefined!");
-    if (which == FPIC_F3_RHO_FIXED) {
-        HIP_TRY(h, hipMemcpyAsync(out, st->rho_fixed, st->nodes * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    if (which == FPIC_F3_RHO_FIXED || which == FPIC_F3_J_FIXED) {
+        if (which == FPIC_F3_J_FIXED && !st->Jfix) return fail(h, FPIC_ERR_STATE, ".which <- the current grid exists in the full-EM mode only (spec.solver = 2)");
+        const void* src = which == FPIC_F3_RHO_FIXED ? static_cast<const void*>(st->rho_fixed) : static_cast<const void*>(st->Jfix);
+        HIP_TRY(h, hipMemcpyAsync(out, src, st->nodes * (which == FPIC_F3_RHO_FIXED ? 1 : 3) * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return FPIC_OK;
     }
@@ -739,8 +837,12 @@ int read_field3(fpic_handle* h, int which, void* out, int dtype)
     case FPIC_F3_E: dev = st->E4; count *= 4; break;
     case FPIC_F3_RHO: dev = st->rho; break;
     case FPIC_F3_PHI: dev = st->phi; break;
+    case FPIC_F3_B_NODES: dev = st->B4n; count *= 4; break;
+    case FPIC_F3_EDGE_E: dev = st->Ey; count *= 4; break;
+    case FPIC_F3_FACE_B: dev = st->By; count *= 4; break;
     default: return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown grid %d", which);
     }
+    if (!dev) return fail(h, FPIC_ERR_STATE, ".which <- this grid exists in the full-EM mode only (spec.solver = 2)");
     if (h->prec == FPIC_F32)
         return dtype == FPIC_F32 ? download_grid<float, float>(h, dev, count, static_cast<float*>(out)) : download_grid<float, double>(h, dev, count, static_cast<double*>(out));
     return dtype == FPIC_F32 ? download_grid<double, float>(h, dev, count, static_cast<float*>(out)) : download_grid<double, double>(h, dev, count, static_cast<double*>(out));
@@ -998,11 +1100,26 @@ int precalc(fpic_handle* h)
         if (int e = dom_ranks_of(h, rk)) return e;
         return h->prec == FPIC_F32 ? dom_precalc<float>(rk) : dom_precalc<double>(rk);
     }
+    if (h->es->solver == FPIC_SOLVER_YEE) {
+        const int rc = h->prec == FPIC_F32 ? em_precalc<float>(h) : em_precalc<double>(h);
+        if (rc == FPIC_OK) h->es->fields_ready = true;
+        return rc;
+    }
     int rc = h->prec == FPIC_F32 ? deposit_cycle<float, true>(h) : deposit_cycle<double, true>(h);
     if (rc) return rc;
     h->deposit_launches++;
     rc = h->prec == FPIC_F32 ? launch_solve<float>(h) : launch_solve<double>(h);
     if (rc == FPIC_OK) h->es->fields_ready = true;
+    return rc;
+}
+
+// density() of the box: the charge grid of the CURRENT positions (the EM cycle deposits currents, not charge)
+int density(fpic_handle* h)
+{
+    if (h->es->solver != FPIC_SOLVER_YEE) return FPIC_OK; // the electrostatic cycle deposits the charge every sub-step
+    if (h->es->dom) return fail(h, FPIC_ERR_STATE, "the full-EM mode is not decomposed yet");
+    const int rc = h->prec == FPIC_F32 ? deposit_cycle<float, true>(h) : deposit_cycle<double, true>(h);
+    if (rc == FPIC_OK) h->deposit_launches++;
     return rc;
 }
 
@@ -1015,6 +1132,11 @@ int step(fpic_handle* h, int ncalls)
         if (int e = dom_ranks_of(h, rk)) return e;
         for (int k = 0; k < 2 * ncalls; ++k)
             if (int rc = h->prec == FPIC_F32 ? dom_substep<float>(rk) : dom_substep<double>(rk)) return rc;
+        return FPIC_OK;
+    }
+    if (h->es->solver == FPIC_SOLVER_YEE) {
+        for (int k = 0; k < 2 * ncalls; ++k)
+            if (int rc = h->prec == FPIC_F32 ? em_substep<float>(h) : em_substep<double>(h)) return rc;
         return FPIC_OK;
     }
     for (int k = 0; k < 2 * ncalls; ++k)
@@ -1038,6 +1160,7 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
 {
     State* st = h->es;
     if (st->dom) return fail(h, FPIC_ERR_STATE, "the handle is already decomposed");
+    if (st->solver == FPIC_SOLVER_YEE) return fail(h, FPIC_ERR_STATE, "the full-EM mode is not decomposed yet");
     if (world < 1 || rank < 0 || rank >= world) return fail(h, FPIC_ERR_INVALID_ARG, ".rank <- %d is outside a world of %d", rank, world);
     if (st->nz % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d planes along z do not divide into %d slabs", st->nz, world);
     const int nzl = st->nz / world;

@@ -17,6 +17,7 @@ int add_b(fpic_handle* h, double bx, double by, double bz);
 int set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int nz, int dtype);
 int read_field3(fpic_handle* h, int which, void* out, int dtype);
 int precalc(fpic_handle* h);
+int density(fpic_handle* h);
 int step(fpic_handle* h, int ncalls);
 int sort(fpic_handle* h);
 int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);

@@ -730,6 +730,249 @@ __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__
 }
 
 
+// ------------------------------------------------------------------ full EM (Yee FDTD), BASELINE configs[4]
+//
+// Parity unpinned; defined by oracle/es3d_oracle_impl.h ("full EM") and oracle/es3d_oracle.c (es3d_current) and
+// followed operation for operation.  Lattice fields 4 T per node: Ey = (Ex(i+1/2,j,k), Ey(i,j+1/2,k), Ez(i,j,k+1/2), 0),
+// By = (Bx(i,j+1/2,k+1/2), By(i+1/2,j,k+1/2), Bz(i+1/2,j+1/2,k), 0); E4n / B4n their node-centred copies; Jfix 3
+// int64 per node (x-, y-, z-edge), 96 * 2^42 per particle crossing a whole dual face: with the charge grid the lattice
+// continuity equation holds exactly in integers.
+
+#define FES_AT(A, ii, jj, kk, comp) A[4 * (static_cast<size_t>(ii) + sy * static_cast<size_t>(jj) + sz * static_cast<size_t>(kk)) + (comp)]
+
+template <typename T>
+__global__ __launch_bounds__(256) void em_nodes_kernel(const T* __restrict__ Ey, const T* __restrict__ By, int nx, int ny, int nz, T* __restrict__ E4n,
+                                                       T* __restrict__ B4n)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
+    if (c >= sz * nz) return;
+    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
+    const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
+    E4n[4 * c] = static_cast<T>(0.5) * (FES_AT(Ey, im, j, k, 0) + FES_AT(Ey, i, j, k, 0));
+    E4n[4 * c + 1] = static_cast<T>(0.5) * (FES_AT(Ey, i, jm, k, 1) + FES_AT(Ey, i, j, k, 1));
+    E4n[4 * c + 2] = static_cast<T>(0.5) * (FES_AT(Ey, i, j, km, 2) + FES_AT(Ey, i, j, k, 2));
+    E4n[4 * c + 3] = static_cast<T>(0);
+    B4n[4 * c] = static_cast<T>(0.25) * (((FES_AT(By, i, jm, km, 0) + FES_AT(By, i, j, km, 0)) + FES_AT(By, i, jm, k, 0)) + FES_AT(By, i, j, k, 0));
+    B4n[4 * c + 1] = static_cast<T>(0.25) * (((FES_AT(By, im, j, km, 1) + FES_AT(By, i, j, km, 1)) + FES_AT(By, im, j, k, 1)) + FES_AT(By, i, j, k, 1));
+    B4n[4 * c + 2] = static_cast<T>(0.25) * (((FES_AT(By, im, jm, k, 2) + FES_AT(By, i, jm, k, 2)) + FES_AT(By, im, j, k, 2)) + FES_AT(By, i, j, k, 2));
+    B4n[4 * c + 3] = static_cast<T>(0);
+}
+
+// B -= cb * curl E (em_update_b)
+template <typename T>
+__global__ __launch_bounds__(256) void em_update_b_kernel(T* __restrict__ By, const T* __restrict__ Ey, int nx, int ny, int nz, T cbx, T cby, T cbz)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
+    if (c >= sz * nz) return;
+    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
+    const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1, kp = (k + 1 == nz) ? 0 : k + 1;
+    const T cx = (FES_AT(Ey, i, jp, k, 2) - FES_AT(Ey, i, j, k, 2)) * cby - (FES_AT(Ey, i, j, kp, 1) - FES_AT(Ey, i, j, k, 1)) * cbz;
+    const T cy = (FES_AT(Ey, i, j, kp, 0) - FES_AT(Ey, i, j, k, 0)) * cbz - (FES_AT(Ey, ip, j, k, 2) - FES_AT(Ey, i, j, k, 2)) * cbx;
+    const T cz = (FES_AT(Ey, ip, j, k, 1) - FES_AT(Ey, i, j, k, 1)) * cbx - (FES_AT(Ey, i, jp, k, 0) - FES_AT(Ey, i, j, k, 0)) * cby;
+    By[4 * c] = By[4 * c] - cx;
+    By[4 * c + 1] = By[4 * c + 1] - cy;
+    By[4 * c + 2] = By[4 * c + 2] - cz;
+}
+
+// E += ce * curl B - je * J, with J = T((double)Jfix * scale) formed on the fly (em_j_real + em_update_e)
+template <typename T>
+__global__ __launch_bounds__(256) void em_update_e_kernel(T* __restrict__ Ey, const T* __restrict__ By, const long long* __restrict__ Jfix, int nx, int ny,
+                                                          int nz, T cex, T cey, T cez, T je, double jsx, double jsy, double jsz)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
+    if (c >= sz * nz) return;
+    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
+    const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
+    const T cx = (FES_AT(By, i, j, k, 2) - FES_AT(By, i, jm, k, 2)) * cey - (FES_AT(By, i, j, k, 1) - FES_AT(By, i, j, km, 1)) * cez;
+    const T cy = (FES_AT(By, i, j, k, 0) - FES_AT(By, i, j, km, 0)) * cez - (FES_AT(By, i, j, k, 2) - FES_AT(By, im, j, k, 2)) * cex;
+    const T cz = (FES_AT(By, i, j, k, 1) - FES_AT(By, im, j, k, 1)) * cex - (FES_AT(By, i, j, k, 0) - FES_AT(By, i, jm, k, 0)) * cey;
+    const T jx = static_cast<T>(static_cast<double>(Jfix[3 * c]) * jsx);
+    const T jy = static_cast<T>(static_cast<double>(Jfix[3 * c + 1]) * jsy);
+    const T jz = static_cast<T>(static_cast<double>(Jfix[3 * c + 2]) * jsz);
+    Ey[4 * c] = (Ey[4 * c] + cx) - je * jx;
+    Ey[4 * c + 1] = (Ey[4 * c + 1] + cy) - je * jy;
+    Ey[4 * c + 2] = (Ey[4 * c + 2] + cz) - je * jz;
+}
+
+// E on the Yee edges from phi (em_edge_gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void em_edge_gradient_kernel(const T* __restrict__ phi, int nx, int ny, int nz, T hx, T hy, T hz, T* __restrict__ Ey)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
+    if (c >= sz * nz) return;
+    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
+    const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1, kp = (k + 1 == nz) ? 0 : k + 1;
+    Ey[4 * c] = (phi[c] - phi[ip + sy * j + sz * k]) * hx;
+    Ey[4 * c + 1] = (phi[c] - phi[i + sy * jp + sz * k]) * hy;
+    Ey[4 * c + 2] = (phi[c] - phi[i + sy * j + sz * kp]) * hz;
+    Ey[4 * c + 3] = static_cast<T>(0);
+}
+#undef FES_AT
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill4_kernel(T* __restrict__ a, size_t nodes, T x, T y, T z)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= nodes) return;
+    a[4 * c] = x; a[4 * c + 1] = y; a[4 * c + 2] = z; a[4 * c + 3] = static_cast<T>(0);
+}
+
+// value[i][j][k][c] -> 4 T per node (the lattice's own arrays)
+template <typename T, typename In>
+__global__ __launch_bounds__(256) void pack_lattice_kernel(const In* __restrict__ in, int nx, int ny, int nz, T* __restrict__ out4)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nx) * ny * nz) return;
+    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / (static_cast<size_t>(nx) * ny));
+    const In* v = in + 3 * ((static_cast<size_t>(i) * ny + j) * nz + k);
+    out4[4 * c] = static_cast<T>(v[0]); out4[4 * c + 1] = static_cast<T>(v[1]); out4[4 * c + 2] = static_cast<T>(v[2]); out4[4 * c + 3] = static_cast<T>(0);
+}
+
+// doubled fixed-point lattice coordinate (em_coord)
+template <typename T>
+__device__ __forceinline__ long long em_coord(T u, int n)
+{
+    int i, w1;
+    axis(u, n, i, w1);
+    return 2 * (static_cast<long long>(i) * 16384 + w1);
+}
+
+__device__ __forceinline__ long long floor_div_ll(long long a, long long s) { return a >= 0 ? a / s : -((-a + s - 1) / s); }
+
+// one straight segment inside one cell (current_segment)
+__device__ __forceinline__ void current_segment(const long long (&p1)[3], const long long (&p2)[3], const long long (&cell)[3], int nx, int ny, int nz, int Z,
+                                                unsigned long long* Jfix)
+{
+    constexpr long long S = 32768;
+    long long d[3], A0[3], A1[3], c0[3], c1[3];
+    const int n[3] = { nx, ny, nz };
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const long long l1 = p1[m] - cell[m] * S, l2 = p2[m] - cell[m] * S;
+        d[m] = l2 - l1;
+        A1[m] = l1 + l2; A0[m] = 2 * S - A1[m];
+        long long w = cell[m] % n[m];
+        if (w < 0) w += n[m];
+        c0[m] = w;
+        c1[m] = (w + 1 == n[m]) ? 0 : w + 1;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if (d[m] == 0) continue;
+        const int u = (m + 1) % 3, v = (m + 2) % 3;
+        const long long cross = d[u] * d[v];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const long long flux = d[m] * (3 * (b ? A1[u] : A0[u]) * (c ? A1[v] : A0[v]) + (b == c ? cross : -cross)) * Z;
+                long long idx[3];
+                idx[m] = c0[m]; idx[u] = b ? c1[u] : c0[u]; idx[v] = c ? c1[v] : c0[v];
+                if (flux) atomicAdd(Jfix + 3 * (static_cast<size_t>(idx[0]) + static_cast<size_t>(nx) * (static_cast<size_t>(idx[1]) + static_cast<size_t>(ny) * idx[2])) + m,
+                                    static_cast<unsigned long long>(flux));
+            }
+    }
+}
+
+// the move a -> b_in (nearest periodic image) cut at the zigzag relay point (es3d_current)
+__device__ __forceinline__ void current_deposit(const long long (&a)[3], const long long (&b_in)[3], int nx, int ny, int nz, int Z, unsigned long long* Jfix)
+{
+    constexpr long long S = 32768;
+    const int n[3] = { nx, ny, nz };
+    long long b[3], ca[3], cb[3], r[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const long long box = static_cast<long long>(n[m]) * S;
+        long long dd = b_in[m] - a[m];
+        if (2 * dd > box) dd -= box;
+        else if (2 * dd < -box) dd += box;
+        b[m] = a[m] + dd;
+        ca[m] = floor_div_ll(a[m], S);
+        cb[m] = floor_div_ll(b[m], S);
+        r[m] = (ca[m] == cb[m]) ? (a[m] + b[m]) / 2 : (ca[m] > cb[m] ? ca[m] : cb[m]) * S;
+    }
+    current_segment(a, r, ca, nx, ny, nz, Z, Jfix);
+    current_segment(r, b, cb, nx, ny, nz, Z, Jfix);
+}
+
+template <typename T>
+struct EmPushArgs {
+    T* slab;
+    size_t stride;
+    unsigned long long n;
+    const T* E4n;
+    const T* B4n;
+    unsigned long long* Jfix;
+    int nx, ny, nz;
+    T h, hc, dx, dy, dz;
+    int Z;
+};
+
+// em_push + em_current for every particle: gathers through L2 (the particles are kept in tile order), the current with
+// 8-byte global atomics.  (First form of the mode: correct and complete; an LDS-staged form as in push3_tiles_kernel
+// needs 8x8x8-cell tiles for the six field components and the three accumulators to fit.)
+template <typename T>
+__global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    const T q14 = static_cast<T>(1.0 / 16384.0);
+    T x = a.slab[p], y = a.slab[a.stride + p], z = a.slab[2 * a.stride + p];
+    T vx = a.slab[3 * a.stride + p], vy = a.slab[4 * a.stride + p], vz = a.slab[5 * a.stride + p];
+    if (x < static_cast<T>(0)) return; // a migrated slot
+    int i, j, k, w1;
+    T fx[2], fy[2], fz[2];
+    axis(x, a.nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14;
+    const long long hx0 = 2 * (static_cast<long long>(i) * 16384 + w1);
+    axis(y, a.ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14;
+    const long long hy0 = 2 * (static_cast<long long>(j) * 16384 + w1);
+    axis(z, a.nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14;
+    const long long hz0 = 2 * (static_cast<long long>(k) * 16384 + w1);
+    T E[3] = { 0, 0, 0 }, B[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const int ii = (i + aa == a.nx) ? 0 : i + aa, jj = (j + b == a.ny) ? 0 : j + b, kk = (k + c == a.nz) ? 0 : k + c;
+                const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(a.nx) * (static_cast<size_t>(jj) + static_cast<size_t>(a.ny) * kk);
+                T e[4], bb[4];
+                fpic::load4(a.E4n + 4 * node, e);
+                fpic::load4(a.B4n + 4 * node, bb);
+                const T w = (fx[aa] * fy[b]) * fz[c];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    E[m] = E[m] + w * e[m];
+                    B[m] = B[m] + w * bb[m];
+                }
+            }
+    const T ax = a.hc * E[0], ay = a.hc * E[1], az = a.hc * E[2];
+    const T tx = a.h * B[0], ty = a.h * B[1], tz = a.h * B[2];
+    const T f = static_cast<T>(2) / (static_cast<T>(1) + ((tx * tx + ty * ty) + tz * tz));
+    const T sx = f * tx, sy = f * ty, sz = f * tz;
+    const T ux = vx + ax, uy = vy + ay, uz = vz + az;
+    const T px = ux + (uy * tz - uz * ty);
+    const T py = uy + (uz * tx - ux * tz);
+    const T pz = uz + (ux * ty - uy * tx);
+    const T qx = ux + (py * sz - pz * sy);
+    const T qy = uy + (pz * sx - px * sz);
+    const T qz = uz + (px * sy - py * sx);
+    vx = qx + ax; vy = qy + ay; vz = qz + az;
+    x = wrap01(x + a.dx * vx);
+    y = wrap01(y + a.dy * vy);
+    z = wrap01(z + a.dz * vz);
+    a.slab[p] = x; a.slab[a.stride + p] = y; a.slab[2 * a.stride + p] = z;
+    a.slab[3 * a.stride + p] = vx; a.slab[4 * a.stride + p] = vy; a.slab[5 * a.stride + p] = vz;
+    const long long from[3] = { hx0, hy0, hz0 };
+    const long long to[3] = { em_coord(x, a.nx), em_coord(y, a.ny), em_coord(z, a.nz) };
+    current_deposit(from, to, a.nx, a.ny, a.nz, a.Z, a.Jfix);
+}
+
 // ------------------------------------------------------------------ spatial decomposition (z-slabs), SURVEY.md 8(e) row 2
 
 // One migrating particle on the wire: the six coordinates and the caller's (global) index.

@@ -1028,7 +1028,7 @@ int fpic_sort(fpic_handle* h)
 int fpic_deposit(fpic_handle* h)
 {
     CHECK_HANDLE(h);
-    if (h->es) return FPIC_OK; // the charge density of the current positions is always at hand
+    if (h->es) return fes::density(h); // electrostatic: always at hand; full EM: deposited now
     bool rebin = !h->binned;
     if (!rebin) {
         if (h->spec.sort_interval > 0) {

@@ -27,8 +27,8 @@ GRID_E, GRID_B, GRID_SINK_MASK, GRID_SOURCE_PDF = 0, 1, 2, 3
  READ_INV_CDF) = range(11)
 BUF_CELL_SUMS, BUF_RHO_FIXED = 0, 1
 GEOM_CYL_RZ, GEOM_CART3D = 0, 1
-SOLVER_NONE, SOLVER_POISSON_FFT = 0, 1
-F3_E, F3_RHO, F3_PHI, F3_RHO_FIXED = 0, 1, 2, 3
+SOLVER_NONE, SOLVER_POISSON_FFT, SOLVER_YEE = 0, 1, 2
+F3_E, F3_RHO, F3_PHI, F3_RHO_FIXED, F3_B_NODES, F3_EDGE_E, F3_FACE_B, F3_J_FIXED = range(8)
 
 ABI_FUNCTIONS = [
     "fpic_last_error", "fpic_abi_version", "fpic_build_arch", "fpic_create", "fpic_destroy", "fpic_set_particles",
@@ -417,7 +417,7 @@ class ElectrostaticBoxPusher:
         s.device = int(device)
         s.sort_interval = int(sort_interval)
         s.geometry = GEOM_CART3D
-        s.solver = {"none": SOLVER_NONE, "poisson_fft": SOLVER_POISSON_FFT}[spec.get("solver", "poisson_fft")]
+        s.solver = {"none": SOLVER_NONE, "poisson_fft": SOLVER_POISSON_FFT, "yee": SOLVER_YEE}[spec.get("solver", "poisson_fft")]
         s.ny = int(spec["ny"])
         s.length_y = float(spec["length_y"])
         s.macro_weight = float(spec.get("macro_weight", 1.0))
@@ -472,11 +472,13 @@ class ElectrostaticBoxPusher:
                 p = a.ctypes.data if key == "position" else None
                 v = a.ctypes.data if key == "velocity" else None
                 self._check(self._lib.fpic_set_particles_of(self._h, species, p, v, n, _code(a)))
-        if value.get("E") is not None:
-            a = _as_float_array(value["E"])
-            if a.shape != (self.nx, self.ny, self.nz, 3):
-                raise FusionPicError(-1, ".E <- expected [%d][%d][%d][3]" % (self.nx, self.ny, self.nz))
-            self._check(self._lib.fpic_set_field3(self._h, F3_E, a.ctypes.data, self.nx, self.ny, self.nz, _code(a)))
+        # E: node-centred (static field / injected field); edge_E, face_B: the Yee lattice's own arrays (full EM)
+        for key, which in (("E", F3_E), ("edge_E", F3_EDGE_E), ("face_B", F3_FACE_B)):
+            if value.get(key) is not None:
+                a = _as_float_array(value[key])
+                if a.shape != (self.nx, self.ny, self.nz, 3):
+                    raise FusionPicError(-1, ".%s <- expected [%d][%d][%d][3]" % (key, self.nx, self.ny, self.nz))
+                self._check(self._lib.fpic_set_field3(self._h, which, a.ctypes.data, self.nx, self.ny, self.nz, _code(a)))
 
     def setRange(self, first, position=None, velocity=None, species=0):
         """the caller's particles [first, first + len) of a species (piecewise upload of a large population)"""
@@ -530,14 +532,15 @@ class ElectrostaticBoxPusher:
     def readField(self, which, dtype=None):
         """F3_E -> [nodes][4] (Ex, Ey, Ez, phi); F3_RHO / F3_PHI -> [nodes]; F3_RHO_FIXED -> int64 [nodes];
         node index i + nr*(j + ny*k)."""
-        if which == F3_RHO_FIXED:
-            out = np.empty(self.nodes, dtype=np.int64)
+        if which in (F3_RHO_FIXED, F3_J_FIXED):
+            out = np.empty(self.nodes * (3 if which == F3_J_FIXED else 1), dtype=np.int64)
             self._check(self._lib.fpic_read_field3(self._h, which, out.ctypes.data, 0))
-            return out
+            return out.reshape(self.nodes, 3) if which == F3_J_FIXED else out
         code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
-        out = np.empty(self.nodes * (4 if which == F3_E else 1), dtype=_np_dtype(code))
+        four = which in (F3_E, F3_B_NODES, F3_EDGE_E, F3_FACE_B)
+        out = np.empty(self.nodes * (4 if four else 1), dtype=_np_dtype(code))
         self._check(self._lib.fpic_read_field3(self._h, which, out.ctypes.data, code))
-        return out.reshape(self.nodes, 4) if which == F3_E else out
+        return out.reshape(self.nodes, 4) if four else out
 
 
 class BoxGroup:

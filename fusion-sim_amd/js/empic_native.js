@@ -119,17 +119,17 @@ function flattenParticles(value, n, name) {
     return out;
 }
 
-const FIELD3 = { E: 0, rho: 1, phi: 2, rho_fixed: 3 };
+const FIELD3 = { E: 0, rho: 1, phi: 2, rho_fixed: 3, B: 4, edge_E: 5, face_B: 6 };   // B, edge_E, face_B: full EM (solver 'yee')
 
 // spec.geometry === 'cart3d': the electrostatic box behind the same method names
 function makeBox(spec, lib) {
     validate_object(spec, { ny: 'number', length_y: 'number', solver: [, 'string'], macro_weight: [, 'number'] });
-    if (spec.solver !== undefined && spec.solver !== 'poisson_fft' && spec.solver !== 'none') throw new Error(".solver <- must be 'poisson_fft' or 'none'");
+    if (spec.solver !== undefined && ['poisson_fft', 'none', 'yee'].indexOf(spec.solver) < 0) throw new Error(".solver <- must be 'poisson_fft', 'yee' or 'none'");
     const fp64 = spec.precision === 'fp64';
     const n0 = spec.count ? spec.count : spec.nparticles * spec.nparticles;
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass, spec.particle_charge,
         spec.count || 0, fp64 ? 1 : 0, spec.device || 0, 0, spec.sort_interval || 0, 0, 0, 0, 0,
-        1, spec.solver === 'none' ? 0 : 1, spec.ny, spec.length_y, spec.macro_weight === undefined ? 1 : spec.macro_weight, 0);
+        1, spec.solver === 'none' ? 0 : (spec.solver === 'yee' ? 2 : 1), spec.ny, spec.length_y, spec.macro_weight === undefined ? 1 : spec.macro_weight, 0);
     const nx = spec.nr, ny = spec.ny, nz = spec.nz, nodes = nx * ny * nz;
     const counts = [n0];
     const Real = fp64 ? Float64Array : Float32Array;
@@ -157,7 +157,7 @@ function makeBox(spec, lib) {
     out.density = function () { lib.density(h); };                             // empic.js:1471: the charge density is always current
     out.readField = function (name, buf) {
         if (!(name in FIELD3)) throw new Error('.name <- unknown field ' + name);
-        const len = nodes * (name === 'E' ? 4 : 1);
+        const len = nodes * (name === 'rho' || name === 'phi' || name === 'rho_fixed' ? 1 : 4);
         const fresh = name === 'rho_fixed' ? new BigInt64Array(len) : new Real(len);
         return lib.readField3(h, FIELD3[name], checkLength(buf, len, 'out') || fresh);
     };

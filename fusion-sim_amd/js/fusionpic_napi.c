@@ -500,10 +500,10 @@ static napi_value n_read_field3(napi_env env, napi_callback_info info)
     napi_typedarray_type t; void* data; size_t len; int dtype = FPIC_F32;
     if (!get_typed(env, argv[2], &t, &data, &len)) return NULL;
     if (!data) { napi_throw_type_error(env, NULL, "expected a typed array"); return NULL; }
-    if ((int)which == FPIC_F3_RHO_FIXED) {
+    if ((int)which == FPIC_F3_RHO_FIXED || (int)which == FPIC_F3_J_FIXED) {
         if (t != napi_bigint64_array) { napi_throw_type_error(env, NULL, "expected a BigInt64Array"); return NULL; }
     } else if (!float_dtype(env, t, &dtype)) return NULL;
-    if (!check_len(env, "out", len, g_box->nodes * ((int)which == FPIC_F3_E ? 4 : 1))) return NULL;
+    if (!check_len(env, "out", len, g_box->nodes * (((int)which == FPIC_F3_RHO || (int)which == FPIC_F3_PHI || (int)which == FPIC_F3_RHO_FIXED) ? 1 : ((int)which == FPIC_F3_J_FIXED ? 3 : 4)))) return NULL;
     if (fpic_read_field3(h, (int)which, data, dtype) != FPIC_OK) return throw_fpic(env, h);
     return argv[2];
 }

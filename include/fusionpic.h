@@ -100,7 +100,10 @@ typedef enum fpic_geometry {
 
 typedef enum fpic_solver {
     FPIC_SOLVER_NONE = 0,        /* fields are what fpic_set_field3 uploaded */
-    FPIC_SOLVER_POISSON_FFT = 1  /* rocFFT forward/inverse around a hand-written k-space kernel */
+    FPIC_SOLVER_POISSON_FFT = 1, /* rocFFT forward/inverse around a hand-written k-space kernel */
+    FPIC_SOLVER_YEE = 2          /* full EM (BASELINE configs[4]): Yee FDTD, node-centred CIC gather of E and B, charge-conserving
+                                    integer current deposit (zigzag); precalc() sets E to the Poisson field of the charge on the
+                                    lattice's edges and B to the uniform external field; density() deposits the charge grid */
 } fpic_solver;
 
 /* spec.shape: the deposit of density() on the (r,z) grid (SURVEY.md 8(b) key shape:'ref11'|'cic'). */
@@ -115,7 +118,13 @@ typedef enum fpic_field3 {
     FPIC_F3_E = 0,         /* in: value[i][j][k][3] V/m;  out: 4 per node (Ex, Ey, Ez, phi) */
     FPIC_F3_RHO = 1,       /* out: C/m^3, 1 per node */
     FPIC_F3_PHI = 2,       /* out: V, 1 per node */
-    FPIC_F3_RHO_FIXED = 3  /* out: int64 per node, 2^42 per unit charge number (exact, order-free) */
+    FPIC_F3_RHO_FIXED = 3, /* out: int64 per node, 2^42 per unit charge number (exact, order-free) */
+    /* full EM only; lattice arrays are 4 per node: E = (Ex(i+1/2,j,k), Ey(i,j+1/2,k), Ez(i,j,k+1/2), 0), B on the faces */
+    FPIC_F3_B_NODES = 4,   /* out: node-centred B, 4 per node */
+    FPIC_F3_EDGE_E = 5,    /* in: value[i][j][k][3]; out: 4 per node */
+    FPIC_F3_FACE_B = 6,    /* in: value[i][j][k][3]; out: 4 per node */
+    FPIC_F3_J_FIXED = 7    /* out: 3 int64 per node (x-, y-, z-edge), 96 * 2^42 per particle crossing a dual face: with RHO_FIXED the
+                              lattice continuity equation 96 (rho^(n+1) - rho^n) + div J = 0 holds exactly */
 } fpic_field3;
 
 /* Device buffers whose address can be handed to a collective (see fpic_device_buffer). */
