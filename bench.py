@@ -282,6 +282,50 @@ def es3d_line(device, n, grid, steps, warmup, stream=None, cpu=True):
     return out
 
 
+def em_line(device, n, grid, steps, warmup, precision="fp64"):
+    """Extension (no reference counterpart, parity unpinned): the full-EM cycle of BASELINE configs[4] on one GPU — node-centred
+    gather + Boris + integer charge-conserving current deposit (both fields and the current accumulators of an 8x8x8-cell tile
+    staged in LDS), Yee FDTD (B half, E, B half)."""
+    import fusionpic as fp
+    import torch
+    c, eps0, me, qe, vth = 2.998e8, 8.8541878128e-12, 9.109e-31, -1.602e-19, 1e-3
+    wp = 1e10
+    dx = vth * c / wp                                   # Debye length
+    L = grid * dx
+    dt = 0.5 * dx / (c * 3 ** 0.5)
+    n0 = wp ** 2 * eps0 * me / qe ** 2
+    spec = dict(radius=L, length_y=L, height=L, nr=grid, ny=grid, nz=grid, dt=dt, nparticles=0, count=n, particle_mass=me, particle_charge=qe,
+                geometry="cart3d", solver="yee", macro_weight=n0 * L ** 3 / n, precision=precision)
+    sim = fp.makeCylindricalParticlePusher(spec, device=device)
+    for first, pos, vel in es3d_blocks(n, L, vth):
+        sim.setRange(first, position=pos, velocity=vel)
+    sim.sort(); sim.precalc()
+    for _ in range(warmup):
+        sim.step()
+    sim.sync(); torch.cuda.synchronize()
+    sim.resetStats(); sim.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.step()
+    sim.sync(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = sim.stats()
+    sim.destroy()
+    sub = 2 * steps
+    esize = 8 if precision == "fp64" else 4
+    push_ms = st["ms_push"] / max(1, st["step_launches"])
+    algo = 12.0 * esize * n
+    return {"what": "spec.solver='yee' (EXTENSION, parity unpinned): %d^3 periodic Yee lattice, %.1e electrons, %s"
+                    % (grid, n, precision),
+            "value": n * sub / el, "unit": "particle-updates/s", "ms_per_substep": 1e3 * el / sub,
+            "kernel_ms_per_substep": {"push_gather_current": push_ms, "fdtd_b_e_b": st["ms_solve"] / max(1, st["solve_launches"]),
+                                      "rebinning": st["ms_sort"] / sub},
+            "roofline": {"bound": "hbm", "kernel": "em_push_tiles_kernel<%s>" % ("double" if esize == 8 else "float"), "achieved": algo / (push_ms * 1e-3) / 1e9 if push_ms else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if push_ms else 0.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": push_ms},
+            "fdtd_algorithmic_bytes": 21 * esize * grid ** 3}
+
+
 def es3d_cpu_port(seconds_target=5.0):
     """The build's own CPU oracle of the same cycle (oracle/es3d_oracle.c, OpenMP) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -341,6 +385,8 @@ def main():
     ap.add_argument("--c3-particles", type=int, default=500_000_000, help="extensions.c3: particles of the electrostatic box (BASELINE configs[2]: 5e8)")
     ap.add_argument("--c3-grid", type=int, default=256, help="extensions.c3: nodes per axis (BASELINE configs[2]: 256)")
     ap.add_argument("--only-c3", action="store_true", help="development: measure extensions.c3 alone and print it")
+    ap.add_argument("--only-em", action="store_true", help="development: measure the full-EM extension alone (--c3-particles, --c3-grid, --em-precision)")
+    ap.add_argument("--em-precision", choices=["fp32", "fp64"], default="fp64")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
 
@@ -371,6 +417,10 @@ def main():
 
     if args.only_c3:
         print(json.dumps({"c3": es3d_line(local_rank, args.c3_particles, args.c3_grid, args.steps, args.warmup, cpu=not args.no_cpu_baseline)}), flush=True)
+        return
+
+    if args.only_em:
+        print(json.dumps({"em": em_line(local_rank, args.c3_particles, args.c3_grid, args.steps, args.warmup, args.em_precision)}), flush=True)
         return
 
     spec = dict(radius=1.0, height=1.0, nr=args.grid, nz=args.grid, dt=2e-9, nparticles=args.side,

@@ -50,6 +50,7 @@ struct State {
     double lx = 0, ly = 0, lz = 0, W = 1;
     size_t nodes = 0;
     int solver = FPIC_SOLVER_NONE;
+    int ltx = 4, lty = 4, ltz = 3; // log2 of the tile edges: 16x16x8 cells (electrostatic), 8x8x8 (full EM)
     int ntx = 0, nty = 0, ntz = 0;
     uint32_t ntiles = 0; // + 1 always-empty bin (the scan kernel's clipped bin)
     long long* rho_fixed = nullptr;
@@ -182,7 +183,8 @@ int launch_push(fpic_handle* h, Species& s)
     const Push3Args<T> a = push_args<T>(h, s);
     const bool has_b = st->B0[0] != 0 || st->B0[1] != 0 || st->B0[2] != 0;
     if (s.n == 0) return FPIC_OK;
-    if (s.binned) {
+    // (the full-EM mode bins by 8x8x8-cell tiles: its charge grid — a diagnostic there — takes the flat form)
+    if (s.binned && st->solver != FPIC_SOLVER_YEE) {
         const unsigned grid = static_cast<unsigned>(s.work_cap);
         constexpr size_t lds = push3_lds_bytes<T>();
         if constexpr (DEPOSIT_ONLY) {
@@ -224,10 +226,14 @@ int launch_bin(fpic_handle* h, Species& s)
     T* dst = static_cast<T*>(s.slab[s.cur ^ 1]);
     const int nw = s.wl ^ 1;
     HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
-    bin3_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
+    const bool em = st->ltx == kEL;
+    if (em) bin3_count_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
+    else bin3_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
     bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
-    bin3_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
-                                                        st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
+    if (em) bin3_scatter_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
+                                                                             st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
+    else bin3_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
+                                                             st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
     HIP_TRY(h, hipGetLastError());
     s.cur ^= 1;
     s.wl = nw;
@@ -392,8 +398,21 @@ int em_substep(fpic_handle* h)
     State* st = h->es;
     bool unbinned = false;
     for (const Species& s : st->sp) unbinned |= !s.binned;
-    if (unbinned || st->substeps_since_bin >= 8) // tile order keeps the L2 gathers and the current's atomics local
+    // re-bin (three-pass form) when currents start to miss the LDS window (lagged read-back) or after 64 sub-steps: an
+    // EM step moves a thermal particle by a small fraction of a cell (c dt < dx / sqrt 3)
+    bool rebin = unbinned || st->substeps_since_bin >= 64;
+    if (!rebin) {
+        const int slot = static_cast<int>(st->spill_seq & 1);
+        if (st->spill_pending[slot]) {
+            HIP_TRY(h, hipEventSynchronize(st->spill_event[slot]));
+            st->last_spill = st->spilled_host[slot];
+            st->spill_pending[slot] = false;
+        }
+        rebin = st->last_spill * 512 > total_particles(st);
+    }
+    if (rebin)
         if (int rc = bin_all<T>(h, true)) return rc;
+    HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
     if (int rc = em_nodes<T>(h)) return rc;
     const double dt = h->spec.dt;
     const double d[3] = { st->lx / st->nx, st->ly / st->ny, st->lz / st->nz };
@@ -411,10 +430,25 @@ int em_substep(fpic_handle* h)
         a.hc = static_cast<T>(hh) / static_cast<T>(kSpeedOfLight); // in T, as the oracle forms it
         a.dx = static_cast<T>(step / st->lx); a.dy = static_cast<T>(step / st->ly); a.dz = static_cast<T>(step / st->lz);
         a.Z = s.Z;
-        em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
+        if (s.binned) {
+            EmTileArgs<T> t{};
+            t.p = a;
+            t.ntx = st->ntx; t.nty = st->nty; t.ntz = st->ntz;
+            t.work = s.work2[s.wl]; t.nwork = s.nwork2[s.wl];
+            t.spilled = st->spilled;
+            em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmThreads, em_lds_bytes<T>(), h->stream>>>(t);
+        } else {
+            em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
+        }
         HIP_TRY(h, hipGetLastError());
     }
     timing_end(h);
+    {
+        const int slot = static_cast<int>(st->spill_seq++ & 1);
+        HIP_TRY(h, hipMemcpyAsync(st->spilled_host + slot, st->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipEventRecord(st->spill_event[slot], h->stream));
+        st->spill_pending[slot] = true;
+    }
     timing_begin(h, KC_SOLVE);
     const T cb[3] = { static_cast<T>(dt / (2 * d[0])), static_cast<T>(dt / (2 * d[1])), static_cast<T>(dt / (2 * d[2])) };
     const double c2 = kSpeedOfLight * kSpeedOfLight;
@@ -598,7 +632,10 @@ int create_state(fpic_handle* h)
         (e = set_lds(push3_tiles_kernel<T, false, false, true>, push3_lds_bytes<T>())) != hipSuccess ||
         (e = set_lds(push3_tiles_kernel<T, true, false, true>, push3_lds_bytes<T>())) != hipSuccess ||
         (e = set_lds(bin3_count_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
-        (e = set_lds(bin3_scatter_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess)
+        (e = set_lds(bin3_scatter_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
+        (e = set_lds(bin3_count_kernel<T, kEL, kEL, kEL>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
+        (e = set_lds(bin3_scatter_kernel<T, kEL, kEL, kEL>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
+        (e = set_lds(em_push_tiles_kernel<T>, em_lds_bytes<T>())) != hipSuccess)
         return fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
 
     if (st->solver == FPIC_SOLVER_YEE) {
@@ -672,13 +709,14 @@ int create(fpic_handle* h)
     st->fields_ready = sp.solver == FPIC_SOLVER_NONE; // static fields (zero until fpic_set_field3) need no precalc()
     st->nodes = static_cast<size_t>(st->nx) * st->ny * st->nz;
     if (st->nodes >= (1ull << 31)) return fail(h, FPIC_ERR_INVALID_ARG, ".nr <- at most 2^31 nodes per device");
-    st->ntx = (st->nx + kTX - 1) / kTX;
-    st->nty = (st->ny + kTY - 1) / kTY;
-    st->ntz = (st->nz + kTZ - 1) / kTZ;
+    if (sp.solver == FPIC_SOLVER_YEE) st->ltx = st->lty = st->ltz = kEL;
+    st->ntx = (st->nx + (1 << st->ltx) - 1) >> st->ltx;
+    st->nty = (st->ny + (1 << st->lty) - 1) >> st->lty;
+    st->ntz = (st->nz + (1 << st->ltz) - 1) >> st->ltz;
     const size_t nt = static_cast<size_t>(st->ntx) * st->nty * st->ntz + 1;
     if (nt > static_cast<size_t>(kMaxTiles3))
         return fail(h, FPIC_ERR_INVALID_ARG, ".nr <- grid of %d x %d x %d nodes exceeds %d tiles of %dx%dx%d cells per device", st->nx, st->ny, st->nz,
-                    kMaxTiles3, kTX, kTY, kTZ);
+                    kMaxTiles3, 1 << st->ltx, 1 << st->lty, 1 << st->ltz);
     st->ntiles = static_cast<uint32_t>(nt);
     Species s0;
     s0.mass = sp.particle_mass; s0.charge = sp.particle_charge; s0.Z = 1;

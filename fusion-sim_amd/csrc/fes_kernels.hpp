@@ -51,7 +51,7 @@ struct Win {
 };
 constexpr int kPushThreads3 = 1024;                // 16 waves per CU: 14 % faster than 512 (profiles/r02_push3_ablation.txt)
 constexpr int kChunk3 = 32768;                   // particles per workgroup and chunk
-constexpr int kMaxTiles3 = 32768;                // LDS histogram limit of the binning passes (256^3 has 8192 tiles)
+constexpr int kMaxTiles3 = 40960;                // LDS histogram limit of the binning passes: 160 KB (256^3: 8192 tiles of 16x16x8, 32768 of 8x8x8)
 constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
 
 template <typename T> __device__ __forceinline__ T floor_(T v);
@@ -301,9 +301,12 @@ __device__ __forceinline__ void store_state3(const Push3Args<T>& a, size_t base,
 }
 
 static_assert((kTX & (kTX - 1)) == 0 && (kTY & (kTY - 1)) == 0 && (kTZ & (kTZ - 1)) == 0, "tile edges are powers of two: cell -> tile is a shift");
+// LX, LY, LZ: log2 of the tile edges (the electrostatic cycle bins by 16x16x8 cells, the full-EM cycle by 8x8x8)
+template <int LX = 4, int LY = 4, int LZ = 3>
 __device__ __forceinline__ uint32_t tile_key3(int i, int j, int k, int ntx, int nty)
 {
-    const unsigned tx = static_cast<unsigned>(i) / kTX, ty = static_cast<unsigned>(j) / kTY, tz = static_cast<unsigned>(k) / kTZ;
+    static_assert((1 << LX) == kTX || LX == 3, "default shape = the electrostatic tile");
+    const unsigned tx = static_cast<unsigned>(i) >> LX, ty = static_cast<unsigned>(j) >> LY, tz = static_cast<unsigned>(k) >> LZ;
     return tx + __umul24(static_cast<unsigned>(ntx), ty + __umul24(static_cast<unsigned>(nty), tz));
 }
 
@@ -665,17 +668,17 @@ __global__ __launch_bounds__(256) void init3_kernel(T* slab, size_t stride, uint
     id[i] = static_cast<uint32_t>(i);
 }
 
-template <typename T>
+template <typename T, int LX = 4, int LY = 4, int LZ = 3>
 __device__ __forceinline__ uint32_t key_of(T x, T y, T z, int nx, int ny, int nz, int ntx, int nty)
 {
     int i, j, k, w;
     axis(x, nx, i, w); axis(y, ny, j, w); axis(z, nz, k, w);
-    return tile_key3(i, j, k, ntx, nty);
+    return tile_key3<LX, LY, LZ>(i, j, k, ntx, nty);
 }
 
 constexpr int kBinPer3 = 8;
 
-template <typename T>
+template <typename T, int LX = 4, int LY = 4, int LZ = 3>
 __global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ slab, size_t stride, size_t n, int nx, int ny, int nz, int ntx, int nty,
                                                          uint32_t ntiles, uint32_t* __restrict__ tile_count)
 {
@@ -686,14 +689,14 @@ __global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ s
     for (int k = 0; k < kBinPer3; ++k) {
         const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
         if (i < n && !(slab[i] < static_cast<T>(0))) // (x < 0 marks a slot whose particle has migrated to another rank)
-            atomicAdd(&hist3[key_of(slab[i], slab[stride + i], slab[2 * stride + i], nx, ny, nz, ntx, nty)], 1u);
+            atomicAdd(&hist3[key_of<T, LX, LY, LZ>(slab[i], slab[stride + i], slab[2 * stride + i], nx, ny, nz, ntx, nty)], 1u);
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < ntiles; t += 256)
         if (hist3[t]) atomicAdd(&tile_count[t], hist3[t]);
 }
 
-template <typename T>
+template <typename T, int LX = 4, int LY = 4, int LZ = 3>
 __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t stride, const uint32_t* __restrict__ src_id,
                                                            uint32_t* __restrict__ dst_id, size_t n, int nx, int ny, int nz, int ntx, int nty,
                                                            uint32_t ntiles, const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor)
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__
         const size_t i = base + static_cast<size_t>(k) * 256 + threadIdx.x;
         key[k] = ~0u; rank[k] = 0;
         if (i < n && !(src[i] < static_cast<T>(0))) {
-            key[k] = key_of(src[i], src[stride + i], src[2 * stride + i], nx, ny, nz, ntx, nty);
+            key[k] = key_of<T, LX, LY, LZ>(src[i], src[stride + i], src[2 * stride + i], nx, ny, nz, ntx, nty);
             rank[k] = atomicAdd(&hist3[key[k]], 1u);
         }
     }
@@ -843,8 +846,9 @@ __device__ __forceinline__ long long em_coord(T u, int n)
 
 __device__ __forceinline__ long long floor_div_ll(long long a, long long s) { return a >= 0 ? a / s : -((-a + s - 1) / s); }
 
-// one straight segment inside one cell (current_segment)
-__device__ __forceinline__ void current_segment(const long long (&p1)[3], const long long (&p2)[3], const long long (&cell)[3], int nx, int ny, int nz, int Z,
+// one straight segment inside one cell (current_segment).  Not inlined: the rare global path must not bloat the
+// unrolled particle loops of its callers.
+__device__ __attribute__((noinline)) void current_segment(const long long (&p1)[3], const long long (&p2)[3], const long long (&cell)[3], int nx, int ny, int nz, int Z,
                                                 unsigned long long* Jfix)
 {
     constexpr long long S = 32768;
@@ -971,6 +975,284 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
     const long long from[3] = { hx0, hy0, hz0 };
     const long long to[3] = { em_coord(x, a.nx), em_coord(y, a.ny), em_coord(z, a.nz) };
     current_deposit(from, to, a.nx, a.ny, a.nz, a.Z, a.Jfix);
+}
+
+// Tiled form of the full-EM push: 8x8x8-cell tiles, so that both node-centred fields (2 x 4 T per node) and the three
+// int64 current accumulators of a tile and its halo fit in LDS (11^3 nodes x 56 B = 74.5 KB float, x 88 B = 117 KB double).  A particle's gather is 16 ds_read_b128 (float), its current 12 ds_add_u64 when
+// it stays in its cell (the two half-segments of es3d_current are merged: their sum equals the whole segment's fluxes
+// exactly, see current_cell) and 24 when it crosses a face.  Out-of-window particles take the global path.
+constexpr int kEL = 3;                 // log2 of the EM tile edge
+constexpr int kET = 1 << kEL;
+constexpr int kEmThreads = 512;
+template <typename T>
+struct EmWin {
+    // one halo cell: an EM step moves a particle by a small fraction of a cell (c dt < dx / sqrt 3), and at 74.5 KB the
+    // float window lets two workgroups share a CU (one stages or flushes while the other computes)
+    static constexpr int H = 1;
+    static constexpr int W = kET + 2 * H + 1;
+    static constexpr int N = W * W * W;
+};
+template <typename T>
+constexpr size_t em_lds_bytes() { return static_cast<size_t>(EmWin<T>::N) * (8 * sizeof(T) + 24) + 16; }
+
+template <typename T>
+struct EmTileArgs {
+    EmPushArgs<T> p;
+    int ntx, nty, ntz;
+    const BlockWork* work;
+    const uint32_t* nwork;
+    unsigned long long* spilled;
+};
+
+// window slot of cell (i,j,k) (all eight corner nodes inside), or -1; cells lie within one box length of the grid
+template <typename T>
+__device__ __forceinline__ int em_slot(int i, int j, int k, int ox, int oy, int oz, int nx, int ny, int nz)
+{
+    int l = i - ox, m = j - oy, n = k - oz;
+    if (l < 0) l += nx;
+    if (l >= nx) l -= nx;
+    if (m < 0) m += ny;
+    if (m >= ny) m -= ny;
+    if (n < 0) n += nz;
+    if (n >= nz) n -= nz;
+    constexpr int W = EmWin<T>::W;
+    const bool in = static_cast<unsigned>(l) <= static_cast<unsigned>(W - 2) && static_cast<unsigned>(m) <= static_cast<unsigned>(W - 2) &&
+                    static_cast<unsigned>(n) <= static_cast<unsigned>(W - 2);
+    return in ? __mul24(__mul24(n, W) + m, W) + l : -1;
+}
+
+// fluxes of one straight segment inside the cell whose window slot is s (current_segment, LDS accumulators)
+template <typename T>
+__device__ __attribute__((noinline)) void current_cell(const int (&p1)[3], const int (&p2)[3], const int (&cell)[3], int s, int Z,
+                                                       FPIC_LDS unsigned long long* lJ)
+{
+    constexpr int S = 32768;
+    constexpr int W = EmWin<T>::W;
+    const int step[3] = { 1, W, W * W };
+    long long d[3], A0[3], A1[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const long long l1 = p1[m] - cell[m] * S, l2 = p2[m] - cell[m] * S;
+        d[m] = l2 - l1;
+        A1[m] = l1 + l2; A0[m] = 2 * S - A1[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if (d[m] == 0) continue;
+        const int u = (m + 1) % 3, v = (m + 2) % 3;
+        const long long cross = d[u] * d[v];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const long long flux = d[m] * (3 * (b ? A1[u] : A0[u]) * (c ? A1[v] : A0[v]) + (b == c ? cross : -cross)) * Z;
+                __hip_atomic_fetch_add(lJ + 3 * (s + b * step[u] + c * step[v]) + m, static_cast<unsigned long long>(flux), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    }
+}
+
+// The common case — the particle stays in its cell — in 32-bit arithmetic.  In single (not doubled) units g = H/2 the
+// whole-segment flux is 8 Z D [3 s_u s_v +- d_u d_v] with s = g1 + g2 <= 2^15, |d| <= 2^14: the bracket is a
+// non-negative number below 2^32 formed with full-rate 24-bit multiplies, and one 32 x 32 -> 64 multiply finishes it
+// (generic 64-bit products were most of this kernel's VALU work).  Equal to the oracle's two half-segments: see above.
+template <typename T>
+__device__ __forceinline__ void current_cell_fast(const int (&p1)[3], const int (&p2)[3], const int (&cell)[3], int s, int Z,
+                                                  FPIC_LDS unsigned long long* lJ)
+{
+    constexpr int Sg = 16384;
+    constexpr int W = EmWin<T>::W;
+    const int step[3] = { 1, W, W * W };
+    int d[3];
+    unsigned A0[3], A1[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int g1 = (p1[m] >> 1) - cell[m] * Sg, g2 = (p2[m] >> 1) - cell[m] * Sg;
+        d[m] = g2 - g1;
+        A1[m] = static_cast<unsigned>(g1 + g2);
+        A0[m] = static_cast<unsigned>(2 * Sg) - A1[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if (d[m] == 0) continue;
+        const int u = (m + 1) % 3, v = (m + 2) % 3;
+        const int cross = __mul24(d[u], d[v]);
+        const int dz8 = 8 * Z * d[m];
+        const unsigned mag = static_cast<unsigned>(dz8 < 0 ? -dz8 : dz8);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned term = 3u * __umul24(b ? A1[u] : A0[u], c ? A1[v] : A0[v]) + static_cast<unsigned>(b == c ? cross : -cross);
+                const unsigned long long pos = static_cast<unsigned long long>(mag) * term; // one v_mad_u64_u32
+                const unsigned long long flux = dz8 < 0 ? 0ull - pos : pos;
+                __hip_atomic_fetch_add(lJ + 3 * (s + b * step[u] + c * step[v]) + m, flux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T> t)
+{
+    const EmPushArgs<T>& a = t.p;
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int W = EmWin<T>::W, WN = EmWin<T>::N, H = EmWin<T>::H;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsem[];
+    FPIC_LDS T* lE = (FPIC_LDS T*)ldsem;
+    FPIC_LDS T* lB = lE + 4 * WN;
+    FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(lB + 4 * WN);
+    if (blockIdx.x >= *t.nwork) return;
+    const BlockWork w = t.work[blockIdx.x];
+    const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
+    const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
+    using V = typename NatVec16<T>::type;
+    constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
+    for (int s = threadIdx.x; s < WN; s += kEmThreads) {
+        const int n = s / (W * W), rem = s - n * (W * W);
+        const int m = rem / W, l = rem - m * W;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        if (gi < 0) gi += a.nx;
+        if (gj < 0) gj += a.ny;
+        if (gk < 0) gk += a.nz;
+        const size_t node = static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk);
+        lJ[3 * s] = 0ull; lJ[3 * s + 1] = 0ull; lJ[3 * s + 2] = 0ull;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.E4n + 4 * node + p * Vec16<T>::N);
+            *reinterpret_cast<FPIC_LDS V*>(lB + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.B4n + 4 * node + p * Vec16<T>::N);
+        }
+    }
+    __syncthreads();
+    unsigned my_spill = 0;
+    const T q14 = static_cast<T>(1.0 / 16384.0);
+    const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
+    const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
+    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kEmThreads) {
+        const size_t base = g * PPT;
+        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+        T v[6][PPT];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (q >= cnt) continue;
+            T x = v[0][q], y = v[1][q], z = v[2][q];
+            if (x < static_cast<T>(0)) continue;
+            int i, j, k, w1;
+            T fx[2], fy[2], fz[2];
+            int from[3]; // doubled fixed-point lattice coordinates fit 32 bits for grids of up to 2^15 nodes per axis
+            axis(x, a.nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14; from[0] = 2 * (i * 16384 + w1);
+            axis(y, a.ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14; from[1] = 2 * (j * 16384 + w1);
+            axis(z, a.nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14; from[2] = 2 * (k * 16384 + w1);
+            T E[3] = { 0, 0, 0 }, B[3] = { 0, 0, 0 };
+            const int s0 = em_slot<T>(i, j, k, ox, oy, oz, a.nx, a.ny, a.nz);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa) {
+                        T e[4], bb[4];
+                        if (s0 >= 0) {
+                            const int sl = s0 + aa + W * b + W * W * c;
+                            load4_lds3(lE + 4 * sl, e);
+                            load4_lds3(lB + 4 * sl, bb);
+                        } else {
+                            const int ii = (i + aa == a.nx) ? 0 : i + aa, jj = (j + b == a.ny) ? 0 : j + b, kk = (k + c == a.nz) ? 0 : k + c;
+                            const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(a.nx) * (static_cast<size_t>(jj) + static_cast<size_t>(a.ny) * kk);
+                            fpic::load4(a.E4n + 4 * node, e);
+                            fpic::load4(a.B4n + 4 * node, bb);
+                        }
+                        const T wgt = (fx[aa] * fy[b]) * fz[c];
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            E[m] = E[m] + wgt * e[m];
+                            B[m] = B[m] + wgt * bb[m];
+                        }
+                    }
+            const T ax = a.hc * E[0], ay = a.hc * E[1], az = a.hc * E[2];
+            const T tx = a.h * B[0], ty = a.h * B[1], tz = a.h * B[2];
+            const T f = static_cast<T>(2) / (static_cast<T>(1) + ((tx * tx + ty * ty) + tz * tz));
+            const T sx = f * tx, sy = f * ty, sz = f * tz;
+            const T ux = v[3][q] + ax, uy = v[4][q] + ay, uz = v[5][q] + az;
+            const T px = ux + (uy * tz - uz * ty);
+            const T py = uy + (uz * tx - ux * tz);
+            const T pz = uz + (ux * ty - uy * tx);
+            const T qx = ux + (py * sz - pz * sy);
+            const T qy = uy + (pz * sx - px * sz);
+            const T qz = uz + (px * sy - py * sx);
+            v[3][q] = qx + ax; v[4][q] = qy + ay; v[5][q] = qz + az;
+            x = wrap01(x + a.dx * v[3][q]);
+            y = wrap01(y + a.dy * v[4][q]);
+            z = wrap01(z + a.dz * v[5][q]);
+            v[0][q] = x; v[1][q] = y; v[2][q] = z;
+            // current: nearest periodic image, relay point, one or two segments (es3d_current), in 32-bit coordinates
+            constexpr int S = 32768;
+            const int nn[3] = { a.nx, a.ny, a.nz };
+            int to[3], ca[3], cb[3], r[3];
+            {
+                int ci, cw;
+                axis(x, a.nx, ci, cw); to[0] = 2 * (ci * 16384 + cw);
+                axis(y, a.ny, ci, cw); to[1] = 2 * (ci * 16384 + cw);
+                axis(z, a.nz, ci, cw); to[2] = 2 * (ci * 16384 + cw);
+            }
+            bool same = true;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int box = nn[m] * S;
+                int dd = to[m] - from[m];
+                if (2 * static_cast<long long>(dd) > box) dd -= box;
+                else if (2 * static_cast<long long>(dd) < -static_cast<long long>(box)) dd += box;
+                to[m] = from[m] + dd;
+                ca[m] = from[m] >> 15;   // floor division by S (arithmetic shift)
+                cb[m] = to[m] >> 15;
+                same &= ca[m] == cb[m];
+                r[m] = (ca[m] == cb[m]) ? (from[m] + to[m]) / 2 : (ca[m] > cb[m] ? ca[m] : cb[m]) * S;
+            }
+            const int sa = em_slot<T>(ca[0], ca[1], ca[2], ox, oy, oz, a.nx, a.ny, a.nz);
+            auto global_segment = [&](const int (&p1)[3], const int (&p2)[3], const int (&cell)[3]) {
+                const long long q1[3] = { p1[0], p1[1], p1[2] }, q2[3] = { p2[0], p2[1], p2[2] }, cc[3] = { cell[0], cell[1], cell[2] };
+                current_segment(q1, q2, cc, a.nx, a.ny, a.nz, a.Z, a.Jfix);
+                ++my_spill;
+            };
+            if (same) {
+                // both half-segments lie in one cell: their fluxes add up to the whole segment's, exactly
+                if (sa >= 0) current_cell_fast<T>(from, to, ca, sa, a.Z, lJ);
+                else global_segment(from, to, ca);
+            } else {
+                const int sb = em_slot<T>(cb[0], cb[1], cb[2], ox, oy, oz, a.nx, a.ny, a.nz);
+                if (sa >= 0) current_cell<T>(from, r, ca, sa, a.Z, lJ);
+                else global_segment(from, r, ca);
+                if (sb >= 0) current_cell<T>(r, to, cb, sb, a.Z, lJ);
+                else global_segment(r, to, cb);
+            }
+        }
+        if (cnt == PPT) {
+#pragma unroll
+            for (int f = 0; f < 6; ++f) store_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                if (q < cnt) {
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) a.slab[f * a.stride + base + q] = v[f][q];
+                }
+        }
+    }
+    __syncthreads();
+    for (int s3 = threadIdx.x; s3 < 3 * WN; s3 += kEmThreads) {
+        const unsigned long long val = lJ[s3];
+        if (val == 0ull) continue;
+        const int s = s3 / 3, m3 = s3 - 3 * s;
+        const int n = s / (W * W), rem = s - n * (W * W);
+        const int m = rem / W, l = rem - m * W;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        if (gi < 0) gi += a.nx;
+        if (gj < 0) gj += a.ny;
+        if (gk < 0) gk += a.nz;
+        atomicAdd(a.Jfix + 3 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)) + m3, val);
+    }
+    if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));
 }
 
 // ------------------------------------------------------------------ spatial decomposition (z-slabs), SURVEY.md 8(e) row 2
