@@ -612,6 +612,7 @@ def main():
             "cic_sums_avg_launch_ms": cs["ms_deposit"] / max(1, cs["deposit_launches"]), "rebinning_launches": cs["sort_passes"]}
         cic.destroy()
         out["extensions"]["dense_sor"] = dense_sor_line(local_rank)
+        out["extensions"]["em"] = em_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, "fp64")
         out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, stream=stream,
                                             cpu=not args.no_cpu_baseline)
     if rank == 0:
