@@ -90,6 +90,14 @@ struct Domain {
     unsigned* counts_dev = nullptr;     // down, up, lost, overflow | received from above, from below
     unsigned* counts_host = nullptr;    // pinned copy
     uint64_t migrated = 0, lost = 0;
+    // slab-decomposed Poisson solve (distributed = true): 2-D transforms of the owned planes, transpose over the ranks,
+    // transforms along z of the rank's share of the ky rows, and back; otherwise every rank transforms the whole grid
+    bool distributed = false;
+    int nyl = 0;
+    void *hatA = nullptr, *hatB = nullptr, *xbuf = nullptr; // [nzl][ny][nxh], [nz][nyl][nxh], transposition staging (complex T each)
+    rocfft_plan p2f = nullptr, p2i = nullptr, pzf = nullptr, pzi = nullptr;
+    rocfft_execution_info i2f = nullptr, i2i = nullptr, izf = nullptr, izi = nullptr;
+    void* fft_work[4] = {};
 };
 
 namespace {
@@ -735,6 +743,13 @@ void release(fpic_handle* h)
                          d->mig_recv[1], static_cast<void*>(d->counts_dev) })
             if (p) (void)hipFree(p);
         if (d->counts_host) (void)hipHostFree(d->counts_host);
+        for (void* p : { d->hatA, d->hatB, d->xbuf, d->fft_work[0], d->fft_work[1], d->fft_work[2], d->fft_work[3] })
+            if (p) (void)hipFree(p);
+        const fdyn::RocFFT& ffd = fdyn::rocfft();
+        if (ffd.ok) {
+            for (rocfft_plan pl : { d->p2f, d->p2i, d->pzf, d->pzi }) if (pl) (void)ffd.plan_destroy(pl);
+            for (rocfft_execution_info in : { d->i2f, d->i2i, d->izf, d->izi }) if (in) (void)ffd.execution_info_destroy(in);
+        }
         delete d;
     }
     for (void* p : { st->Ey, st->By, st->B4n, static_cast<void*>(st->Jfix) })
@@ -896,8 +911,9 @@ struct Xfer {
     size_t send_bytes;
     void* recv;
     size_t recv_bytes;
+    int tag;                // a message meets the receive of its destination that names the sender and carries the same tag
 };
-enum Exchange { X_GHOST = 0, X_MIG_COUNTS, X_MIG_PAYLOAD };
+enum Exchange { X_GHOST = 0, X_MIG_COUNTS, X_MIG_PAYLOAD, X_TRANSPOSE, X_TRANSPOSE_BACK, X_PHI };
 
 // The messages of one exchange, in an order every rank shares: [0] goes to the slab below and is met there by
 // what arrives from above, [1] goes up and is met by what arrives from below.  (RCCL matches the sends and
@@ -912,15 +928,26 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
     out.clear();
     if (which == X_GHOST) {
         const int lo = (d.z0 - d.G + st->nz) % st->nz, hi = (d.z0 + d.nzl) % st->nz;
-        out.push_back({ down, up, st->rho_fixed + lo * plane, d.G * plane * 8, d.ghost_recv[0], d.G * plane * 8 });
-        out.push_back({ up, down, st->rho_fixed + hi * plane, (d.G + 1) * plane * 8, d.ghost_recv[1], (d.G + 1) * plane * 8 });
+        out.push_back({ down, up, st->rho_fixed + lo * plane, d.G * plane * 8, d.ghost_recv[0], d.G * plane * 8, 0 });
+        out.push_back({ up, down, st->rho_fixed + hi * plane, (d.G + 1) * plane * 8, d.ghost_recv[1], (d.G + 1) * plane * 8, 1 });
     } else if (which == X_MIG_COUNTS) {
-        out.push_back({ down, up, d.counts_dev + 0, 4, d.counts_dev + 4, 4 });
-        out.push_back({ up, down, d.counts_dev + 1, 4, d.counts_dev + 5, 4 });
-    } else {
+        out.push_back({ down, up, d.counts_dev + 0, 4, d.counts_dev + 4, 4, 0 });
+        out.push_back({ up, down, d.counts_dev + 1, 4, d.counts_dev + 5, 4, 1 });
+    } else if (which == X_MIG_PAYLOAD) {
         const size_t rec = sizeof(MigRecord<T>);
-        out.push_back({ down, up, d.mig_send[0], d.counts_host[0] * rec, d.mig_recv[0], d.counts_host[4] * rec });
-        out.push_back({ up, down, d.mig_send[1], d.counts_host[1] * rec, d.mig_recv[1], d.counts_host[5] * rec });
+        out.push_back({ down, up, d.mig_send[0], d.counts_host[0] * rec, d.mig_recv[0], d.counts_host[4] * rec, 0 });
+        out.push_back({ up, down, d.mig_send[1], d.counts_host[1] * rec, d.mig_recv[1], d.counts_host[5] * rec, 1 });
+    } else if (which == X_TRANSPOSE || which == X_TRANSPOSE_BACK) {
+        // all-to-all of equal chunks: chunk q of the send side goes to rank q and lands there as chunk `rank`
+        const size_t chunk = static_cast<size_t>(d.nzl) * d.nyl * (st->nx / 2 + 1) * 2 * sizeof(T);
+        const char* src = static_cast<const char*>(which == X_TRANSPOSE ? d.xbuf : d.hatB);
+        char* dst = static_cast<char*>(which == X_TRANSPOSE ? d.hatB : d.xbuf);
+        for (int q = 0; q < d.world; ++q) out.push_back({ q, q, src + q * chunk, chunk, dst + q * chunk, chunk, 0 });
+    } else { // X_PHI: the potential on the planes the gradient of my slab and its ghost planes needs
+        T* phi = static_cast<T*>(st->phi);
+        const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.G - 1 + st->nz) % st->nz;
+        out.push_back({ down, up, phi + d.z0 * plane, (d.G + 2) * plane * sizeof(T), phi + above * plane, (d.G + 2) * plane * sizeof(T), 0 });
+        out.push_back({ up, down, phi + (d.z0 + d.nzl - d.G - 1) * plane, (d.G + 1) * plane * sizeof(T), phi + below * plane, (d.G + 1) * plane * sizeof(T), 1 });
     }
 }
 
@@ -940,24 +967,32 @@ int exchange(Ranks& rk, int which)
         std::vector<Xfer> x;
         dom_xfers<T>(h, which, x);
         if (int e = fcomm::check(h, rc.GroupStart(), "ncclGroupStart")) return e;
+        const int me = h->comm->rank;
         for (const Xfer& m : x) {
+            if (m.to == me && m.from == me) continue; // to myself: a copy, below
             if (m.send_bytes)
                 if (int e = fcomm::check(h, rc.Send(m.send, m.send_bytes, ncclChar, m.to, h->comm->nccl, h->stream), "ncclSend")) return e;
             if (m.recv_bytes)
                 if (int e = fcomm::check(h, rc.Recv(m.recv, m.recv_bytes, ncclChar, m.from, h->comm->nccl, h->stream), "ncclRecv")) return e;
         }
-        return fcomm::check(h, rc.GroupEnd(), "ncclGroupEnd");
+        if (int e = fcomm::check(h, rc.GroupEnd(), "ncclGroupEnd")) return e;
+        for (const Xfer& m : x)
+            if (m.to == me && m.from == me && m.send_bytes && m.recv != m.send)
+                HIP_TRY(h, hipMemcpyAsync(m.recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, h->stream));
+        return FPIC_OK;
     }
     std::vector<std::vector<Xfer>> all(rk.hs.size());
     for (size_t r = 0; r < rk.hs.size(); ++r) dom_xfers<T>(rk.hs[r], which, all[r]);
     for (size_t r = 0; r < rk.hs.size(); ++r)
-        for (size_t i = 0; i < all[r].size(); ++i) {
-            const Xfer& m = all[r][i];
-            const Xfer& peer = all[m.to][i];
-            if (peer.recv_bytes != m.send_bytes || peer.from != static_cast<int>(r))
-                return fail(rk.hs[r], FPIC_ERR_STATE, "decomposition exchange %d: message %zu of rank %zu (%zu bytes) does not match rank %d's receive (%zu bytes)",
-                            which, i, r, m.send_bytes, m.to, peer.recv_bytes);
-            if (m.send_bytes) HIP_TRY(rk.hs[r], hipMemcpyAsync(peer.recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, rk.hs[0]->stream));
+        for (const Xfer& m : all[r]) {
+            const Xfer* peer = nullptr;
+            for (const Xfer& c : all[m.to])
+                if (c.from == static_cast<int>(r) && c.tag == m.tag) { peer = &c; break; }
+            if (!peer || peer->recv_bytes != m.send_bytes)
+                return fail(rk.hs[r], FPIC_ERR_STATE, "decomposition exchange %d: a message of rank %zu to rank %d (%zu bytes, tag %d) has no matching receive", which, r,
+                            m.to, m.send_bytes, m.tag);
+            if (m.send_bytes && peer->recv != m.send)
+                HIP_TRY(rk.hs[r], hipMemcpyAsync(peer->recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, rk.hs[0]->stream));
         }
     return FPIC_OK;
 }
@@ -1048,6 +1083,76 @@ int migrate(Ranks& rk)
     return FPIC_OK;
 }
 
+// The Poisson solve of a decomposed run without any rank holding the whole spectrum: per rank 2-D real transforms of
+// its nzl planes, an all-to-all transposition (each pair of ranks exchanges nzl * nyl * nxh complex values), the
+// transforms along z and the k-space factor on the rank's nyl rows of ky, the transposition back, the inverse 2-D
+// transforms, and the potential of G + 1 / G + 2 neighbouring planes for the gradient on the slab and its ghost planes.
+template <typename T>
+int solve_distributed(Ranks& rk)
+{
+    const fdyn::RocFFT& ff = fdyn::rocfft();
+    auto each = [&](auto fn) -> int {
+        for (fpic_handle* h : rk.hs)
+            if (int e = fn(h)) return e;
+        return FPIC_OK;
+    };
+    auto run_fft = [&](fpic_handle* h, rocfft_plan plan, rocfft_execution_info info, void* in, void* out, const char* what) -> int {
+        if (int e = fft_status(h, ff.execution_info_set_stream(info, h->stream), "rocfft_execution_info_set_stream")) return e;
+        void* ib[1] = { in };
+        void* ob[1] = { out };
+        return fft_status(h, ff.execute(plan, ib, ob, info), what);
+    };
+    if (int e = each([&](fpic_handle* h) -> int {
+            State* st = h->es;
+            Domain& d = *st->dom;
+            const int nxh = st->nx / 2 + 1;
+            const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+            timing_begin(h, KC_SOLVE);
+            if (int e2 = run_fft(h, d.p2f, d.i2f, static_cast<T*>(st->rho) + d.z0 * plane, d.hatA, "rocfft_execute (2-D forward)")) return e2;
+            const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
+            transpose_pack_kernel<T><<<blocks_for(total), 256, 0, h->stream>>>(static_cast<const T*>(d.hatA), nxh, st->ny, d.nzl, d.nyl, static_cast<T*>(d.xbuf));
+            HIP_TRY(h, hipGetLastError());
+            return FPIC_OK;
+        })) return e;
+    if (int e = exchange<T>(rk, X_TRANSPOSE)) return e;
+    if (int e = each([&](fpic_handle* h) -> int {
+            State* st = h->es;
+            Domain& d = *st->dom;
+            const int nxh = st->nx / 2 + 1;
+            if (int e2 = run_fft(h, d.pzf, d.izf, d.hatB, d.hatB, "rocfft_execute (z forward)")) return e2;
+            const size_t modes = static_cast<size_t>(nxh) * d.nyl * st->nz;
+            kspace_slab_kernel<T><<<blocks_for(modes), 256, 0, h->stream>>>(static_cast<T*>(d.hatB), nxh, d.nyl, st->nz, d.rank * d.nyl, st->k2[0], st->k2[1], st->k2[2],
+                                                                           1.0 / (kEps0 * static_cast<double>(st->nodes)));
+            HIP_TRY(h, hipGetLastError());
+            return run_fft(h, d.pzi, d.izi, d.hatB, d.hatB, "rocfft_execute (z inverse)");
+        })) return e;
+    if (int e = exchange<T>(rk, X_TRANSPOSE_BACK)) return e;
+    if (int e = each([&](fpic_handle* h) -> int {
+            State* st = h->es;
+            Domain& d = *st->dom;
+            const int nxh = st->nx / 2 + 1;
+            const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+            const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
+            transpose_unpack_kernel<T><<<blocks_for(total), 256, 0, h->stream>>>(static_cast<const T*>(d.xbuf), nxh, st->ny, d.nzl, d.nyl, static_cast<T*>(d.hatA));
+            HIP_TRY(h, hipGetLastError());
+            return run_fft(h, d.p2i, d.i2i, d.hatA, static_cast<T*>(st->phi) + d.z0 * plane, "rocfft_execute (2-D inverse)");
+        })) return e;
+    if (int e = exchange<T>(rk, X_PHI)) return e;
+    return each([&](fpic_handle* h) -> int {
+        State* st = h->es;
+        Domain& d = *st->dom;
+        const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+        const int count = d.nzl + 2 * d.G + 1;
+        gradient_planes_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
+            static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, d.z0 - d.G, count, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
+            static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4));
+        HIP_TRY(h, hipGetLastError());
+        timing_end(h);
+        h->solve_launches++;
+        return FPIC_OK;
+    });
+}
+
 template <typename T>
 int dom_fields(Ranks& rk)
 {
@@ -1071,6 +1176,7 @@ int dom_fields(Ranks& rk)
         HIP_TRY(h, hipGetLastError());
         timing_end(h);
     }
+    if (multi && rk.hs[0]->es->dom->distributed) return solve_distributed<T>(rk);
     if (multi)
         if (int e = allgather_rho<T>(rk)) return e;
     for (fpic_handle* h : rk.hs)
@@ -1194,7 +1300,7 @@ int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes)
 
 // ---- decomposition entry points (fpic_domain_*, fpic_group_*)
 
-int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every)
+int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve)
 {
     State* st = h->es;
     if (st->dom) return fail(h, FPIC_ERR_STATE, "the handle is already decomposed");
@@ -1224,6 +1330,43 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&d->counts_host), 8 * sizeof(unsigned)));
     std::memset(d->counts_host, 0, 8 * sizeof(unsigned));
     for (Species& s : st->sp) s.n = 0; // the rank's particles arrive through domain_set_particles
+    if (distributed_solve && world > 1 && st->solver == FPIC_SOLVER_POISSON_FFT) {
+        if (st->ny % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d rows along y do not divide into %d shares for the decomposed solve", st->ny, world);
+        if (ghost_planes + 2 > nzl) return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- the decomposed solve needs ghost_planes + 2 <= %d planes per slab", nzl);
+        const fdyn::RocFFT& ff = fdyn::rocfft();
+        if (!ff.ok) return fail(h, FPIC_ERR_STATE, "rocFFT is not available (%s)", ff.why.c_str());
+        d->distributed = true;
+        d->nyl = st->ny / world;
+        const size_t nxh = st->nx / 2 + 1, esz = h->esize;
+        const size_t cbytes = nxh * st->ny * nzl * 2 * esz;
+        if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc))) return rc;
+        const rocfft_precision prec = h->prec == FPIC_F32 ? rocfft_precision_single : rocfft_precision_double;
+        const size_t len2[2] = { static_cast<size_t>(st->nx), static_cast<size_t>(st->ny) };
+        const size_t lenz[1] = { static_cast<size_t>(st->nz) };
+        rocfft_plan_description desc = nullptr;
+        const size_t stride[1] = { static_cast<size_t>(d->nyl) * nxh }, off[1] = { 0 };
+        if ((rc = fft_status(h, ff.plan_create(&d->p2f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 2, len2, nzl, nullptr), "rocfft_plan_create (2-D forward)")) ||
+            (rc = fft_status(h, ff.plan_create(&d->p2i, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 2, len2, nzl, nullptr), "rocfft_plan_create (2-D inverse)")) ||
+            (rc = fft_status(h, ff.plan_description_create(&desc), "rocfft_plan_description_create")) ||
+            (rc = fft_status(h, ff.plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, off, off, 1, stride, 1, 1,
+                                                                   stride, 1), "rocfft_plan_description_set_data_layout")) ||
+            (rc = fft_status(h, ff.plan_create(&d->pzf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 1, lenz, stride[0], desc), "rocfft_plan_create (z forward)")) ||
+            (rc = fft_status(h, ff.plan_create(&d->pzi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 1, lenz, stride[0], desc), "rocfft_plan_create (z inverse)")))
+            return rc;
+        (void)ff.plan_description_destroy(desc);
+        rocfft_plan plans[4] = { d->p2f, d->p2i, d->pzf, d->pzi };
+        rocfft_execution_info* infos[4] = { &d->i2f, &d->i2i, &d->izf, &d->izi };
+        for (int k = 0; k < 4; ++k) {
+            size_t wb = 0;
+            if ((rc = fft_status(h, ff.execution_info_create(infos[k]), "rocfft_execution_info_create")) ||
+                (rc = fft_status(h, ff.plan_get_work_buffer_size(plans[k], &wb), "rocfft_plan_get_work_buffer_size")))
+                return rc;
+            if (wb) {
+                if ((rc = dev_alloc(h, &d->fft_work[k], wb, acc))) return rc;
+                if ((rc = fft_status(h, ff.execution_info_set_work_buffer(*infos[k], d->fft_work[k], wb), "rocfft_execution_info_set_work_buffer"))) return rc;
+            }
+        }
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FPIC_OK;
 }

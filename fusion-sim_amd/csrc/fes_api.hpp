@@ -22,7 +22,7 @@ int step(fpic_handle* h, int ncalls);
 int sort(fpic_handle* h);
 int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
 // z-slab decomposition
-int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every);
+int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve);
 int domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype);
 int domain_get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, uint32_t* ids, uint64_t capacity, uint64_t* n_out, int dtype);
 int domain_stats(fpic_handle* h, uint64_t* migrated, uint64_t* lost);

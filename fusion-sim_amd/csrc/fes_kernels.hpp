@@ -1315,6 +1315,73 @@ static __global__ __launch_bounds__(256) void ghost_add_kernel(long long* __rest
     if (c < count) dst[c] += src[c];
 }
 
+// ---- slab-decomposed Poisson solve: the half spectrum of the owned planes, hatA [nzl][ny][nxh] (complex T), is
+// transposed over the ranks into hatB [nz][nyl][nxh] (all z, the rank's share of the ky rows) and back
+
+// hatA -> send buffer [q][nzl][nyl][nxh]: the block of rows that rank q transforms along z
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pack_kernel(const T* __restrict__ hatA, int nxh, int ny, int nzl, int nyl, T* __restrict__ send)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t total = static_cast<size_t>(nxh) * ny * nzl;
+    if (c >= total) return;
+    const int x = static_cast<int>(c % nxh), y = static_cast<int>((c / nxh) % ny), z = static_cast<int>(c / (static_cast<size_t>(nxh) * ny));
+    const int q = y / nyl, yl = y - q * nyl;
+    const size_t d = ((static_cast<size_t>(q) * nzl + z) * nyl + yl) * nxh + x;
+    send[2 * d] = hatA[2 * c];
+    send[2 * d + 1] = hatA[2 * c + 1];
+}
+
+// receive buffer [q][nzl][nyl][nxh] (what rank q transformed of MY planes) -> hatA
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_unpack_kernel(const T* __restrict__ recv, int nxh, int ny, int nzl, int nyl, T* __restrict__ hatA)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t total = static_cast<size_t>(nxh) * ny * nzl;
+    if (c >= total) return;
+    const int x = static_cast<int>(c % nxh), y = static_cast<int>((c / nxh) % ny), z = static_cast<int>(c / (static_cast<size_t>(nxh) * ny));
+    const int q = y / nyl, yl = y - q * nyl;
+    const size_t d = ((static_cast<size_t>(q) * nzl + z) * nyl + yl) * nxh + x;
+    hatA[2 * c] = recv[2 * d];
+    hatA[2 * c + 1] = recv[2 * d + 1];
+}
+
+// phi_hat = rho_hat / (eps0 K^2 N) on hatB [nz][nyl][nxh]: ky = y0 + yl (kspace_kernel of the decomposed solve)
+template <typename T>
+__global__ __launch_bounds__(256) void kspace_slab_kernel(T* __restrict__ hatB, int nxh, int nyl, int nz, int y0, const double* __restrict__ k2x,
+                                                          const double* __restrict__ k2y, const double* __restrict__ k2z, double inv_eps0_n)
+{
+    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= static_cast<size_t>(nxh) * nyl * nz) return;
+    const int i = static_cast<int>(c % nxh), j = y0 + static_cast<int>((c / nxh) % nyl), k = static_cast<int>(c / (static_cast<size_t>(nxh) * nyl));
+    const double K2 = (k2x[i] + k2y[j]) + k2z[k];
+    const T g = (i | j | k) ? static_cast<T>(inv_eps0_n / K2) : static_cast<T>(0);
+    hatB[2 * c] = hatB[2 * c] * g;
+    hatB[2 * c + 1] = hatB[2 * c + 1] * g;
+}
+
+// gradient_kernel on the planes k0 .. k0 + count - 1 (periodic)
+template <typename T>
+__global__ __launch_bounds__(256) void gradient_planes_kernel(const T* __restrict__ phi, int nx, int ny, int nz, int k0, int count, T hx, T hy, T hz,
+                                                              T* __restrict__ E4)
+{
+    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
+    if (t >= sz * count) return;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny);
+    int k = k0 + static_cast<int>(t / sz);
+    k %= nz;
+    if (k < 0) k += nz;
+    const size_t c = i + sy * j + sz * k;
+    const int im = i ? i - 1 : nx - 1, ip = (i + 1 == nx) ? 0 : i + 1;
+    const int jm = j ? j - 1 : ny - 1, jp = (j + 1 == ny) ? 0 : j + 1;
+    const int km = k ? k - 1 : nz - 1, kp = (k + 1 == nz) ? 0 : k + 1;
+    E4[4 * c] = (phi[im + sy * j + sz * k] - phi[ip + sy * j + sz * k]) * hx;
+    E4[4 * c + 1] = (phi[i + sy * jm + sz * k] - phi[i + sy * jp + sz * k]) * hy;
+    E4[4 * c + 2] = (phi[i + sy * j + sz * km] - phi[i + sy * j + sz * kp]) * hz;
+    E4[4 * c + 3] = phi[c];
+}
+
 // ids of a freshly uploaded population: first + slot
 static __global__ __launch_bounds__(256) void iota3_kernel(uint32_t* id, size_t n, uint32_t first)
 {

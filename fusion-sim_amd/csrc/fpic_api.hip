@@ -1278,11 +1278,11 @@ int fpic_set_particles_range(fpic_handle* h, int species, uint64_t first, uint64
 }
 
 // ---- CART3D spatial decomposition (z-slabs)
-int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every)
+int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve)
 {
     CHECK_HANDLE(h);
     BOX_ONLY(h, "fpic_domain_init");
-    return fes::domain_init(h, rank, world, ghost_planes, migrate_every);
+    return fes::domain_init(h, rank, world, ghost_planes, migrate_every, distributed_solve);
 }
 int fpic_domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype)
 {

@@ -43,6 +43,9 @@ const RocFFT& rocfft()
         bool ok = bind(lib, "rocfft_setup", r.setup, r.why);
         ok &= bind(lib, "rocfft_plan_create", r.plan_create, r.why);
         ok &= bind(lib, "rocfft_plan_destroy", r.plan_destroy, r.why);
+        ok &= bind(lib, "rocfft_plan_description_create", r.plan_description_create, r.why);
+        ok &= bind(lib, "rocfft_plan_description_destroy", r.plan_description_destroy, r.why);
+        ok &= bind(lib, "rocfft_plan_description_set_data_layout", r.plan_description_set_data_layout, r.why);
         ok &= bind(lib, "rocfft_plan_get_work_buffer_size", r.plan_get_work_buffer_size, r.why);
         ok &= bind(lib, "rocfft_execution_info_create", r.execution_info_create, r.why);
         ok &= bind(lib, "rocfft_execution_info_destroy", r.execution_info_destroy, r.why);

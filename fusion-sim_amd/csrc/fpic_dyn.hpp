@@ -18,6 +18,9 @@ struct RocFFT {
     decltype(&rocfft_setup) setup = nullptr;
     decltype(&rocfft_plan_create) plan_create = nullptr;
     decltype(&rocfft_plan_destroy) plan_destroy = nullptr;
+    decltype(&rocfft_plan_description_create) plan_description_create = nullptr;
+    decltype(&rocfft_plan_description_destroy) plan_description_destroy = nullptr;
+    decltype(&rocfft_plan_description_set_data_layout) plan_description_set_data_layout = nullptr;
     decltype(&rocfft_plan_get_work_buffer_size) plan_get_work_buffer_size = nullptr;
     decltype(&rocfft_execution_info_create) execution_info_create = nullptr;
     decltype(&rocfft_execution_info_destroy) execution_info_destroy = nullptr;

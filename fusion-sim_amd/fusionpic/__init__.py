@@ -134,7 +134,7 @@ def load_library(path=None):
     lib.fpic_comm_destroy.argtypes = [vp]
     lib.fpic_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.fpic_comm_set_overlap.argtypes = [vp, ci]
-    lib.fpic_domain_init.argtypes = [vp, ci, ci, ci, ci]
+    lib.fpic_domain_init.argtypes = [vp, ci, ci, ci, ci, ci]
     lib.fpic_domain_set_particles.argtypes = [vp, ci, ctypes.c_uint64, vp, vp, ctypes.c_uint32, ci]
     lib.fpic_domain_get_particles.argtypes = [vp, ci, vp, vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ci]
     lib.fpic_domain_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
@@ -491,8 +491,8 @@ class ElectrostaticBoxPusher:
         self._check(self._lib.fpic_set_particles_range(self._h, species, int(first), m, ptr(arrs[0]), ptr(arrs[1]), codes.pop()))
 
     # ---- spatial decomposition (z-slabs; include/fusionpic.h, fpic_domain_*)
-    def domainInit(self, rank, world, ghost_planes=2, migrate_every=4):
-        self._check(self._lib.fpic_domain_init(self._h, int(rank), int(world), int(ghost_planes), int(migrate_every)))
+    def domainInit(self, rank, world, ghost_planes=2, migrate_every=4, distributed_solve=False):
+        self._check(self._lib.fpic_domain_init(self._h, int(rank), int(world), int(ghost_planes), int(migrate_every), 1 if distributed_solve else 0))
 
     def domainSet(self, position, velocity, first_id, species=0):
         p, v = _as_float_array(position), _as_float_array(velocity)

@@ -319,7 +319,11 @@ int fpic_comm_set_overlap(fpic_handle* h, int enable);
  *   with a communicator (fpic_comm_init, one process per GPU): fpic_precalc / fpic_step exchange over RCCL;
  *   fpic_group_precalc / fpic_group_step: all `n` ranks are handles of THIS process on one device and the exchange
  *   is device-to-device copies — the stand-in that lets one GPU run and test an N-rank decomposition. */
-int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every);
+/* distributed_solve = 0: every rank gathers rho and transforms the whole grid (the N-rank run is then bit-identical to one GPU);
+ * 1: the Poisson solve is decomposed too — 2-D transforms of the owned planes, an all-to-all transposition (each pair of ranks
+ * exchanges nz/N * ny/N * (nx/2+1) complex values), transforms along z on ny/N rows, the transposition back, and G+1 / G+2 planes
+ * of the potential from the neighbours: no rank touches the whole grid, fields agree with one GPU to rounding (needs ny % N == 0) */
+int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve);
 /* the rank's initial particles (positions anywhere in its slab +- ghost planes); their global indices are first_id, first_id+1, ... */
 int fpic_domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype);
 /* the particles the rank holds now, in no particular order, with their global indices; *n receives the count
