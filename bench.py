@@ -454,7 +454,11 @@ def main():
 
     sim = build(args.rng)
     sim.precalc()
+    sim.sync()
+    t_bin = time.perf_counter()
     sim.sort()  # first binning of the randomly ordered upload belongs to setup, like the upload itself
+    sim.sync()
+    first_binning_ms = 1e3 * (time.perf_counter() - t_bin)
 
     sharded = None
     if distributed and args.comm == "lib":
@@ -544,6 +548,8 @@ def main():
                 "bin_table_scan": st["ms_sort"] / args.steps, "rebinning_launches": st["sort_passes"],
                 "last_spilled": st["deposit_spilled"],
             },
+            "setup": {"first_binning_ms": first_binning_ms,
+                      "what": "count + scan + two-level scatter of the randomly ordered upload (host clock, synchronised), outside the timed region"},
         }
         tr = measured_traffic({"particles_per_gpu": n_local, "grid": [spec["nr"], spec["nz"]], "rng": args.rng, "dtype": "f32"})
         if tr is None:

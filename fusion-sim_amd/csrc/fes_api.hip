@@ -129,7 +129,7 @@ int alloc_species(fpic_handle* h, Species& s)
     uint64_t* acc = &h->bytes_grid;
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * st->ntiles, acc)))
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * (st->ntiles + fpic::kSortMaxBins + 1), acc))) // + chunk_first of the two-level binning
         return rc;
     for (int k = 0; k < 2; ++k)
         if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_start2[k]), sizeof(uint32_t) * (st->ntiles + 1), acc)) ||
@@ -238,12 +238,51 @@ int launch_bin(fpic_handle* h, Species& s)
     if (em) bin3_count_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
     else bin3_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
     bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
-    if (em) bin3_scatter_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
-                                                                             st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
-    else bin3_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
-                                                             st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
+    // large populations: scatter staged through LDS (fpic_kernels.hpp, sort_scatter_kernel), in two levels when there
+    // are many tiles; after two passes the compact sorted array is back in the set it started in
+    const bool staged = s.n >= h->two_level_min;
+    bool two_level = false;
+    if (staged) {
+        uint32_t div = 1; // few tiles: one staged pass is enough
+        while (st->ntiles > 64 && div * div < st->ntiles) ++div;
+        two_level = div > 1;
+        const uint32_t ncoarse = (st->ntiles + div - 1) / div;
+        uint32_t* chunk_first = s.tile_cursor + st->ntiles;
+        auto columns = [&](int from) {
+            fpic::SortColumns<T, 6, false> c{};
+            for (int f = 0; f < 6; ++f) {
+                c.src[f] = static_cast<const T*>(s.slab[from]) + f * s.n_pad;
+                c.dst[f] = static_cast<T*>(s.slab[from ^ 1]) + f * s.n_pad;
+            }
+            c.src_id = s.id[from]; c.dst_id = s.id[from ^ 1];
+            return c;
+        };
+        const size_t lds = fpic::sort_scatter_lds(sizeof(T));
+        const unsigned nc = blocks_for(s.n, fpic::kSortChunk);
+        auto run = [&](auto key) -> int {
+            auto kern = fpic::sort_scatter_kernel<T, 6, false, decltype(key)>;
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            fpic::sort_chunks_kernel<<<1, 1024, 0, h->stream>>>(s.tile_start2[nw], st->ntiles, div, ncoarse, chunk_first);
+            kern<<<nc, fpic::kSortThreads, lds, h->stream>>>(columns(s.cur), s.n, key, st->ntiles, div, ncoarse, s.tile_start2[nw], s.tile_cursor, nullptr);
+            if (two_level) {
+                HIP_TRY(h, hipMemsetAsync(s.tile_cursor, 0, sizeof(uint32_t) * st->ntiles, h->stream));
+                kern<<<nc + ncoarse, fpic::kSortThreads, lds, h->stream>>>(columns(s.cur ^ 1), s.n, key, st->ntiles, div, ncoarse, s.tile_start2[nw],
+                                                                          s.tile_cursor, chunk_first);
+            }
+            return FPIC_OK;
+        };
+        if (int rc = em ? run(BoxTileKey<T, kEL, kEL, kEL>{ st->nx, st->ny, st->nz, st->ntx, st->nty })
+                        : run(BoxTileKey<T>{ st->nx, st->ny, st->nz, st->ntx, st->nty }))
+            return rc;
+    } else if (em) {
+        bin3_scatter_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
+                                                                        st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
+    } else {
+        bin3_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx, st->nty,
+                                                        st->ntiles, s.tile_start2[nw], s.tile_cursor);
+    }
     HIP_TRY(h, hipGetLastError());
-    s.cur ^= 1;
+    if (!two_level) s.cur ^= 1;
     s.wl = nw;
     s.binned = true;
     s.census_fresh = s.rebin_pending = false; // tile_count now describes this binning, not a push

@@ -678,6 +678,16 @@ __device__ __forceinline__ uint32_t key_of(T x, T y, T z, int nx, int ny, int nz
 
 constexpr int kBinPer3 = 8;
 
+// the key of the LDS-staged two-level binning (fpic_kernels.hpp); a slot with x < 0 is dead and is not copied
+template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+struct BoxTileKey {
+    int nx, ny, nz, ntx, nty;
+    __device__ __forceinline__ uint32_t operator()(T x, T y, T z) const
+    {
+        return x < static_cast<T>(0) ? ~0u : key_of<T, LX, LY, LZ>(x, y, z, nx, ny, nz, ntx, nty);
+    }
+};
+
 template <typename T, int LX = 4, int LY = 4, int LZ = 3>
 __global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ slab, size_t stride, size_t n, int nx, int ny, int nz, int ntx, int nty,
                                                          uint32_t ntiles, uint32_t* __restrict__ tile_count)

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -317,11 +318,42 @@ int launch_bin(fpic_handle* h)
     bin_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_count);
     const int nw = h->wl ^ 1;
     bin_scan_kernel<<<1, 1024, 0, h->stream>>>(h->tile_count, h->ntiles, h->tile_start2[nw], h->tile_cursor, h->work2[nw], h->nwork2[nw]);
-    bin_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_start2[nw],
-                                                       h->tile_cursor);
+    // large populations: scatter staged through LDS, in two levels (by group of tiles, then by tile) when there are
+    // many tiles; after two passes the data is back in the set it started in
+    const bool staged = h->n >= h->two_level_min;
+    bool two_level = false;
+    if (staged) {
+        uint32_t div = 1; // few tiles: one staged pass is enough (runs of >= 64 elements)
+        while (h->ntiles > 64 && div * div < h->ntiles) ++div;
+        two_level = div > 1;
+        const uint32_t ncoarse = (h->ntiles + div - 1) / div;
+        auto columns = [](const ParticleArrays<T>& a, const ParticleArrays<T>& b) {
+            SortColumns<T, 10, true> c{};
+            const T* s[10] = { a.x, a.y, a.z, a.vx, a.vy, a.vz, a.u1, a.u2, a.c1, a.c2 };
+            T* d[10] = { b.x, b.y, b.z, b.vx, b.vy, b.vz, b.u1, b.u2, b.c1, b.c2 };
+            for (int k = 0; k < 10; ++k) { c.src[k] = s[k]; c.dst[k] = d[k]; }
+            c.src_byte = a.alive; c.dst_byte = b.alive; c.src_id = a.id; c.dst_id = b.id;
+            return c;
+        };
+        const RzTileKey<T> key{ h->nr, h->nz, h->ntx, h->ntiles - 1 };
+        const size_t lds = sort_scatter_lds(sizeof(T));
+        auto kern = sort_scatter_kernel<T, 10, true, RzTileKey<T>>;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        sort_chunks_kernel<<<1, 1024, 0, h->stream>>>(h->tile_start2[nw], h->ntiles, div, ncoarse, h->coarse_cursor);
+        kern<<<blocks_for(h->n, kSortChunk), kSortThreads, lds, h->stream>>>(columns(src, dst), h->n, key, h->ntiles, div, ncoarse, h->tile_start2[nw],
+                                                                          h->tile_cursor, nullptr);
+        if (two_level) {
+            HIP_TRY(h, hipMemsetAsync(h->tile_cursor, 0, sizeof(uint32_t) * h->ntiles, h->stream));
+            kern<<<blocks_for(h->n, kSortChunk) + ncoarse, kSortThreads, lds, h->stream>>>(columns(dst, src), h->n, key, h->ntiles, div, ncoarse,
+                                                                                        h->tile_start2[nw], h->tile_cursor, h->coarse_cursor);
+        }
+    } else {
+        bin_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, h->n, h->nr, h->nz, h->ntx, h->ntiles, h->tile_start2[nw],
+                                                           h->tile_cursor);
+    }
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
-    h->cur ^= 1;
+    if (!two_level) h->cur ^= 1;
     h->wl = nw;
     h->census_fresh = false; // tile_count now describes this binning, not a fused push
     h->scatter_pending = false;
@@ -537,7 +569,7 @@ void release(fpic_handle* h)
     }
     void* bufs[] = { h->E, h->B, h->sink, h->sink_alive, h->inv_cdf_xy, h->entropy, h->coef, h->cell_sums, h->moments,
                      h->norm, h->avg, h->stamp, h->shape_half, h->shape_tenth, h->tile_count, h->tile_start2[0],
-                     h->tile_start2[1], h->tile_cursor, h->nwork2[0], h->nwork2[1], h->work2[0], h->work2[1], h->spilled };
+                     h->tile_start2[1], h->tile_cursor, h->coarse_cursor, h->nwork2[0], h->nwork2[1], h->work2[0], h->work2[1], h->spilled };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->spilled_host) (void)hipHostFree(h->spilled_host);
     for (hipEvent_t e : h->spill_event) if (e) (void)hipEventDestroy(e);
@@ -796,6 +828,7 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     fpic_handle* h = new (std::nothrow) fpic_handle();
     if (!h) return fail(nullptr, FPIC_ERR_OOM, "host allocation failed");
     h->spec = *spec;
+    if (const char* v = std::getenv("FPIC_TWO_LEVEL_MIN")) h->two_level_min = static_cast<size_t>(std::strtoull(v, nullptr, 10));
     h->k = derive_constants(*spec);
     h->prec = spec->precision;
     h->esize = spec->precision == FPIC_F64 ? 8 : 4;
@@ -856,6 +889,7 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_start2[0]), sizeof(uint32_t) * (h->ntiles + 1), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_start2[1]), sizeof(uint32_t) * (h->ntiles + 1), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->tile_cursor), sizeof(uint32_t) * h->ntiles, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->coarse_cursor), sizeof(uint32_t) * (kSortMaxBins + 1), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->nwork2[0]), sizeof(uint32_t), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->nwork2[1]), sizeof(uint32_t), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work2[0]), sizeof(BlockWork) * h->work_cap, acc)) ||

@@ -74,6 +74,8 @@ struct fpic_handle {
     fpic::BlockWork* work2[2] = {};
     int wl = 0;
     uint32_t* tile_cursor = nullptr;
+    size_t two_level_min = size_t(1) << 20; // populations from this size on are binned in two levels (FPIC_TWO_LEVEL_MIN overrides: tests)
+    uint32_t* coarse_cursor = nullptr; // two-level first binning: first chunk of each coarse bin (sort_chunks_kernel)
     size_t work_cap = 0;
     bool binned = false;
     int deposits_since_bin = 0;

@@ -742,4 +742,193 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(ParticleArrays<T> src,
     }
 }
 
+// First binning of a randomly ordered upload in two levels, each level a scatter staged through LDS.
+//
+// A single scatter by tile writes every particle to an unrelated place: from a 2048-particle chunk into 1000+ tiles the
+// runs are 2 elements long and every wave store touches 64 lines.  Here the population is scattered first by a COARSE
+// key (div = ceil(sqrt(ntiles)) consecutive tiles; coarse_start[c] = tile_start[c * div]) and then by tile inside each
+// coarse bin, and in both passes a workgroup sorts its 4096-particle chunk in LDS before it writes: every column goes
+// through a stage so that the 64 lanes of a wave store 64 consecutive elements of the locally sorted order (one run
+// of ~128 elements per bin and chunk).  The data moves twice, but in full lines.
+//
+// Columns: NT arrays of T (the first three are the position the key is taken from), then an optional byte column and
+// the 32-bit id column.  Key(x, y, z) returns the tile, or ~0u for a slot that is not to be copied (a dead slot of the
+// decomposed box).  Coarse pass: chunk_first == nullptr, chunks tile [0, n), bin = key / d.  Fine pass: chunk b
+// belongs to coarse bin c with chunk_first[c] <= b < chunk_first[c + 1] and covers
+// [tile_start[c * div] + m * chunk, tile_start[(c + 1) * div]), bin = key - c * div, d = 1.  Either way the bin's
+// destination is tile_start[key_lo + bin * d] + a workgroup-level reservation on cursor[key_lo + bin * d].
+constexpr int kSortThreads = 1024, kSortPer = 4, kSortChunk = kSortThreads * kSortPer, kSortMaxBins = 1024;
+
+template <typename T, int NT, bool HAS_BYTE>
+struct SortColumns {
+    const T* src[NT];
+    T* dst[NT];
+    const uint8_t* src_byte;
+    uint8_t* dst_byte;
+    const uint32_t* src_id;
+    uint32_t* dst_id;
+};
+
+inline size_t sort_scatter_lds(size_t elem) { return sizeof(uint32_t) * (kSortMaxBins + 32 + kSortChunk) + 3 * kSortChunk * elem; }
+
+// chunk_first[c] for the fine pass: exclusive prefix of ceil(count_c / chunk) over the coarse bins (one workgroup)
+static __global__ __launch_bounds__(1024) void sort_chunks_kernel(const uint32_t* __restrict__ tile_start, uint32_t ntiles, uint32_t div,
+                                                                  uint32_t ncoarse, uint32_t* __restrict__ chunk_first)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t c = threadIdx.x;
+    uint32_t v = 0;
+    if (c < ncoarse) {
+        const uint32_t lo = tile_start[c * div], hi = tile_start[min((c + 1) * div, ntiles)];
+        v = (hi - lo + kSortChunk - 1) / kSortChunk;
+    }
+    part[c] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t t = c >= static_cast<uint32_t>(o) ? part[c - o] : 0;
+        __syncthreads();
+        part[c] += t;
+        __syncthreads();
+    }
+    if (c < ncoarse) chunk_first[c] = part[c] - v;
+    if (c == ncoarse) chunk_first[c] = part[1023];
+}
+
+template <typename T, int NT, bool HAS_BYTE, typename Key>
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortColumns<T, NT, HAS_BYTE> col, size_t n, Key key_of_pos, uint32_t ntiles, uint32_t div,
+                                                                     uint32_t ncoarse, const uint32_t* __restrict__ tile_start,
+                                                                     uint32_t* __restrict__ cursor, const uint32_t* __restrict__ chunk_first)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(sort_lds);  // [kSortMaxBins]: counts, then local firsts, then global bases
+    uint32_t* wsum = hist + kSortMaxBins;                    // [32]
+    uint32_t* dst_of = wsum + 32;                            // [chunk]: global destination of locally sorted position j
+    T* stage = reinterpret_cast<T*>(dst_of + kSortChunk);    // [3][chunk]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // which part of the array, which bins
+    size_t begin, end;
+    uint32_t key_lo, d, nbins;
+    if (chunk_first == nullptr) {
+        begin = static_cast<size_t>(blockIdx.x) * kSortChunk;
+        end = min(n, begin + kSortChunk);
+        key_lo = 0; d = div; nbins = ncoarse;
+    } else {
+        if (blockIdx.x >= chunk_first[ncoarse]) return;
+        uint32_t lo = 0, hi = ncoarse; // largest c with chunk_first[c] <= blockIdx.x
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (chunk_first[mid] <= blockIdx.x) lo = mid; else hi = mid;
+        }
+        key_lo = lo * div; d = 1; nbins = min(div, ntiles - key_lo);
+        begin = static_cast<size_t>(tile_start[key_lo]) + static_cast<size_t>(blockIdx.x - chunk_first[lo]) * kSortChunk;
+        end = min(static_cast<size_t>(tile_start[min(key_lo + div, ntiles)]), begin + kSortChunk);
+    }
+    hist[tid] = 0;
+    __syncthreads();
+
+    T px[kSortPer], py[kSortPer], pz[kSortPer];
+    uint32_t bin[kSortPer], rank[kSortPer], pos[kSortPer];
+#pragma unroll
+    for (int k = 0; k < kSortPer; ++k) {
+        const size_t i = begin + static_cast<size_t>(k) * kSortThreads + tid;
+        bin[k] = ~0u; rank[k] = 0; px[k] = py[k] = pz[k] = 0;
+        if (i < end) {
+            px[k] = col.src[0][i]; py[k] = col.src[1][i]; pz[k] = col.src[2][i];
+            const uint32_t key = key_of_pos(px[k], py[k], pz[k]);
+            if (key != ~0u) {
+                bin[k] = (key - key_lo) / d;
+                rank[k] = atomicAdd(&hist[bin[k]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the (<= 1024) bin counts: local first position of each bin
+    const uint32_t cnt = hist[tid];
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t w = lane < kSortThreads / 64 ? wsum[lane] : 0;
+        uint32_t wi = w;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(wi, o);
+            if (lane >= static_cast<uint32_t>(o)) wi += t;
+        }
+        if (lane < kSortThreads / 64) wsum[lane] = wi - w;
+        if (lane == kSortThreads / 64 - 1) wsum[16] = wi;
+    }
+    __syncthreads();
+    hist[tid] = incl - cnt + wsum[wave];
+    const uint32_t total = wsum[16];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortPer; ++k) pos[k] = bin[k] != ~0u ? hist[bin[k]] + rank[k] : ~0u;
+    __syncthreads();
+    if (tid < nbins) {
+        const uint32_t idx = key_lo + tid * d;
+        hist[tid] = cnt ? tile_start[idx] + atomicAdd(&cursor[idx], cnt) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortPer; ++k)
+        if (pos[k] != ~0u) dst_of[pos[k]] = hist[bin[k]] + rank[k];
+
+    // the columns, three at a time: into the stage at the sorted position, out of it in sorted order
+    constexpr int NCOL = NT + (HAS_BYTE ? 1 : 0) + 1;
+    uint32_t* stage32 = reinterpret_cast<uint32_t*>(stage);
+#pragma unroll
+    for (int c0 = 0; c0 < NCOL; c0 += 3) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int c = c0 + s;
+            if (c >= NCOL) break;
+#pragma unroll
+            for (int k = 0; k < kSortPer; ++k) {
+                if (pos[k] == ~0u) continue;
+                const size_t i = begin + static_cast<size_t>(k) * kSortThreads + tid;
+                if (c < NT) {
+                    T v;
+                    if (c == 0) v = px[k]; else if (c == 1) v = py[k]; else if (c == 2) v = pz[k]; else v = col.src[c < NT ? c : 0][i];
+                    stage[s * kSortChunk + pos[k]] = v;
+                } else if (HAS_BYTE && c == NT) {
+                    stage32[s * kSortChunk * (sizeof(T) / 4) + pos[k]] = col.src_byte[i];
+                } else {
+                    stage32[s * kSortChunk * (sizeof(T) / 4) + pos[k]] = col.src_id[i];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int c = c0 + s;
+            if (c >= NCOL) break;
+#pragma unroll
+            for (int k = 0; k < kSortPer; ++k) {
+                const uint32_t j = static_cast<uint32_t>(k) * kSortThreads + tid;
+                if (j >= total) continue;
+                const size_t to = dst_of[j];
+                if (c < NT) col.dst[c < NT ? c : 0][to] = stage[s * kSortChunk + j];
+                else if (HAS_BYTE && c == NT) col.dst_byte[to] = static_cast<uint8_t>(stage32[s * kSortChunk * (sizeof(T) / 4) + j]);
+                else col.dst_id[to] = stage32[s * kSortChunk * (sizeof(T) / 4) + j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+struct RzTileKey {
+    int nr, nz, ntx;
+    uint32_t last;
+    __device__ __forceinline__ uint32_t operator()(T x, T y, T z) const { return tile_key(x, y, z, nr, nz, ntx, last); }
+};
+
 } // namespace fpic

@@ -184,3 +184,10 @@ def test_em_from_precalc_keeps_gauss_and_energy(fp, eo, precision):
     dpos = np.abs(got["position"] - ora.positions()); dpos = np.minimum(dpos, 1 - dpos)
     assert dpos.max() <= (2e-3 if precision == "fp32" else 1e-7)
     sim.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_em_cycle_with_the_staged_binning(fp, eo, monkeypatch, precision):
+    """The LDS-staged two-level first binning (production: >= 2^20 particles) with the 8^3 tiles of the Yee mode."""
+    monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    test_em_cycle_bit_exact_in_given_lattice_fields(fp, eo, precision, (40, 32, 48), 20000)

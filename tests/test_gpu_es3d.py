@@ -468,3 +468,27 @@ def test_slab_decomposed_poisson_solve(fp, eo, precision, world, shape):
     assert sum(s["migrated"] for s in stats) > 0 and all(s["lost"] == 0 for s in stats)
     for s in ranks + [one]:
         s.destroy()
+
+
+# ---------------------------------------------------------------------------- LDS-staged (two-level) first binning
+# Populations of 2^20 particles and more are binned by sort_scatter_kernel; FPIC_TWO_LEVEL_MIN (read when the handle is
+# created) lowers that size so that the small oracle-checked scenes above run through the same kernels: ragged last
+# chunks, empty coarse bins, dead slots of a decomposed rank, fp64 stage, the 8^3 tiles of the Yee mode.
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("shape,n", [((16, 16, 8), 4000), ((72, 40, 48), 30011), ((160, 16, 16), 5000)])
+def test_staged_binning_on_small_scenes(fp, eo, monkeypatch, precision, shape, n):
+    monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    test_push_and_deposit_bit_exact_in_a_given_field(fp, eo, precision, shape, n, True, 1)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_staged_binning_of_a_decomposed_box(fp, eo, monkeypatch, precision):
+    monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    test_slab_decomposition_reproduces_one_gpu_bit_for_bit(fp, eo, precision, 4, (72, 40, 96), True)
+
+
+def test_two_level_binning_at_a_million_particles_is_bit_exact(fp, eo):
+    """2^20 + 777 electrons on a 64 x 64 x 32 grid (65 tiles: coarse groups of 9): the production size threshold, no
+    override; push + integer deposit bit-exact against the oracle after a first binning and two re-binnings."""
+    test_push_and_deposit_bit_exact_in_a_given_field(fp, eo, "fp32", (64, 64, 32), (1 << 20) + 777, True, 2)

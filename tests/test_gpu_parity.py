@@ -1130,3 +1130,33 @@ def test_sharded_pusher_overlapped_exchange_world_of_one(fp, po):
     finally:
         if own:
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------- LDS-staged (two-level) first binning
+# Populations of 2^20 particles and more are binned by sort_scatter_kernel (the full-size tests above); with
+# FPIC_TWO_LEVEL_MIN (read when the handle is created) the oracle-checked scenes run through the same kernels.
+
+@pytest.mark.parametrize("seed", [3, 101, 150, 160, 250, 310])
+def test_staged_binning_randomised_scenes(fp, po, monkeypatch, seed):
+    monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    test_randomised_scenes(fp, po, seed)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_staged_binning_many_tiles(fp, po, monkeypatch, precision):
+    """330 x 290 cells = 11 x 10 tiles: coarse groups of 11 tiles, a ragged last group, fp64 stage."""
+    monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    spec = make_spec(330, 290, 300, radius=1.0, height=2.0)
+    sim, ora = build_pair(fp, po, spec, precision, seed=5)
+    before = sim.getParticles()
+    sim.sort()
+    after = sim.getParticles()
+    for k in before:
+        assert same_bits(before[k], after[k])
+    for calls in (1, 2):
+        sim.step(calls); ora.step(calls)
+        sim.density(); ora.density()
+        assert_particles_equal(sim, ora, exact=True)
+    sim.sort()
+    sim.step(); ora.step()
+    assert_particles_equal(sim, ora, exact=True)
