@@ -326,6 +326,138 @@ def em_line(device, n, grid, steps, warmup, precision="fp64"):
             "fdtd_algorithmic_bytes": 21 * esize * grid ** 3}
 
 
+def c4_scene(total, grid, world):
+    """BASELINE configs[3] shape: periodic grid^3 box, electrons + protons (total/2 each) at the plasma parameters of
+    es3d_scene; returns the spec of ONE handle holding `share` x world particles per species."""
+    spec, L, vth = es3d_scene(total // 2, grid)
+    return spec, L, vth, 1836.15267 * spec["particle_mass"], -spec["particle_charge"]
+
+
+def c4_rank_particles(rank, world, species, share, L, vth, mass_ratio, device):
+    """Particles [rank*share, (rank+1)*share) of a species, generated on the device (2e9 particles would be minutes of
+    numpy): the ones that start in z-slab `rank` of `world`.  x, y on the Kronecker lattice of es3d_blocks,
+    z = (rank + frac) * L / world with a 20-bit frac (exact in float32, so a particle never rounds into the next
+    slab); velocities a Maxwellian block repeated with alternating sign."""
+    import torch
+    dev = torch.device("cuda", device)
+    ids = torch.arange(rank * share, (rank + 1) * share, dtype=torch.int64, device=dev)
+    pos = torch.empty((share, 3), dtype=torch.float32, device=dev)
+    for a, mult in enumerate((3518319155, 2882110345, 2360945575)):
+        t = (ids * mult + 0x9E3779B9 * (species + 1)) & 0xFFFFFFFF           # frac(i * alpha) in 32 bits
+        if a < 2:
+            pos[:, a] = (t >> 8).to(torch.float32) * (L / 16777216.0)
+        else:
+            pos[:, a] = ((t >> 12).to(torch.float32) * (1.0 / 1048576.0) + float(rank)) * (L / world)
+        del t
+    del ids
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC4 + species)
+    block = min(share, 1 << 24)
+    half = torch.randn((block, 3), dtype=torch.float32, device=dev, generator=gen) * (vth / mass_ratio ** 0.5)
+    pair = torch.cat([half, -half])
+    reps = (share + pair.shape[0] - 1) // pair.shape[0]
+    vel = pair.repeat(reps, 1)[:share].contiguous()
+    torch.cuda.synchronize(dev)
+    return pos, vel
+
+
+def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_single=False):
+    """Extension, parity unpinned: BASELINE configs[3] (two species, grid^3, `total` particles, z-slab decomposition over
+    `world` ranks) exercised at full size on ONE GPU: (1) one handle holding everything = the single-GPU strong-scaling
+    baseline; (2) the `world` ranks of the decomposition as handles of this process (fpic_group_*: the exchange is
+    device-to-device copies of the same buffers RCCL sends), which gives each rank's kernel time at its real share
+    and the bytes every exchange moves.  What one GPU cannot give is the link time of (2): it is priced in DESIGN.md 6
+    from these byte counts."""
+    import fusionpic as fp
+    import torch
+    spec, L, vth, mi, qi = c4_scene(total, grid, world)
+    share = total // 2 // world
+    def particles(r, sp):
+        return c4_rank_particles(r, world, sp, share, L, vth, 1.0 if sp == 0 else mi / spec["particle_mass"], device)
+
+    def run(step_fn, sync_fn, reset_fn):
+        for _ in range(warmup):
+            step_fn()
+        sync_fn(); torch.cuda.synchronize()
+        reset_fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync_fn(); torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    out = {"what": "BASELINE configs[3] shape on ONE GPU (EXTENSION, parity unpinned): %d^3 periodic grid, %.1e electrons + %.1e protons, %s, "
+                   "Poisson solve every sub-step" % (grid, share * world, share * world, precision),
+           "unit": "particle-updates/s"}
+    n_all = 2 * share * world
+    sub = 2 * steps
+    if not skip_single:
+        one = fp.makeCylindricalParticlePusher(dict(spec, count=share * world), device=device, precision=precision)
+        one.addSpecies(mi, qi, share * world)
+        for sp in (0, 1):
+            for r in range(world):
+                p, v = particles(r, sp)
+                one.setRange(r * share, position=p, velocity=v, species=sp)
+                del p, v
+        torch.cuda.empty_cache()
+        one.sort(); one.precalc()
+        def reset_one():
+            one.resetStats(); one.profile(True)
+        el = run(one.step, one.sync, reset_one)
+        st = one.stats()
+        fixed_sum = None
+        out["single_handle"] = {"value": n_all * sub / el, "ms_per_substep": 1e3 * el / sub,
+                                "kernel_ms_per_substep": {"push_both_species": st["ms_push"] / sub, "poisson_solve": st["ms_solve"] / max(1, st["solve_launches"]),
+                                                          "rebinning": st["ms_sort"] / sub},
+                                "device_bytes": st["bytes_particle_state"] + st["bytes_grid_state"]}
+        one.destroy()
+        del one
+    ranks = []
+    cap = int(share * 1.25)
+    for r in range(world):
+        s_ = fp.makeCylindricalParticlePusher(dict(spec, count=cap), device=device, precision=precision)
+        s_.addSpecies(mi, qi, cap)
+        s_.domainInit(r, world, ghost_planes=2, migrate_every=4, distributed_solve=True)
+        for sp in (0, 1):
+            p, v = particles(r, sp)
+            s_.domainSet(p, v, first_id=r * share, species=sp)
+            del p, v
+        ranks.append(s_)
+    torch.cuda.empty_cache()
+    group = fp.BoxGroup(ranks)
+    group.precalc()
+    def sync_all():
+        for s_ in ranks:
+            s_.sync()
+
+    def reset_all():
+        for s_ in ranks:
+            s_.resetStats(); s_.profile(True)
+    mig0 = [0]
+
+    def reset_and_note():
+        reset_all()
+        mig0[0] = sum(s_.domainStats()["migrated"] for s_ in ranks)
+    el = run(group.step, sync_all, reset_and_note)
+    sts = [s_.stats() for s_ in ranks]
+    dom = [s_.domainStats() for s_ in ranks]
+    esz = 4 if precision == "fp32" else 8
+    plane = grid * grid
+    slowest = max(range(world), key=lambda r: sts[r]["ms_push"] + sts[r]["ms_solve"] + sts[r]["ms_sort"])
+    out["decomposed_in_process"] = {
+        "ranks": world, "serial_ms_per_substep_all_ranks": 1e3 * el / sub,
+        "slowest_rank_kernel_ms_per_substep": {"push_both_species": sts[slowest]["ms_push"] / sub, "solve_share": sts[slowest]["ms_solve"] / sub,
+                                                "rebinning_and_migration": sts[slowest]["ms_sort"] / sub},
+        "particles_migrated_per_substep": (sum(d["migrated"] for d in dom) - mig0[0]) / float(sub), "lost": sum(d["lost"] for d in dom),
+        "exchange_bytes_per_rank_per_substep": {"ghost_planes_int64_reduce": 2 * 2 * plane * 8,
+                                                "fft_transposes": 2 * 2 * (grid // 2 + 1) * grid * (grid // world) * 2 * esz * (world - 1) // world,
+                                                "field_ghost_planes": 2 * 3 * plane * 4 * esz},
+    }
+    for s_ in ranks:
+        s_.destroy()
+    return out
+
+
 def es3d_cpu_port(seconds_target=5.0):
     """The build's own CPU oracle of the same cycle (oracle/es3d_oracle.c, OpenMP) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -387,6 +519,11 @@ def main():
     ap.add_argument("--only-c3", action="store_true", help="development: measure extensions.c3 alone and print it")
     ap.add_argument("--only-em", action="store_true", help="development: measure the full-EM extension alone (--c3-particles, --c3-grid, --em-precision)")
     ap.add_argument("--em-precision", choices=["fp32", "fp64"], default="fp64")
+    ap.add_argument("--only-c4", action="store_true", help="development: BASELINE configs[3] shape on one GPU (one handle, then the in-process decomposition)")
+    ap.add_argument("--c4-particles", type=float, default=2e9, help="--only-c4: total particles (two species, half each)")
+    ap.add_argument("--c4-grid", type=int, default=512)
+    ap.add_argument("--c4-ranks", type=int, default=8)
+    ap.add_argument("--c4-skip-single", action="store_true")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
 
@@ -417,6 +554,11 @@ def main():
 
     if args.only_c3:
         print(json.dumps({"c3": es3d_line(local_rank, args.c3_particles, args.c3_grid, args.steps, args.warmup, cpu=not args.no_cpu_baseline)}), flush=True)
+        return
+
+    if args.only_c4:
+        print(json.dumps({"c4": c4_line(local_rank, int(args.c4_particles), args.c4_grid, args.c4_ranks, args.steps, args.warmup,
+                                        skip_single=args.c4_skip_single)}), flush=True)
         return
 
     if args.only_em:

@@ -36,6 +36,9 @@ struct Species {
     // two bin tables: [wl] describes the live particle order, [wl ^ 1] is laid out by the next binning
     // (which may be the next push, see rebin_pending)
     uint32_t *tile_count = nullptr, *tile_cursor = nullptr;
+    // a migration rides on the next re-binning push: arrivals appended at [tail_first, tail_first + tail_count) of the
+    // current set, n_after = the population once that push has compacted the set
+    size_t tail_first = 0, tail_count = 0, n_after = 0;
     uint32_t *tile_start2[2] = {}, *nwork2[2] = {};
     BlockWork* work2[2] = {};
     int wl = 0;
@@ -205,11 +208,17 @@ int launch_push(fpic_handle* h, Species& s)
             else if (rebin) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else push3_tiles_kernel<T, false, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
+            if (rebin && s.tail_count) { // the arrivals of the migration that asked for this re-binning
+                if (has_b) push3_tail_kernel<T, true><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(a, s.tail_first, s.tail_count);
+                else push3_tail_kernel<T, false><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(a, s.tail_first, s.tail_count);
+            }
             HIP_TRY(h, hipGetLastError());
             s.census_fresh = true;
             if (rebin) { // this launch was the binning: the other set and the other tables are live now
                 s.cur ^= 1;
                 s.wl ^= 1;
+                if (s.n_after) s.n = s.n_after;
+                s.tail_first = s.tail_count = s.n_after = 0;
             }
         }
     } else {
@@ -235,12 +244,15 @@ int launch_bin(fpic_handle* h, Species& s)
     const int nw = s.wl ^ 1;
     HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
     const bool em = st->ltx == kEL;
-    if (em) bin3_count_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
+    const bool many_tiles = st->ntiles > static_cast<uint32_t>(kMaxTiles3); // no LDS histogram of that size
+    if (many_tiles && em) bin3_count_global_kernel<T, kEL, kEL, kEL><<<blocks_for(s.n), 256, 0, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, s.tile_count);
+    else if (many_tiles) bin3_count_global_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, s.tile_count);
+    else if (em) bin3_count_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
     else bin3_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
     bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
     // large populations: scatter staged through LDS (fpic_kernels.hpp, sort_scatter_kernel), in two levels when there
     // are many tiles; after two passes the compact sorted array is back in the set it started in
-    const bool staged = s.n >= h->two_level_min;
+    const bool staged = s.n >= h->two_level_min || many_tiles;
     bool two_level = false;
     if (staged) {
         uint32_t div = 1; // few tiles: one staged pass is enough
@@ -515,7 +527,7 @@ int em_substep(fpic_handle* h)
     return FPIC_OK;
 }
 
-// host holds the caller's particles [first, first + count)
+// `host` (host or device memory) holds the caller's particles [first, first + count)
 template <typename T, typename In>
 int upload_pos(fpic_handle* h, Species& s, const In* host, size_t first, size_t count)
 {
@@ -526,7 +538,7 @@ int upload_pos(fpic_handle* h, Species& s, const In* host, size_t first, size_t 
     T* a = static_cast<T*>(s.slab[s.cur]);
     for (size_t b = 0; b < count; b += chunk) {
         const size_t m = std::min(chunk, count - b);
-        hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyHostToDevice, h->stream);
+        hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyDefault, h->stream); // host or device memory
         if (e == hipSuccess) {
             set_pos3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1 / st->lx, 1 / st->ly, 1 / st->lz, a, a + s.n_pad,
                                                                          a + 2 * s.n_pad, s.id[s.cur], s.n);
@@ -548,7 +560,7 @@ int upload_vel(fpic_handle* h, Species& s, const In* host, size_t first, size_t 
     T* a = static_cast<T*>(s.slab[s.cur]);
     for (size_t b = 0; b < count; b += chunk) {
         const size_t m = std::min(chunk, count - b);
-        hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyHostToDevice, h->stream);
+        hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyDefault, h->stream); // host or device memory
         if (e == hipSuccess) {
             // velocities stay in units of c, unscaled
             set_vec3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1.0, 1.0, a + 3 * s.n_pad, a + 4 * s.n_pad,
@@ -761,9 +773,9 @@ int create(fpic_handle* h)
     st->nty = (st->ny + (1 << st->lty) - 1) >> st->lty;
     st->ntz = (st->nz + (1 << st->ltz) - 1) >> st->ltz;
     const size_t nt = static_cast<size_t>(st->ntx) * st->nty * st->ntz + 1;
-    if (nt > static_cast<size_t>(kMaxTiles3))
+    if (nt > static_cast<size_t>(kMaxTilesStaged3))
         return fail(h, FPIC_ERR_INVALID_ARG, ".nr <- grid of %d x %d x %d nodes exceeds %d tiles of %dx%dx%d cells per device", st->nx, st->ny, st->nz,
-                    kMaxTiles3, 1 << st->ltx, 1 << st->lty, 1 << st->ltz);
+                    kMaxTilesStaged3, 1 << st->ltx, 1 << st->lty, 1 << st->ltz);
     st->ntiles = static_cast<uint32_t>(nt);
     Species s0;
     s0.mass = sp.particle_mass; s0.charge = sp.particle_charge; s0.Z = 1;
@@ -1071,10 +1083,13 @@ int migrate(Ranks& rk)
             Domain& d = *st->dom;
             Species& s = st->sp[sp];
             HIP_TRY(h, hipMemsetAsync(d.counts_dev, 0, 8 * sizeof(unsigned), h->stream));
+            // a species whose last push left a census of the current positions is not re-binned by separate passes:
+            // the census is corrected for leavers and arrivals and the next push re-bins (and compacts) itself
+            const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
             if (s.n)
                 mig_pack_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
                                                                           static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]),
-                                                                          d.mig_cap, d.counts_dev);
+                                                                          d.mig_cap, d.counts_dev, riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty);
             HIP_TRY(h, hipGetLastError());
         }
         if (int e = exchange<T>(rk, X_MIG_COUNTS)) return e;
@@ -1098,18 +1113,33 @@ int migrate(Ranks& rk)
             if (s.n + in > s.n_pad || s.n - out + in > s.cap)
                 return fail(h, FPIC_ERR_STATE, "migration: rank %d would hold %zu particles of species %zu, capacity %zu", d.rank, s.n - out + in, sp, s.cap);
             T* slab = static_cast<T*>(s.slab[s.cur]);
+            const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
+            uint32_t* census = riding ? s.tile_count : nullptr;
             if (d.counts_host[4])
                 mig_append_kernel<T><<<blocks_for(d.counts_host[4]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[0]), d.counts_host[4], slab, s.n_pad,
-                                                                                        s.id[s.cur], s.n);
+                                                                                        s.id[s.cur], s.n, census, st->nx, st->ny, st->nz, st->ntx, st->nty);
             if (d.counts_host[5])
                 mig_append_kernel<T><<<blocks_for(d.counts_host[5]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[1]), d.counts_host[5], slab, s.n_pad,
-                                                                                        s.id[s.cur], s.n + d.counts_host[4]);
+                                                                                        s.id[s.cur], s.n + d.counts_host[4], census, st->nx, st->ny, st->nz, st->ntx,
+                                                                                        st->nty);
             HIP_TRY(h, hipGetLastError());
-            // the binning runs over the old slots (dead ones skipped) and the arrivals, and leaves a compact array
-            const size_t slots = s.n + in;
-            s.n = slots;
-            if (int e = launch_bin<T>(h, s)) return e;
-            s.n = slots - out;
+            if (riding) {
+                // the next bin table from the corrected census; the push that follows skips the dead slots, takes the
+                // arrivals from the tail and leaves a compact sorted array in the other set
+                const int nw = s.wl ^ 1;
+                bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
+                HIP_TRY(h, hipGetLastError());
+                s.rebin_pending = true;
+                s.tail_first = s.n; s.tail_count = in;
+                s.n_after = s.n - out + in;
+                if (s.n_after == 0) { s.n = 0; s.rebin_pending = false; s.tail_count = 0; } // (an emptied rank: nothing to push)
+            } else {
+                // the binning runs over the old slots (dead ones skipped) and the arrivals, and leaves a compact array
+                const size_t slots = s.n + in;
+                s.n = slots;
+                if (int e = launch_bin<T>(h, s)) return e;
+                s.n = slots - out;
+            }
         }
     }
     for (fpic_handle* h : rk.hs) {

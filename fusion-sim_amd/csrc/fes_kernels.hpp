@@ -51,7 +51,8 @@ struct Win {
 };
 constexpr int kPushThreads3 = 1024;                // 16 waves per CU: 14 % faster than 512 (profiles/r02_push3_ablation.txt)
 constexpr int kChunk3 = 32768;                   // particles per workgroup and chunk
-constexpr int kMaxTiles3 = 40960;                // LDS histogram limit of the binning passes: 160 KB (256^3: 8192 tiles of 16x16x8, 32768 of 8x8x8)
+constexpr int kMaxTiles3 = 40960;                // LDS histogram limit of the one-level binning passes: 160 KB (256^3: 8192 tiles of 16x16x8, 32768 of 8x8x8)
+constexpr int kMaxTilesStaged3 = 1 << 20;        // beyond kMaxTiles3 (512^3: 65536 / 262144 tiles): global-atomic census + the staged two-level scatter (<= 1024^2 bins)
 constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
 
 template <typename T> __device__ __forceinline__ T floor_(T v);
@@ -310,6 +311,15 @@ __device__ __forceinline__ uint32_t tile_key3(int i, int j, int k, int ntx, int 
     return tx + __umul24(static_cast<unsigned>(ntx), ty + __umul24(static_cast<unsigned>(nty), tz));
 }
 
+// the tile of a position
+template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+__device__ __forceinline__ uint32_t key_of(T x, T y, T z, int nx, int ny, int nz, int ntx, int nty)
+{
+    int i, j, k, w;
+    axis(x, nx, i, w); axis(y, ny, j, w); axis(z, nz, k, w);
+    return tile_key3<LX, LY, LZ>(i, j, k, ntx, nty);
+}
+
 // Flat form: any particle order, everything through global memory (L2 gathers, 8-byte global
 // atomics).  Used until the particles have been binned.  DEPOSIT_ONLY: no push, the deposit of
 // the CURRENT positions (precalc()).
@@ -338,6 +348,29 @@ __global__ __launch_bounds__(256) void push3_flat_kernel(Push3Args<T> a)
         }
     }
     if constexpr (!DEPOSIT_ONLY) store_state3(a, base, cnt, q);
+}
+
+// The arrivals of a migration (appended behind the sorted array, in no order) inside a re-binning launch: pushed
+// against the global grid, stored in the other particle set at their bin (the tile of the position they arrived
+// with, which the migration added to the census), counted in the census of the new positions.
+template <typename T, bool HAS_B>
+__global__ __launch_bounds__(256) void push3_tail_kernel(Push3Args<T> a, size_t first, size_t count)
+{
+    const size_t r = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const size_t s = first + r;
+    const GlobalGrid<T> grid{ a.E4, a.rho, a.nx, a.ny, a.nz };
+    P3<T> q;
+    q.x = a.slab[s]; q.y = a.slab[a.stride + s]; q.z = a.slab[2 * a.stride + s];
+    q.vx = a.slab[3 * a.stride + s]; q.vy = a.slab[4 * a.stride + s]; q.vz = a.slab[5 * a.stride + s];
+    const uint32_t bin = key_of<T>(q.x, q.y, q.z, a.nx, a.ny, a.nz, a.ntx, a.nty);
+    const size_t d = static_cast<size_t>(a.dst_tile_start[bin]) + atomicAdd(a.dst_tile_cursor + bin, 1u);
+    int ni, nj, nk;
+    substep3<T, HAS_B>(q, a, grid, ni, nj, nk);
+    atomicAdd(a.tile_count + tile_key3<4, 4, 3>(ni, nj, nk, a.ntx, a.nty), 1u);
+    a.dst_slab[d] = q.x; a.dst_slab[a.stride + d] = q.y; a.dst_slab[2 * a.stride + d] = q.z;
+    a.dst_slab[3 * a.stride + d] = q.vx; a.dst_slab[4 * a.stride + d] = q.vy; a.dst_slab[5 * a.stride + d] = q.vz;
+    a.dst_id[d] = a.id[s];
 }
 
 // A workgroup tracks its own tile and the 26 around it (periodic) in LDS when it counts or ranks particles
@@ -440,7 +473,7 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
             load_lane<T, PPT>(a.slab + 2 * a.stride, base, pz);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                if (k >= cnt) continue;
+                if (k >= cnt || px[k] < static_cast<T>(0)) continue; // (x < 0: the slot of a particle that has migrated away)
                 int i, j, kk, wgt;
                 axis(px[k], a.nx, i, wgt); axis(py[k], a.ny, j, wgt); axis(pz[k], a.nz, kk, wgt);
                 uint32_t key;
@@ -477,7 +510,7 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 dest[k] = 0; pid[k] = 0; slot_of[k] = -2;
-                if (k >= cnt) continue;
+                if (k >= cnt || q[k].x < static_cast<T>(0)) continue;
                 pid[k] = a.id[base + k];
                 int i, j, kk, wgt;
                 axis(q[k].x, a.nx, i, wgt); axis(q[k].y, a.ny, j, wgt); axis(q[k].z, a.nz, kk, wgt);
@@ -506,6 +539,7 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             if (k >= cnt) continue;
+            if constexpr (REBIN) { if (slot_of[k] == -2) continue; } // a dead slot
             int ni, nj, nk;
             if constexpr (DEPOSIT_ONLY) {
                 int wx[2], wy[2], wz[2];
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
         if constexpr (REBIN) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                if (k >= cnt) continue;
+                if (k >= cnt || slot_of[k] == -2) continue;
                 const size_t d = dest[k];
                 a.dst_slab[0 * a.stride + d] = q[k].x; a.dst_slab[1 * a.stride + d] = q[k].y; a.dst_slab[2 * a.stride + d] = q[k].z;
                 a.dst_slab[3 * a.stride + d] = q[k].vx; a.dst_slab[4 * a.stride + d] = q[k].vy; a.dst_slab[5 * a.stride + d] = q[k].vz;
@@ -668,14 +702,6 @@ __global__ __launch_bounds__(256) void init3_kernel(T* slab, size_t stride, uint
     id[i] = static_cast<uint32_t>(i);
 }
 
-template <typename T, int LX = 4, int LY = 4, int LZ = 3>
-__device__ __forceinline__ uint32_t key_of(T x, T y, T z, int nx, int ny, int nz, int ntx, int nty)
-{
-    int i, j, k, w;
-    axis(x, nx, i, w); axis(y, ny, j, w); axis(z, nz, k, w);
-    return tile_key3<LX, LY, LZ>(i, j, k, ntx, nty);
-}
-
 constexpr int kBinPer3 = 8;
 
 // the key of the LDS-staged two-level binning (fpic_kernels.hpp); a slot with x < 0 is dead and is not copied
@@ -704,6 +730,28 @@ __global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ s
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < ntiles; t += 256)
         if (hist3[t]) atomicAdd(&tile_count[t], hist3[t]);
+}
+
+// the census of a grid with more tiles than an LDS histogram holds: atomics on the global table, two rounds of
+// wave-level aggregation first (an already sorted input sends one atomic per wave instead of 64 to one address)
+template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+__global__ __launch_bounds__(256) void bin3_count_global_kernel(const T* __restrict__ slab, size_t stride, size_t n, int nx, int ny, int nz, int ntx, int nty,
+                                                                uint32_t* __restrict__ tile_count)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    bool todo = i < n && !(slab[i] < static_cast<T>(0));
+    const uint32_t key = todo ? key_of<T, LX, LY, LZ>(slab[i], slab[stride + i], slab[2 * stride + i], nx, ny, nz, ntx, nty) : 0u;
+    const int lane = static_cast<int>(threadIdx.x & 63);
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long open = __ballot(todo);
+        if (!open) return;
+        const int leader = __ffsll(open) - 1;
+        const uint32_t k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(todo && key == k0);
+        if (lane == leader) atomicAdd(&tile_count[k0], static_cast<uint32_t>(__popcll(same)));
+        if (key == k0) todo = false;
+    }
+    if (todo) atomicAdd(&tile_count[key], 1u);
 }
 
 template <typename T, int LX = 4, int LY = 4, int LZ = 3>
@@ -1282,7 +1330,8 @@ struct MigRecord {
 template <typename T>
 __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, const uint32_t* __restrict__ id, size_t n, int nz, int z0, int nzl,
                                                        int reach, int world, MigRecord<T>* down, MigRecord<T>* up, unsigned cap,
-                                                       unsigned* __restrict__ counts /* down, up, lost, overflow */)
+                                                       unsigned* __restrict__ counts /* down, up, lost, overflow */,
+                                                       uint32_t* __restrict__ census = nullptr, int nx = 0, int ny = 0, int ntx = 0, int nty = 0)
 {
     const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (s >= n) return;
@@ -1305,10 +1354,13 @@ __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, c
     r.pad = 0;
     (go_up ? up : down)[slot] = r;
     slab[s] = static_cast<T>(-1);
+    // the census of the last push counted it in its tile: the next bin table is laid out without it
+    if (census) atomicSub(census + key_of<T>(r.v[0], r.v[1], r.v[2], nx, ny, nz, ntx, nty), 1u);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void mig_append_kernel(const MigRecord<T>* __restrict__ in, unsigned count, T* slab, size_t stride, uint32_t* id, size_t first)
+__global__ __launch_bounds__(256) void mig_append_kernel(const MigRecord<T>* __restrict__ in, unsigned count, T* slab, size_t stride, uint32_t* id, size_t first,
+                                                         uint32_t* __restrict__ census = nullptr, int nx = 0, int ny = 0, int nz = 0, int ntx = 0, int nty = 0)
 {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
@@ -1316,6 +1368,7 @@ __global__ __launch_bounds__(256) void mig_append_kernel(const MigRecord<T>* __r
 #pragma unroll
     for (int f = 0; f < 6; ++f) slab[f * stride + first + r] = m.v[f];
     id[first + r] = m.id;
+    if (census) atomicAdd(census + key_of<T>(m.v[0], m.v[1], m.v[2], nx, ny, nz, ntx, nty), 1u); // ... and with the arrivals
 }
 
 // ghost planes received from a neighbour, added onto this rank's own planes (exact: int64)

@@ -180,6 +180,24 @@ def _as_float_array(a):
     return np.ascontiguousarray(a)
 
 
+class _Buffer:
+    """pointer + shape + element code of an [n][3] array the library reads: a numpy array, or device memory
+    (a tensor with data_ptr(), e.g. torch on the GPU) for the entry points that copy with hipMemcpyDefault"""
+
+    def __init__(self, ptr, shape, code, keep):
+        self.ptr, self.shape, self.code, self.keep = ptr, tuple(shape), code, keep
+
+
+def _device_or_host(a):
+    if hasattr(a, "data_ptr") and hasattr(a, "is_contiguous"):
+        name = str(a.dtype)
+        if not a.is_contiguous() or not (name.endswith("float32") or name.endswith("float64")):
+            raise FusionPicError(-1, ".position <- a device tensor must be contiguous float32 or float64")
+        return _Buffer(a.data_ptr(), a.shape, F32 if name.endswith("float32") else F64, a)
+    h = _as_float_array(a)
+    return _Buffer(h.ctypes.data, h.shape, _code(h), h)
+
+
 class CylindricalParticlePusher:
     """Object returned by makeCylindricalParticlePusher (empic.js:1528)."""
 
@@ -481,13 +499,15 @@ class ElectrostaticBoxPusher:
                 self._check(self._lib.fpic_set_field3(self._h, which, a.ctypes.data, self.nx, self.ny, self.nz, _code(a)))
 
     def setRange(self, first, position=None, velocity=None, species=0):
-        """the caller's particles [first, first + len) of a species (piecewise upload of a large population)"""
-        arrs = [None if a is None else _as_float_array(a) for a in (position, velocity)]
+        """the caller's particles [first, first + len) of a species (piecewise upload of a large population); numpy
+        arrays, or device-resident tensors (anything with data_ptr(): the library copies with hipMemcpyDefault, and
+        the caller has synchronised the stream that produced them)"""
+        arrs = [None if a is None else _device_or_host(a) for a in (position, velocity)]
         m = next(a.shape[0] for a in arrs if a is not None)
-        codes = {_code(a) for a in arrs if a is not None}
+        codes = {a.code for a in arrs if a is not None}
         if len(codes) != 1 or any(a is not None and a.shape != (m, 3) for a in arrs):
             raise FusionPicError(-1, ".position <- position and velocity must be [m][3] of one element type")
-        ptr = lambda a: None if a is None else a.ctypes.data
+        ptr = lambda a: None if a is None else a.ptr
         self._check(self._lib.fpic_set_particles_range(self._h, species, int(first), m, ptr(arrs[0]), ptr(arrs[1]), codes.pop()))
 
     # ---- spatial decomposition (z-slabs; include/fusionpic.h, fpic_domain_*)
@@ -495,10 +515,10 @@ class ElectrostaticBoxPusher:
         self._check(self._lib.fpic_domain_init(self._h, int(rank), int(world), int(ghost_planes), int(migrate_every), 1 if distributed_solve else 0))
 
     def domainSet(self, position, velocity, first_id, species=0):
-        p, v = _as_float_array(position), _as_float_array(velocity)
-        if p.shape != v.shape or p.ndim != 2 or p.shape[1] != 3 or p.dtype != v.dtype:
+        p, v = _device_or_host(position), _device_or_host(velocity)
+        if p.shape != v.shape or len(p.shape) != 2 or p.shape[1] != 3 or p.code != v.code:
             raise FusionPicError(-1, ".position <- position and velocity must be [n][3] of one element type")
-        self._check(self._lib.fpic_domain_set_particles(self._h, species, p.shape[0], p.ctypes.data, v.ctypes.data, int(first_id), _code(p)))
+        self._check(self._lib.fpic_domain_set_particles(self._h, species, p.shape[0], p.ptr, v.ptr, int(first_id), p.code))
 
     def domainGet(self, dtype=None, species=0):
         """{position, velocity, ids} of the particles this rank holds now (no particular order)"""

@@ -281,7 +281,9 @@ int fpic_get_stream(fpic_handle* h, void** hip_stream);
 int fpic_add_species(fpic_handle* h, double mass, double charge, uint64_t count, int* index);
 int fpic_set_particles_of(fpic_handle* h, int species, const void* pos_aos, const void* vel_aos, uint64_t n, int dtype);
 /* the caller's particles [first, first + n) of a species: populations too large for one host array are
- * uploaded piecewise (2e9 particles are 48 GB of AoS floats) */
+ * uploaded piecewise (2e9 particles are 48 GB of AoS floats).  pos_aos / vel_aos here and in
+ * fpic_domain_set_particles may be host OR device memory (copied with hipMemcpyDefault on the handle's stream;
+ * for device memory the caller has synchronised whatever produced it). */
 int fpic_set_particles_range(fpic_handle* h, int species, uint64_t first, uint64_t n, const void* pos_aos, const void* vel_aos, int dtype);
 int fpic_get_particles_of(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype);
 int fpic_get_cells_of(fpic_handle* h, int species, int32_t* cells);

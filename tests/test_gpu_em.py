@@ -191,3 +191,9 @@ def test_em_cycle_with_the_staged_binning(fp, eo, monkeypatch, precision):
     """The LDS-staged two-level first binning (production: >= 2^20 particles) with the 8^3 tiles of the Yee mode."""
     monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
     test_em_cycle_bit_exact_in_given_lattice_fields(fp, eo, precision, (40, 32, 48), 20000)
+
+
+def test_em_cycle_on_a_grid_with_more_tiles_than_an_lds_histogram_holds(fp, eo):
+    """288 x 288 x 280 nodes = 45 360 tiles of 8^3 cells (> 40 960: the census of the binning uses atomics on the
+    global table and the scatter is the staged two-level one at any population size) — the path 512^3 grids take."""
+    test_em_cycle_bit_exact_in_given_lattice_fields(fp, eo, "fp32", (288, 288, 280), 20000)
