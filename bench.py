@@ -297,8 +297,17 @@ def em_line(device, n, grid, steps, warmup, precision="fp64"):
     spec = dict(radius=L, length_y=L, height=L, nr=grid, ny=grid, nz=grid, dt=dt, nparticles=0, count=n, particle_mass=me, particle_charge=qe,
                 geometry="cart3d", solver="yee", macro_weight=n0 * L ** 3 / n, precision=precision)
     sim = fp.makeCylindricalParticlePusher(spec, device=device)
-    for first, pos, vel in es3d_blocks(n, L, vth):
-        sim.setRange(first, position=pos, velocity=vel)
+    if n > 600_000_000:  # (minutes of numpy at this size: generated on the device, slab by slab)
+        chunks = 16
+        assert n % chunks == 0
+        for r in range(chunks):
+            pos, vel = c4_rank_particles(r, chunks, 0, n // chunks, L, vth, 1.0, device)
+            sim.setRange(r * (n // chunks), position=pos, velocity=vel)
+            del pos, vel
+        torch.cuda.empty_cache()
+    else:
+        for first, pos, vel in es3d_blocks(n, L, vth):
+            sim.setRange(first, position=pos, velocity=vel)
     sim.sort(); sim.precalc()
     for _ in range(warmup):
         sim.step()
@@ -310,6 +319,7 @@ def em_line(device, n, grid, steps, warmup, precision="fp64"):
     sim.sync(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
     st = sim.stats()
+    device_bytes = st["bytes_particle_state"] + st["bytes_grid_state"]
     sim.destroy()
     sub = 2 * steps
     esize = 8 if precision == "fp64" else 4
@@ -323,7 +333,7 @@ def em_line(device, n, grid, steps, warmup, precision="fp64"):
             "roofline": {"bound": "hbm", "kernel": "em_push_tiles_kernel<%s>" % ("double" if esize == 8 else "float"), "achieved": algo / (push_ms * 1e-3) / 1e9 if push_ms else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if push_ms else 0.0, "traffic": None,
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": push_ms},
-            "fdtd_algorithmic_bytes": 21 * esize * grid ** 3}
+            "fdtd_algorithmic_bytes": 21 * esize * grid ** 3, "device_bytes": device_bytes}
 
 
 def c4_scene(total, grid, world):
@@ -361,7 +371,7 @@ def c4_rank_particles(rank, world, species, share, L, vth, mass_ratio, device):
     return pos, vel
 
 
-def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_single=False):
+def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_single=False, ghost=4):
     """Extension, parity unpinned: BASELINE configs[3] (two species, grid^3, `total` particles, z-slab decomposition over
     `world` ranks) exercised at full size on ONE GPU: (1) one handle holding everything = the single-GPU strong-scaling
     baseline; (2) the `world` ranks of the decomposition as handles of this process (fpic_group_*: the exchange is
@@ -417,7 +427,7 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     for r in range(world):
         s_ = fp.makeCylindricalParticlePusher(dict(spec, count=cap), device=device, precision=precision)
         s_.addSpecies(mi, qi, cap)
-        s_.domainInit(r, world, ghost_planes=2, migrate_every=4, distributed_solve=True)
+        s_.domainInit(r, world, ghost_planes=ghost, migrate_every=2 * ghost, distributed_solve=True)
         for sp in (0, 1):
             p, v = particles(r, sp)
             s_.domainSet(p, v, first_id=r * share, species=sp)
@@ -443,13 +453,13 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     dom = [s_.domainStats() for s_ in ranks]
     esz = 4 if precision == "fp32" else 8
     plane = grid * grid
-    slowest = max(range(world), key=lambda r: sts[r]["ms_push"] + sts[r]["ms_solve"] + sts[r]["ms_sort"])
     out["decomposed_in_process"] = {
         "ranks": world, "serial_ms_per_substep_all_ranks": 1e3 * el / sub,
-        "slowest_rank_kernel_ms_per_substep": {"push_both_species": sts[slowest]["ms_push"] / sub, "solve_share": sts[slowest]["ms_solve"] / sub,
-                                                "rebinning_and_migration": sts[slowest]["ms_sort"] / sub},
+        "note": "the ranks share one GPU and run one after the other: per-rank kernel times are in the rocprofv3 kernel stats of this command "
+                "(profiles/r02_c4_kernel_stats.csv: totals / ranks), not in this wall-clock figure",
         "particles_migrated_per_substep": (sum(d["migrated"] for d in dom) - mig0[0]) / float(sub), "lost": sum(d["lost"] for d in dom),
-        "exchange_bytes_per_rank_per_substep": {"ghost_planes_int64_reduce": 2 * 2 * plane * 8,
+        "ghost_planes": ghost, "migrate_every": 2 * ghost,
+        "exchange_bytes_per_rank_per_substep": {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
                                                 "fft_transposes": 2 * 2 * (grid // 2 + 1) * grid * (grid // world) * 2 * esz * (world - 1) // world,
                                                 "field_ghost_planes": 2 * 3 * plane * 4 * esz},
     }

@@ -382,7 +382,19 @@ int deposit_cycle(fpic_handle* h)
 {
     State* st = h->es;
     timing_begin(h, DEPOSIT_ONLY ? KC_DEPOSIT : KC_PUSH);
-    HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, st->nodes * sizeof(long long), h->stream));
+    if (st->dom && st->dom->world > 1) {
+        // a rank of a decomposition deposits on its own planes and the ghost planes only (whatever a particle that has
+        // outrun them adds elsewhere is never read): planes [z0 - G, z0 + nzl + G], periodic
+        const Domain& d = *st->dom;
+        const size_t plane = static_cast<size_t>(st->nx) * st->ny; // nodes
+        const int span = std::min(st->nz, d.nzl + 2 * d.G + 1);
+        const int lo = ((d.z0 - d.G) % st->nz + st->nz) % st->nz;
+        const int head = std::min(span, st->nz - lo);
+        HIP_TRY(h, hipMemsetAsync(st->rho_fixed + lo * plane, 0, head * plane * sizeof(long long), h->stream));
+        if (span > head) HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, (span - head) * plane * sizeof(long long), h->stream));
+    } else {
+        HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, st->nodes * sizeof(long long), h->stream));
+    }
     HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
     int rc = FPIC_OK;
     for (Species& s : st->sp)
@@ -1087,7 +1099,7 @@ int migrate(Ranks& rk)
             // the census is corrected for leavers and arrivals and the next push re-bins (and compacts) itself
             const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
             if (s.n)
-                mig_pack_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
+                mig_pack_kernel<T><<<blocks_for(s.n, 256 * kMigPer), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
                                                                           static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]),
                                                                           d.mig_cap, d.counts_dev, riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty);
             HIP_TRY(h, hipGetLastError());

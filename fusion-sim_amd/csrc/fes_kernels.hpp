@@ -1327,35 +1327,63 @@ struct MigRecord {
 // neighbour that owns it (0: the slab below, 1: the slab above) and their slot is marked dead (x = -1);
 // the re-binning that follows drops dead slots.  A particle further than `reach` planes from the slab has
 // outrun the ghost planes (its charge was lost from the exchange): counted in lost.
+constexpr int kMigPer = 16; // particles per lane of the pack: one reservation on the message counters per 4096 particles
 template <typename T>
 __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, const uint32_t* __restrict__ id, size_t n, int nz, int z0, int nzl,
                                                        int reach, int world, MigRecord<T>* down, MigRecord<T>* up, unsigned cap,
                                                        unsigned* __restrict__ counts /* down, up, lost, overflow */,
                                                        uint32_t* __restrict__ census = nullptr, int nx = 0, int ny = 0, int ntx = 0, int nty = 0)
 {
-    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const T x = slab[s];
-    if (x < static_cast<T>(0)) return;
-    int k, w;
-    axis(slab[2 * stride + s], nz, k, w);
-    int d = k - z0;                     // planes above the slab's first, periodic
-    if (d < 0) d += nz;
-    if (d < nzl) return;                // still at home
-    const int above = d - nzl, below = nz - d - 1; // cells beyond the upper / lower face
-    const bool go_up = world == 2 ? true : above <= below;
-    if ((above <= below ? above : below) >= reach) atomicAdd(counts + 2, 1u);
-    const unsigned slot = atomicAdd(counts + (go_up ? 1 : 0), 1u);
-    if (slot >= cap) { atomicAdd(counts + 3, 1u); return; } // stays (and is reported): no room in the message
-    MigRecord<T> r;
+    // (the leavers of a sorted array sit in the tiles along the two faces: counted in LDS first, so that the two
+    // message counters see one atomic per workgroup and direction instead of one per particle)
+    __shared__ unsigned l_cnt[2], l_base[2], l_lost;
+    if (threadIdx.x < 2) l_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 2) l_lost = 0;
+    __syncthreads();
+    const size_t first = static_cast<size_t>(blockIdx.x) * (256 * kMigPer);
+    uint32_t flags = 0; // two bits per particle of this lane: 1 = down, 2 = up
 #pragma unroll
-    for (int f = 0; f < 6; ++f) r.v[f] = slab[f * stride + s];
-    r.id = id[s];
-    r.pad = 0;
-    (go_up ? up : down)[slot] = r;
-    slab[s] = static_cast<T>(-1);
-    // the census of the last push counted it in its tile: the next bin table is laid out without it
-    if (census) atomicSub(census + key_of<T>(r.v[0], r.v[1], r.v[2], nx, ny, nz, ntx, nty), 1u);
+    for (int k = 0; k < kMigPer; ++k) {
+        const size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+        if (s >= n) continue;
+        if (slab[s] < static_cast<T>(0)) continue;
+        int kz, w;
+        axis(slab[2 * stride + s], nz, kz, w);
+        int d = kz - z0;                    // planes above the slab's first, periodic
+        if (d < 0) d += nz;
+        if (d < nzl) continue;              // still at home
+        const int above = d - nzl, below = nz - d - 1; // cells beyond the upper / lower face
+        const bool go_up = world == 2 ? true : above <= below;
+        if ((above <= below ? above : below) >= reach) atomicAdd(&l_lost, 1u);
+        atomicAdd(&l_cnt[go_up ? 1 : 0], 1u);
+        flags |= (go_up ? 2u : 1u) << (2 * k);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned c = l_cnt[threadIdx.x];
+        l_base[threadIdx.x] = c ? atomicAdd(counts + threadIdx.x, c) : 0u;
+        l_cnt[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 2 && l_lost) atomicAdd(counts + 2, l_lost);
+    __syncthreads();
+    if (!flags) return;
+#pragma unroll
+    for (int k = 0; k < kMigPer; ++k) {
+        const unsigned dir = (flags >> (2 * k)) & 3u;
+        if (!dir) continue;
+        const size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+        const unsigned slot = l_base[dir - 1] + atomicAdd(&l_cnt[dir - 1], 1u);
+        if (slot >= cap) { atomicAdd(counts + 3, 1u); continue; } // stays (and is reported): no room in the message
+        MigRecord<T> r;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) r.v[f] = slab[f * stride + s];
+        r.id = id[s];
+        r.pad = 0;
+        (dir == 2 ? up : down)[slot] = r;
+        slab[s] = static_cast<T>(-1);
+        // the census of the last push counted it in its tile: the next bin table is laid out without it
+        if (census) atomicSub(census + key_of<T>(r.v[0], r.v[1], r.v[2], nx, ny, nz, ntx, nty), 1u);
+    }
 }
 
 template <typename T>
