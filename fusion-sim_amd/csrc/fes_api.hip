@@ -90,6 +90,10 @@ struct Domain {
     void* mig_send[2] = {};             // [0]: to the slab below, [1]: to the slab above
     void* mig_recv[2] = {};             // [0]: from above, [1]: from below
     unsigned mig_cap = 0;               // records per buffer
+    // full EM: halo planes of the lattice fields / ghost planes of the current on each side (G + 2), and where the
+    // neighbours' current ghost planes arrive (3 int64 per node)
+    int H = 0;
+    long long* j_recv[2] = {};
     unsigned* counts_dev = nullptr;     // down, up, lost, overflow | received from above, from below
     unsigned* counts_host = nullptr;    // pinned copy
     uint64_t migrated = 0, lost = 0;
@@ -441,11 +445,87 @@ int substep(fpic_handle* h)
 
 // ---- full EM (solver = YEE): em_nodes, em_push + em_current, B half, E, B half (oracle: em_substep)
 template <typename T>
-int em_nodes(fpic_handle* h)
+int em_nodes(fpic_handle* h, int k0 = 0, int nk = -1)
 {
     State* st = h->es;
-    em_nodes_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->Ey), static_cast<const T*>(st->By), st->nx, st->ny, st->nz,
-                                                                   static_cast<T*>(st->E4), static_cast<T*>(st->B4n));
+    if (nk < 0 || nk > st->nz) nk = st->nz;
+    k0 = (k0 % st->nz + st->nz) % st->nz;
+    em_nodes_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<const T*>(st->Ey), static_cast<const T*>(st->By), st->nx,
+                                                                                                  st->ny, st->nz, static_cast<T*>(st->E4), static_cast<T*>(st->B4n), k0, nk);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+// the currents of one sub-step: gather + Boris + move + integer current deposit of every species (Jfix zeroed by the caller)
+template <typename T>
+int em_push_all(fpic_handle* h)
+{
+    State* st = h->es;
+    const double dt = h->spec.dt;
+    for (Species& s : st->sp) {
+        if (!s.n) continue;
+        EmPushArgs<T> a{};
+        a.slab = static_cast<T*>(s.slab[s.cur]); a.stride = s.n_pad; a.n = s.n;
+        a.E4n = static_cast<const T*>(st->E4); a.B4n = static_cast<const T*>(st->B4n);
+        a.Jfix = reinterpret_cast<unsigned long long*>(st->Jfix);
+        a.nx = st->nx; a.ny = st->ny; a.nz = st->nz;
+        const double hh = s.charge * dt / (2 * s.mass), step = dt * kSpeedOfLight;
+        a.h = static_cast<T>(hh);
+        a.hc = static_cast<T>(hh) / static_cast<T>(kSpeedOfLight); // in T, as the oracle forms it
+        a.dx = static_cast<T>(step / st->lx); a.dy = static_cast<T>(step / st->ly); a.dz = static_cast<T>(step / st->lz);
+        a.Z = s.Z;
+        if (s.binned) {
+            EmTileArgs<T> t{};
+            t.p = a;
+            t.ntx = st->ntx; t.nty = st->nty; t.ntz = st->ntz;
+            t.work = s.work2[s.wl]; t.nwork = s.nwork2[s.wl];
+            t.spilled = st->spilled;
+            em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmThreads, em_lds_bytes<T>(), h->stream>>>(t);
+        } else {
+            em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
+        }
+        HIP_TRY(h, hipGetLastError());
+    }
+    return FPIC_OK;
+}
+
+// the lattice update, piecewise: planes [k0, k0 + nk) (periodic) of B (half a step) or E (a step)
+template <typename T>
+struct EmCoef {
+    T cb[3], ce[3], je;
+    double js[3];
+    EmCoef(const fpic_handle* h)
+    {
+        const State* st = h->es;
+        const double dt = h->spec.dt;
+        const double d[3] = { st->lx / st->nx, st->ly / st->ny, st->lz / st->nz };
+        const double c2 = kSpeedOfLight * kSpeedOfLight;
+        const double base = h->spec.particle_charge * st->W / (96.0 * 4398046511104.0 * dt);
+        for (int a = 0; a < 3; ++a) { cb[a] = static_cast<T>(dt / (2 * d[a])); ce[a] = static_cast<T>(c2 * dt / d[a]); }
+        je = static_cast<T>(dt / kEps0);
+        js[0] = base / (d[1] * d[2]); js[1] = base / (d[0] * d[2]); js[2] = base / (d[0] * d[1]);
+    }
+};
+
+template <typename T>
+int em_half_b(fpic_handle* h, const EmCoef<T>& c, int k0, int nk)
+{
+    State* st = h->es;
+    k0 = (k0 % st->nz + st->nz) % st->nz;
+    em_update_b_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->By), static_cast<const T*>(st->Ey), st->nx, st->ny,
+                                                                                                     st->nz, c.cb[0], c.cb[1], c.cb[2], k0, nk);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int em_full_e(fpic_handle* h, const EmCoef<T>& c, int k0, int nk)
+{
+    State* st = h->es;
+    k0 = (k0 % st->nz + st->nz) % st->nz;
+    em_update_e_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(st->By), st->Jfix, st->nx,
+                                                                                                     st->ny, st->nz, c.ce[0], c.ce[1], c.ce[2], c.je, c.js[0], c.js[1],
+                                                                                                     c.js[2], k0, nk);
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -485,34 +565,9 @@ int em_substep(fpic_handle* h)
         if (int rc = bin_all<T>(h, true)) return rc;
     HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
     if (int rc = em_nodes<T>(h)) return rc;
-    const double dt = h->spec.dt;
-    const double d[3] = { st->lx / st->nx, st->ly / st->ny, st->lz / st->nz };
     timing_begin(h, KC_PUSH);
     HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, st->nodes * 3 * sizeof(long long), h->stream));
-    for (Species& s : st->sp) {
-        if (!s.n) continue;
-        EmPushArgs<T> a{};
-        a.slab = static_cast<T*>(s.slab[s.cur]); a.stride = s.n_pad; a.n = s.n;
-        a.E4n = static_cast<const T*>(st->E4); a.B4n = static_cast<const T*>(st->B4n);
-        a.Jfix = reinterpret_cast<unsigned long long*>(st->Jfix);
-        a.nx = st->nx; a.ny = st->ny; a.nz = st->nz;
-        const double hh = s.charge * dt / (2 * s.mass), step = dt * kSpeedOfLight;
-        a.h = static_cast<T>(hh);
-        a.hc = static_cast<T>(hh) / static_cast<T>(kSpeedOfLight); // in T, as the oracle forms it
-        a.dx = static_cast<T>(step / st->lx); a.dy = static_cast<T>(step / st->ly); a.dz = static_cast<T>(step / st->lz);
-        a.Z = s.Z;
-        if (s.binned) {
-            EmTileArgs<T> t{};
-            t.p = a;
-            t.ntx = st->ntx; t.nty = st->nty; t.ntz = st->ntz;
-            t.work = s.work2[s.wl]; t.nwork = s.nwork2[s.wl];
-            t.spilled = st->spilled;
-            em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmThreads, em_lds_bytes<T>(), h->stream>>>(t);
-        } else {
-            em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
-        }
-        HIP_TRY(h, hipGetLastError());
-    }
+    if (int rc = em_push_all<T>(h)) return rc;
     timing_end(h);
     {
         const int slot = static_cast<int>(st->spill_seq++ & 1);
@@ -521,16 +576,10 @@ int em_substep(fpic_handle* h)
         st->spill_pending[slot] = true;
     }
     timing_begin(h, KC_SOLVE);
-    const T cb[3] = { static_cast<T>(dt / (2 * d[0])), static_cast<T>(dt / (2 * d[1])), static_cast<T>(dt / (2 * d[2])) };
-    const double c2 = kSpeedOfLight * kSpeedOfLight;
-    const T ce[3] = { static_cast<T>(c2 * dt / d[0]), static_cast<T>(c2 * dt / d[1]), static_cast<T>(c2 * dt / d[2]) };
-    const double base = h->spec.particle_charge * st->W / (96.0 * 4398046511104.0 * dt);
-    em_update_b_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), static_cast<const T*>(st->Ey), st->nx, st->ny, st->nz, cb[0], cb[1], cb[2]);
-    em_update_e_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(st->By), st->Jfix, st->nx, st->ny, st->nz, ce[0],
-                                                                      ce[1], ce[2], static_cast<T>(dt / kEps0), base / (d[1] * d[2]), base / (d[0] * d[2]),
-                                                                      base / (d[0] * d[1]));
-    em_update_b_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), static_cast<const T*>(st->Ey), st->nx, st->ny, st->nz, cb[0], cb[1], cb[2]);
-    HIP_TRY(h, hipGetLastError());
+    const EmCoef<T> co(h);
+    if (int rc = em_half_b<T>(h, co, 0, st->nz)) return rc;
+    if (int rc = em_full_e<T>(h, co, 0, st->nz)) return rc;
+    if (int rc = em_half_b<T>(h, co, 0, st->nz)) return rc;
     timing_end(h);
     st->substeps_since_bin++;
     h->step_launches++;
@@ -803,7 +852,7 @@ void release(fpic_handle* h)
     for (Species& s : st->sp) free_species(s);
     if (Domain* d = st->dom) {
         for (void* p : { static_cast<void*>(d->ghost_recv[0]), static_cast<void*>(d->ghost_recv[1]), d->mig_send[0], d->mig_send[1], d->mig_recv[0],
-                         d->mig_recv[1], static_cast<void*>(d->counts_dev) })
+                         d->mig_recv[1], static_cast<void*>(d->counts_dev), static_cast<void*>(d->j_recv[0]), static_cast<void*>(d->j_recv[1]) })
             if (p) (void)hipFree(p);
         if (d->counts_host) (void)hipHostFree(d->counts_host);
         for (void* p : { d->hatA, d->hatB, d->xbuf, d->fft_work[0], d->fft_work[1], d->fft_work[2], d->fft_work[3] })
@@ -976,7 +1025,7 @@ struct Xfer {
     size_t recv_bytes;
     int tag;                // a message meets the receive of its destination that names the sender and carries the same tag
 };
-enum Exchange { X_GHOST = 0, X_MIG_COUNTS, X_MIG_PAYLOAD, X_TRANSPOSE, X_TRANSPOSE_BACK, X_PHI };
+enum Exchange { X_GHOST = 0, X_MIG_COUNTS, X_MIG_PAYLOAD, X_TRANSPOSE, X_TRANSPOSE_BACK, X_PHI, X_EM_J, X_EM_E, X_EM_B };
 
 // The messages of one exchange, in an order every rank shares: [0] goes to the slab below and is met there by
 // what arrives from above, [1] goes up and is met by what arrives from below.  (RCCL matches the sends and
@@ -1006,6 +1055,20 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
         const char* src = static_cast<const char*>(which == X_TRANSPOSE ? d.xbuf : d.hatB);
         char* dst = static_cast<char*>(which == X_TRANSPOSE ? d.hatB : d.xbuf);
         for (int q = 0; q < d.world; ++q) out.push_back({ q, q, src + q * chunk, chunk, dst + q * chunk, chunk, 0 });
+    } else if (which == X_EM_J) {
+        // the current a rank's particles left on its H ghost planes below / above goes to the slab that owns them
+        const int lo = (d.z0 - d.H + st->nz) % st->nz, hi = (d.z0 + d.nzl) % st->nz;
+        const size_t bytes = static_cast<size_t>(d.H) * plane * 3 * sizeof(long long);
+        out.push_back({ down, up, st->Jfix + 3 * lo * plane, bytes, d.j_recv[0], bytes, 0 });
+        out.push_back({ up, down, st->Jfix + 3 * hi * plane, bytes, d.j_recv[1], bytes, 1 });
+    } else if (which == X_EM_E || which == X_EM_B) {
+        // halo copy of a lattice field: my first H planes are the lower neighbour's upper halo, my last H planes the
+        // upper neighbour's lower halo; what arrives lands in my halo planes in place
+        T* f = static_cast<T*>(which == X_EM_E ? st->Ey : st->By);
+        const size_t bytes = static_cast<size_t>(d.H) * plane * 4 * sizeof(T);
+        const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.H + st->nz) % st->nz;
+        out.push_back({ down, up, f + 4 * d.z0 * plane, bytes, f + 4 * above * plane, bytes, 0 });
+        out.push_back({ up, down, f + 4 * (d.z0 + d.nzl - d.H) * plane, bytes, f + 4 * below * plane, bytes, 1 });
     } else { // X_PHI: the potential on the planes the gradient of my slab and its ghost planes needs
         T* phi = static_cast<T*>(st->phi);
         const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.G - 1 + st->nz) % st->nz;
@@ -1266,6 +1329,9 @@ int dom_fields(Ranks& rk)
 }
 
 template <typename T>
+int dom_em_after_precalc(Ranks& rk);
+
+template <typename T>
 int dom_precalc(Ranks& rk)
 {
     for (fpic_handle* h : rk.hs) {
@@ -1273,13 +1339,109 @@ int dom_precalc(Ranks& rk)
         h->deposit_launches++;
     }
     if (int e = dom_fields<T>(rk)) return e;
+    if (rk.hs[0]->es->solver == FPIC_SOLVER_YEE)
+        if (int e = dom_em_after_precalc<T>(rk)) return e;
     for (fpic_handle* h : rk.hs) h->es->fields_ready = true;
+    return FPIC_OK;
+}
+
+// ---- the full-EM cycle of a decomposition.  Every rank keeps the lattice fields of its slab and of H = G + 2 halo
+// planes on each side current: after the E update and after the second B half step the boundary planes are copied to
+// the neighbours (X_EM_E, X_EM_B); the current of a sub-step is completed on the owned planes by adding what the
+// neighbours' particles left on their ghost planes (X_EM_J, exact: int64).  Plane for plane the arithmetic is the one
+// handle's, so the fields, the currents and the particles are bit-identical to an undecomposed run.
+template <typename T>
+int dom_em_after_precalc(Ranks& rk)
+{
+    for (fpic_handle* h : rk.hs) {
+        State* st = h->es;
+        fill4_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), st->nodes, static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
+                                                                    static_cast<T>(st->B0[2]));
+        HIP_TRY(h, hipGetLastError());
+        if (int e = em_nodes<T>(h)) return e; // (every rank has solved the whole grid: its E is valid everywhere)
+    }
+    return FPIC_OK;
+}
+
+template <typename T>
+int dom_em_substep(Ranks& rk)
+{
+    State* s0 = rk.hs[0]->es;
+    const bool multi = s0->dom->world > 1;
+    bool unbinned = false;
+    for (fpic_handle* h : rk.hs)
+        for (const Species& s : h->es->sp) unbinned |= !s.binned;
+    if (multi) {
+        if (unbinned || s0->dom->substeps_since_migration >= s0->dom->migrate_every)
+            if (int e = migrate<T>(rk)) return e;
+    } else if (unbinned || s0->substeps_since_bin >= 64) {
+        for (fpic_handle* h : rk.hs)
+            if (int e = bin_all<T>(h, true)) return e;
+    }
+    for (fpic_handle* h : rk.hs) {
+        State* st = h->es;
+        const Domain& d = *st->dom;
+        const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+        HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
+        // node-centred fields where this rank's particles can be: cells [z0 - G, z0 + nzl + G) -> nodes one further up
+        if (int e = multi ? em_nodes<T>(h, d.z0 - d.G - 1, std::min(st->nz, d.nzl + 2 * d.G + 3)) : em_nodes<T>(h)) return e;
+        timing_begin(h, KC_PUSH);
+        if (multi) { // the planes the slab's particles can deposit on
+            const int span = std::min(st->nz, d.nzl + 2 * d.H), lo = ((d.z0 - d.H) % st->nz + st->nz) % st->nz, head = std::min(span, st->nz - lo);
+            HIP_TRY(h, hipMemsetAsync(st->Jfix + 3 * lo * plane, 0, 3 * head * plane * sizeof(long long), h->stream));
+            if (span > head) HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, 3 * (span - head) * plane * sizeof(long long), h->stream));
+        } else {
+            HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, st->nodes * 3 * sizeof(long long), h->stream));
+        }
+        if (int e = em_push_all<T>(h)) return e;
+        timing_end(h);
+    }
+    if (multi)
+        if (int e = exchange<T>(rk, X_EM_J)) return e;
+    for (fpic_handle* h : rk.hs) {
+        State* st = h->es;
+        const Domain& d = *st->dom;
+        const size_t plane = static_cast<size_t>(st->nx) * st->ny, count = 3 * d.H * plane;
+        timing_begin(h, KC_SOLVE);
+        const EmCoef<T> co(h);
+        if (multi) {
+            // from above: the upper neighbour's lower ghost planes = my last H planes; from below: my first H planes
+            ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * (d.z0 + d.nzl - d.H) * plane, d.j_recv[0], count);
+            ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * d.z0 * plane, d.j_recv[1], count);
+            HIP_TRY(h, hipGetLastError());
+            // B half a step on the slab and on the plane below it (the E update of the first owned plane reads it)
+            if (int e = em_half_b<T>(h, co, d.z0 - 1, d.nzl + 1)) return e;
+            if (int e = em_full_e<T>(h, co, d.z0, d.nzl)) return e;
+        } else {
+            if (int e = em_half_b<T>(h, co, 0, st->nz)) return e;
+            if (int e = em_full_e<T>(h, co, 0, st->nz)) return e;
+        }
+        timing_end(h);
+    }
+    if (multi)
+        if (int e = exchange<T>(rk, X_EM_E)) return e;
+    for (fpic_handle* h : rk.hs) {
+        State* st = h->es;
+        const Domain& d = *st->dom;
+        timing_begin(h, KC_SOLVE);
+        const EmCoef<T> co(h);
+        if (int e = multi ? em_half_b<T>(h, co, d.z0, d.nzl) : em_half_b<T>(h, co, 0, st->nz)) return e;
+        timing_end(h);
+        st->substeps_since_bin++;
+        st->dom->substeps_since_migration++;
+        h->step_launches++;
+        h->solve_launches++;
+        h->particle_updates += total_particles(st);
+    }
+    if (multi)
+        if (int e = exchange<T>(rk, X_EM_B)) return e;
     return FPIC_OK;
 }
 
 template <typename T>
 int dom_substep(Ranks& rk)
 {
+    if (rk.hs[0]->es->solver == FPIC_SOLVER_YEE) return dom_em_substep<T>(rk);
     State* s0 = rk.hs[0]->es;
     bool unbinned = false;
     for (fpic_handle* h : rk.hs)
@@ -1342,7 +1504,7 @@ int precalc(fpic_handle* h)
 int density(fpic_handle* h)
 {
     if (h->es->solver != FPIC_SOLVER_YEE) return FPIC_OK; // the electrostatic cycle deposits the charge every sub-step
-    if (h->es->dom) return fail(h, FPIC_ERR_STATE, "the full-EM mode is not decomposed yet");
+    if (h->es->dom) return fail(h, FPIC_ERR_STATE, "density() is not available on a rank of a decomposed full-EM run (the cycle deposits currents: read FPIC_F3_J_FIXED)");
     const int rc = h->prec == FPIC_F32 ? deposit_cycle<float, true>(h) : deposit_cycle<double, true>(h);
     if (rc == FPIC_OK) h->deposit_launches++;
     return rc;
@@ -1385,12 +1547,14 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
 {
     State* st = h->es;
     if (st->dom) return fail(h, FPIC_ERR_STATE, "the handle is already decomposed");
-    if (st->solver == FPIC_SOLVER_YEE) return fail(h, FPIC_ERR_STATE, "the full-EM mode is not decomposed yet");
     if (world < 1 || rank < 0 || rank >= world) return fail(h, FPIC_ERR_INVALID_ARG, ".rank <- %d is outside a world of %d", rank, world);
     if (st->nz % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d planes along z do not divide into %d slabs", st->nz, world);
     const int nzl = st->nz / world;
     if (ghost_planes < 1 || ghost_planes >= nzl) return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- must lie in [1, %d)", nzl);
     if (migrate_every < 1) return fail(h, FPIC_ERR_INVALID_ARG, ".migrate_every <- must be at least 1");
+    if (st->solver == FPIC_SOLVER_YEE && world > 1 && 2 * (ghost_planes + 2) > nzl)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- the full-EM mode keeps ghost_planes + 2 halo planes per side: a slab of %d planes holds at most %d ghost planes",
+                    nzl, nzl / 2 - 2);
     Domain* d = new (std::nothrow) Domain();
     if (!d) return fail(h, FPIC_ERR_OOM, "host allocation failed");
     st->dom = d;
@@ -1408,6 +1572,11 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
         return rc;
     for (int k = 0; k < 2; ++k)
         if ((rc = dev_alloc(h, &d->mig_send[k], d->mig_cap * rec, acc)) || (rc = dev_alloc(h, &d->mig_recv[k], d->mig_cap * rec, acc))) return rc;
+    if (st->solver == FPIC_SOLVER_YEE) {
+        d->H = ghost_planes + 2;
+        for (int k = 0; k < 2; ++k)
+            if ((rc = dev_alloc(h, reinterpret_cast<void**>(&d->j_recv[k]), static_cast<size_t>(d->H) * plane * 3 * sizeof(long long), acc))) return rc;
+    }
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&d->counts_host), 8 * sizeof(unsigned)));
     std::memset(d->counts_host, 0, 8 * sizeof(unsigned));
     for (Species& s : st->sp) s.n = 0; // the rank's particles arrive through domain_set_particles

@@ -803,12 +803,14 @@ __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(256) void em_nodes_kernel(const T* __restrict__ Ey, const T* __restrict__ By, int nx, int ny, int nz, T* __restrict__ E4n,
-                                                       T* __restrict__ B4n)
+                                                       T* __restrict__ B4n, int k0, int nk)
 {
-    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // planes k0 .. k0 + nk - 1 (periodic): the whole grid for one handle, the slab and its ghost planes for a rank
+    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (c >= sz * nz) return;
-    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
+    if (t >= sz * nk) return;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), k = (k0 + static_cast<int>(t / sz)) % nz;
+    const size_t c = i + sy * j + sz * k;
     const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
     E4n[4 * c] = static_cast<T>(0.5) * (FES_AT(Ey, im, j, k, 0) + FES_AT(Ey, i, j, k, 0));
     E4n[4 * c + 1] = static_cast<T>(0.5) * (FES_AT(Ey, i, jm, k, 1) + FES_AT(Ey, i, j, k, 1));
@@ -822,12 +824,14 @@ __global__ __launch_bounds__(256) void em_nodes_kernel(const T* __restrict__ Ey,
 
 // B -= cb * curl E (em_update_b)
 template <typename T>
-__global__ __launch_bounds__(256) void em_update_b_kernel(T* __restrict__ By, const T* __restrict__ Ey, int nx, int ny, int nz, T cbx, T cby, T cbz)
+__global__ __launch_bounds__(256) void em_update_b_kernel(T* __restrict__ By, const T* __restrict__ Ey, int nx, int ny, int nz, T cbx, T cby, T cbz, int k0,
+                                                          int nk)
 {
-    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (c >= sz * nz) return;
-    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
+    if (t >= sz * nk) return;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), k = (k0 + static_cast<int>(t / sz)) % nz;
+    const size_t c = i + sy * j + sz * k;
     const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1, kp = (k + 1 == nz) ? 0 : k + 1;
     const T cx = (FES_AT(Ey, i, jp, k, 2) - FES_AT(Ey, i, j, k, 2)) * cby - (FES_AT(Ey, i, j, kp, 1) - FES_AT(Ey, i, j, k, 1)) * cbz;
     const T cy = (FES_AT(Ey, i, j, kp, 0) - FES_AT(Ey, i, j, k, 0)) * cbz - (FES_AT(Ey, ip, j, k, 2) - FES_AT(Ey, i, j, k, 2)) * cbx;
@@ -840,12 +844,13 @@ __global__ __launch_bounds__(256) void em_update_b_kernel(T* __restrict__ By, co
 // E += ce * curl B - je * J, with J = T((double)Jfix * scale) formed on the fly (em_j_real + em_update_e)
 template <typename T>
 __global__ __launch_bounds__(256) void em_update_e_kernel(T* __restrict__ Ey, const T* __restrict__ By, const long long* __restrict__ Jfix, int nx, int ny,
-                                                          int nz, T cex, T cey, T cez, T je, double jsx, double jsy, double jsz)
+                                                          int nz, T cex, T cey, T cez, T je, double jsx, double jsy, double jsz, int k0, int nk)
 {
-    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (c >= sz * nz) return;
-    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
+    if (t >= sz * nk) return;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), k = (k0 + static_cast<int>(t / sz)) % nz;
+    const size_t c = i + sy * j + sz * k;
     const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
     const T cx = (FES_AT(By, i, j, k, 2) - FES_AT(By, i, jm, k, 2)) * cey - (FES_AT(By, i, j, k, 1) - FES_AT(By, i, j, km, 1)) * cez;
     const T cy = (FES_AT(By, i, j, k, 0) - FES_AT(By, i, j, km, 0)) * cez - (FES_AT(By, i, j, k, 2) - FES_AT(By, im, j, k, 2)) * cex;

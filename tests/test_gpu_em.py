@@ -197,3 +197,123 @@ def test_em_cycle_on_a_grid_with_more_tiles_than_an_lds_histogram_holds(fp, eo):
     """288 x 288 x 280 nodes = 45 360 tiles of 8^3 cells (> 40 960: the census of the binning uses atomics on the
     global table and the scatter is the staged two-level one at any population size) — the path 512^3 grids take."""
     test_em_cycle_bit_exact_in_given_lattice_fields(fp, eo, "fp32", (288, 288, 280), 20000)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape,ghost", [(2, (16, 12, 16), 2), (4, (24, 16, 32), 2), (4, (20, 20, 48), 4)])
+def test_slab_decomposed_em_reproduces_one_gpu_bit_for_bit(fp, eo, precision, world, shape, ghost):
+    """SURVEY 8(e) row 2 for the full-EM cycle (BASELINE configs[4] is its 8-GPU form): `world` ranks stepped as an
+    in-process group — halo copies of the edge E and the face B (ghost + 2 planes per side), ghost-plane reduce of the
+    int64 current, migration.  Against ONE handle holding everything, after every frame: the current grid, both lattice
+    fields (on each rank's own planes) and every particle (matched by its global index) are bit-identical."""
+    dtype = np.float32 if precision == "fp32" else np.float64
+    rng = np.random.default_rng(world * 100 + ghost)
+    n, ni = 24000, 6000
+    L = tuple(1e-3 * s for s in shape)
+    spec = em_spec(shape, L, n, cfl_dt(shape, L), macro_weight=1e6)
+    nzl = shape[2] // world
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.3, (n, 3))          # fast: a cell every two or three sub-steps
+    pi, vi = rng.random((ni, 3)) * L, rng.normal(0, 0.05, (ni, 3))
+    sets = []
+    for p, v in ((pos, vel), (pi, vi)):                                      # global indices contiguous per rank
+        owner = np.floor(p[:, 2] / L[2] * shape[2]).astype(int) // nzl
+        order = np.argsort(owner, kind="stable")
+        sets.append((p[order], v[order], np.bincount(owner, minlength=world)))
+    E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
+
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.addSpecies(1836 * ME, -2 * QE, ni)
+    for sp, (p, v, _) in enumerate(sets):
+        one.set(position=p, velocity=v, species=sp)
+    one.set(edge_E=E, face_B=B)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(spec, precision=precision)     # capacity: everything could end up here
+        s.addSpecies(1836 * ME, -2 * QE, ni)
+        s.domainInit(r, world, ghost_planes=ghost, migrate_every=2)
+        for sp, (p, v, counts) in enumerate(sets):
+            first = int(counts[:r].sum())
+            s.domainSet(p[first:first + counts[r]], v[first:first + counts[r]], first_id=first, species=sp)
+        s.set(edge_E=E, face_B=B)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+
+    def compare(tag):
+        for which in (fp.F3_EDGE_E, fp.F3_FACE_B):
+            ref = one.readField(which).reshape(shape[2], -1)
+            for r, s in enumerate(ranks):
+                got = s.readField(which).reshape(shape[2], -1)
+                assert same_bits(got[r * nzl:(r + 1) * nzl], ref[r * nzl:(r + 1) * nzl]), (tag, which, r)
+        for sp, total in ((0, n), (1, ni)):
+            parts = [s.domainGet(species=sp) for s in ranks]
+            ids = np.concatenate([p["ids"] for p in parts])
+            assert len(ids) == total and np.array_equal(np.sort(ids), np.arange(total)), (tag, sp)
+            ref = one.getParticles(species=sp)
+            assert same_bits(np.concatenate([p["position"] for p in parts])[np.argsort(ids)], ref["position"]), (tag, sp)
+            assert same_bits(np.concatenate([p["velocity"] for p in parts])[np.argsort(ids)], ref["velocity"]), (tag, sp)
+
+    compare("upload")
+    for frame in range(4):
+        one.step(); group.step()
+        jref = one.readField(fp.F3_J_FIXED).reshape(shape[2], -1)
+        for r, s in enumerate(ranks):
+            got = s.readField(fp.F3_J_FIXED).reshape(shape[2], -1)
+            assert np.array_equal(got[r * nzl:(r + 1) * nzl], jref[r * nzl:(r + 1) * nzl]), (frame, r)
+        compare("frame %d" % frame)
+    stats = [s.domainStats() for s in ranks]
+    assert sum(s["migrated"] for s in stats) > 0 and all(s["lost"] == 0 for s in stats)
+    for s in ranks + [one]:
+        s.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_slab_decomposed_em_from_precalc(fp, eo, precision):
+    """precalc() of a decomposed full-EM run: ghost-plane reduce of the charge, every rank solves the gathered grid, the
+    Poisson field on the edges + the external B; then 6 frames: lattice fields on the own planes and all particles
+    bit-identical to one handle's, Gauss's law still at rounding level on the assembled field."""
+    rng = np.random.default_rng(17)
+    world, shape, L = 2, (12, 12, 16), (0.012, 0.012, 0.016)
+    n = 12 * 12 * 16 * 8
+    dt = cfl_dt(shape, L, 0.5)
+    dens = (0.02 / dt) ** 2 * eo.EPS0 * ME / QE ** 2
+    spec = em_spec(shape, L, n, dt, macro_weight=dens * np.prod(L) / n)
+    nzl = shape[2] // world
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.05, (n, 3))
+    owner = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
+    order = np.argsort(owner, kind="stable")
+    pos, vel, counts = pos[order], vel[order], np.bincount(owner, minlength=world)
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.set(position=pos, velocity=vel)
+    one.addB(0.0, 0.0, 0.01)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(spec, precision=precision)
+        s.domainInit(r, world, ghost_planes=2, migrate_every=8)
+        first = int(counts[:r].sum())
+        s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
+        s.addB(0.0, 0.0, 0.01)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+
+    def assembled(which):
+        out = np.empty_like(one.readField(which)).reshape(shape[2], -1)
+        for r, s in enumerate(ranks):
+            out[r * nzl:(r + 1) * nzl] = s.readField(which).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl]
+        return out
+
+    for frame in range(7):
+        for which in (fp.F3_EDGE_E, fp.F3_FACE_B):
+            assert same_bits(assembled(which), one.readField(which).reshape(shape[2], -1)), (frame, which)
+        parts = [s.domainGet() for s in ranks]
+        ids = np.concatenate([p["ids"] for p in parts])
+        ref = one.getParticles()
+        assert np.array_equal(np.sort(ids), np.arange(n))
+        assert same_bits(np.concatenate([p["position"] for p in parts])[np.argsort(ids)], ref["position"]), frame
+        assert same_bits(np.concatenate([p["velocity"] for p in parts])[np.argsort(ids)], ref["velocity"]), frame
+        if frame < 6:
+            one.step(); group.step()
+    with pytest.raises(fp.FusionPicError):
+        ranks[0].density()
+    for s in ranks + [one]:
+        s.destroy()
