@@ -371,7 +371,7 @@ def c4_rank_particles(rank, world, species, share, L, vth, mass_ratio, device):
     return pos, vel
 
 
-def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_single=False, ghost=4):
+def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_single=False, ghost=4, solver="poisson_fft"):
     """Extension, parity unpinned: BASELINE configs[3] (two species, grid^3, `total` particles, z-slab decomposition over
     `world` ranks) exercised at full size on ONE GPU: (1) one handle holding everything = the single-GPU strong-scaling
     baseline; (2) the `world` ranks of the decomposition as handles of this process (fpic_group_*: the exchange is
@@ -381,7 +381,14 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     import fusionpic as fp
     import torch
     spec, L, vth, mi, qi = c4_scene(total, grid, world)
-    share = total // 2 // world
+    em = solver == "yee"
+    nspecies = 1 if em else 2          # configs[4] names no second species: electrons against a neutralising background
+    share = total // nspecies // world
+    migrate_every = 2 * ghost
+    if em:  # the time step of the Yee lattice (c dt = dx / 2 sqrt 3): a thermal electron moves 3e-4 cells per sub-step
+        dx = L / grid
+        spec = dict(spec, solver="yee", dt=0.5 * dx / (2.998e8 * 3 ** 0.5), macro_weight=spec["macro_weight"] * 2)
+        migrate_every = 64
     def particles(r, sp):
         return c4_rank_particles(r, world, sp, share, L, vth, 1.0 if sp == 0 else mi / spec["particle_mass"], device)
 
@@ -396,15 +403,18 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
         sync_fn(); torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    out = {"what": "BASELINE configs[3] shape on ONE GPU (EXTENSION, parity unpinned): %d^3 periodic grid, %.1e electrons + %.1e protons, %s, "
-                   "Poisson solve every sub-step" % (grid, share * world, share * world, precision),
+    out = {"what": ("BASELINE configs[4] shape on ONE GPU (EXTENSION, parity unpinned): %d^3 Yee lattice, %.1e electrons, %s, full EM"
+                    % (grid, share * world, precision)) if em else
+                   ("BASELINE configs[3] shape on ONE GPU (EXTENSION, parity unpinned): %d^3 periodic grid, %.1e electrons + %.1e protons, %s, "
+                    "Poisson solve every sub-step" % (grid, share * world, share * world, precision)),
            "unit": "particle-updates/s"}
-    n_all = 2 * share * world
+    n_all = nspecies * share * world
     sub = 2 * steps
     if not skip_single:
         one = fp.makeCylindricalParticlePusher(dict(spec, count=share * world), device=device, precision=precision)
-        one.addSpecies(mi, qi, share * world)
-        for sp in (0, 1):
+        if nspecies == 2:
+            one.addSpecies(mi, qi, share * world)
+        for sp in range(nspecies):
             for r in range(world):
                 p, v = particles(r, sp)
                 one.setRange(r * share, position=p, velocity=v, species=sp)
@@ -417,7 +427,7 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
         st = one.stats()
         fixed_sum = None
         out["single_handle"] = {"value": n_all * sub / el, "ms_per_substep": 1e3 * el / sub,
-                                "kernel_ms_per_substep": {"push_both_species": st["ms_push"] / sub, "poisson_solve": st["ms_solve"] / max(1, st["solve_launches"]),
+                                "kernel_ms_per_substep": {"push_all_species": st["ms_push"] / sub, "field_solve": st["ms_solve"] / max(1, st["solve_launches"]),
                                                           "rebinning": st["ms_sort"] / sub},
                                 "device_bytes": st["bytes_particle_state"] + st["bytes_grid_state"]}
         one.destroy()
@@ -426,9 +436,10 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     cap = int(share * 1.25)
     for r in range(world):
         s_ = fp.makeCylindricalParticlePusher(dict(spec, count=cap), device=device, precision=precision)
-        s_.addSpecies(mi, qi, cap)
-        s_.domainInit(r, world, ghost_planes=ghost, migrate_every=2 * ghost, distributed_solve=True)
-        for sp in (0, 1):
+        if nspecies == 2:
+            s_.addSpecies(mi, qi, cap)
+        s_.domainInit(r, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=not em)
+        for sp in range(nspecies):
             p, v = particles(r, sp)
             s_.domainSet(p, v, first_id=r * share, species=sp)
             del p, v
@@ -458,10 +469,12 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
         "note": "the ranks share one GPU and run one after the other: per-rank kernel times are in the rocprofv3 kernel stats of this command "
                 "(profiles/r02_c4_kernel_stats.csv: totals / ranks), not in this wall-clock figure",
         "particles_migrated_per_substep": (sum(d["migrated"] for d in dom) - mig0[0]) / float(sub), "lost": sum(d["lost"] for d in dom),
-        "ghost_planes": ghost, "migrate_every": 2 * ghost,
-        "exchange_bytes_per_rank_per_substep": {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
-                                                "fft_transposes": 2 * 2 * (grid // 2 + 1) * grid * (grid // world) * 2 * esz * (world - 1) // world,
-                                                "field_ghost_planes": 2 * 3 * plane * 4 * esz},
+        "ghost_planes": ghost, "migrate_every": migrate_every,
+        "exchange_bytes_per_rank_per_substep":
+            {"current_ghost_planes_int64_reduce": 2 * (ghost + 2) * plane * 3 * 8, "lattice_halo_copies_E_and_B": 2 * 2 * (ghost + 2) * plane * 4 * esz} if em else
+            {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
+             "fft_transposes": 2 * 2 * (grid // 2 + 1) * grid * (grid // world) * 2 * esz * (world - 1) // world,
+             "field_ghost_planes": 2 * 3 * plane * 4 * esz},
     }
     for s_ in ranks:
         s_.destroy()
@@ -534,6 +547,9 @@ def main():
     ap.add_argument("--c4-grid", type=int, default=512)
     ap.add_argument("--c4-ranks", type=int, default=8)
     ap.add_argument("--c4-skip-single", action="store_true")
+    ap.add_argument("--c4-solver", choices=["poisson_fft", "yee"], default="poisson_fft", help="--only-c4: 'yee' rehearses the full-EM decomposition (configs[4])")
+    ap.add_argument("--c4-precision", choices=["fp32", "fp64"], default="fp32")
+    ap.add_argument("--c4-ghost", type=int, default=4)
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
 
@@ -568,7 +584,7 @@ def main():
 
     if args.only_c4:
         print(json.dumps({"c4": c4_line(local_rank, int(args.c4_particles), args.c4_grid, args.c4_ranks, args.steps, args.warmup,
-                                        skip_single=args.c4_skip_single)}), flush=True)
+                                        precision=args.c4_precision, skip_single=args.c4_skip_single, ghost=args.c4_ghost, solver=args.c4_solver)}), flush=True)
         return
 
     if args.only_em:
