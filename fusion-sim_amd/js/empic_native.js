@@ -171,6 +171,27 @@ function makeBox(spec, lib) {
     out.getCells = function (buf, species) { const n = counts[species || 0]; return lib.getCellsOf(h, species || 0, checkLength(buf, n, 'cells') || new Int32Array(n)); };
     out.commInit = function (id, rank, world, overlap) { lib.commInit(h, id, rank, world, overlap === false ? 0 : 1); };
     out.commDestroy = function () { lib.commDestroy(h); };
+    // z-slab decomposition (this process = rank `rank` of `world`, after commInit with the same numbers): the rank's
+    // particles arrive through domainSet with their global indices; step() then exchanges ghost planes, halos and
+    // migrating particles with the neighbours inside the library
+    out.domainInit = function (rank, world, options) {
+        const o = options || {};
+        lib.domainInit(h, rank, world, o.ghost_planes === undefined ? 2 : o.ghost_planes, o.migrate_every === undefined ? 4 : o.migrate_every,
+                       o.distributed_solve ? 1 : 0);
+    };
+    out.domainSet = function (value, firstId, species) {
+        const sp = species || 0;
+        const p = isFloatArray(value.position) ? value.position : flattenParticles(value.position, value.position.length, 'position');
+        const v = isFloatArray(value.velocity) ? value.velocity : flattenParticles(value.velocity, value.velocity.length, 'velocity');
+        lib.domainSetParticles(h, sp, p, v, firstId || 0);
+    };
+    out.domainGet = function (species) {
+        const sp = species || 0, cap = counts[sp];
+        const position = new Real(3 * cap), velocity = new Real(3 * cap), ids = new Uint32Array(cap);
+        const n = lib.domainGetParticles(h, sp, position, velocity, ids);
+        return { n: n, position: position.subarray(0, 3 * n), velocity: velocity.subarray(0, 3 * n), ids: ids.subarray(0, n) };
+    };
+    out.domainStats = function () { return lib.domainStats(h); };
     out.sort = function () { lib.sort(h); };
     out.sync = function () { lib.sync(h); };
     out.profile = function (on) { lib.profile(h, on ? 1 : 0); };

@@ -535,6 +535,78 @@ static napi_value n_comm_init(napi_env env, napi_callback_info info)
 }
 SIMPLE_CALL(n_comm_destroy, fpic_comm_destroy)
 
+/* ---- multi-GPU: z-slab decomposition of the box (this process = one rank; exchange over the communicator) ---- */
+/* domainInit(h, rank, world, ghostPlanes, migrateEvery, distributedSolve) */
+static napi_value n_domain_init(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6]; fpic_handle* h; double v[5];
+    if (!get_args(env, info, 6, argv, &h)) return NULL;
+    for (int k = 0; k < 5; ++k)
+        if (!get_double(env, argv[1 + k], &v[k])) return NULL;
+    if (fpic_domain_init(h, (int)v[0], (int)v[1], (int)v[2], (int)v[3], (int)v[4]) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* domainSetParticles(h, species, position, velocity, firstId): the rank's initial particles, global indices firstId.. */
+static napi_value n_domain_set_particles(napi_env env, napi_callback_info info)
+{
+    napi_value argv[5]; fpic_handle* h; int sp; double first;
+    if (!get_args(env, info, 5, argv, &h)) return NULL;
+    if (!get_species(env, argv[1], &sp) || !get_double(env, argv[4], &first)) return NULL;
+    napi_typedarray_type t[2]; void* p[2]; size_t len[2]; int d[2];
+    for (int k = 0; k < 2; ++k) {
+        if (!get_typed(env, argv[2 + k], &t[k], &p[k], &len[k])) return NULL;
+        if (!p[k]) { napi_throw_type_error(env, NULL, "expected position and velocity typed arrays"); return NULL; }
+        if (!float_dtype(env, t[k], &d[k])) return NULL;
+    }
+    if (d[0] != d[1]) { napi_throw_type_error(env, NULL, "position and velocity must have the same element type"); return NULL; }
+    if (len[0] % 3) { napi_throw_range_error(env, NULL, ".position <- length must be a multiple of 3"); return NULL; }
+    if (!check_len(env, "velocity", len[1], len[0])) return NULL;
+    if (len[0] / 3 > g_box->count[sp]) { napi_throw_range_error(env, NULL, ".position <- more particles than the species' capacity"); return NULL; }
+    if (first < 0 || first > 4294967295.0) { napi_throw_range_error(env, NULL, ".firstId <- must fit 32 bits"); return NULL; }
+    if (fpic_domain_set_particles(h, sp, len[0] / 3, p[0], p[1], (uint32_t)first, d[0]) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* domainGetParticles(h, species, position, velocity, ids) -> count; all three sized for the species' capacity */
+static napi_value n_domain_get_particles(napi_env env, napi_callback_info info)
+{
+    napi_value argv[5]; fpic_handle* h; int sp;
+    if (!get_args(env, info, 5, argv, &h)) return NULL;
+    if (!get_species(env, argv[1], &sp)) return NULL;
+    napi_typedarray_type t[3]; void* p[3]; size_t len[3]; int d[2];
+    for (int k = 0; k < 3; ++k) {
+        if (!get_typed(env, argv[2 + k], &t[k], &p[k], &len[k])) return NULL;
+        if (!p[k]) { napi_throw_type_error(env, NULL, "expected position, velocity and ids typed arrays"); return NULL; }
+    }
+    if (!float_dtype(env, t[0], &d[0]) || !float_dtype(env, t[1], &d[1])) return NULL;
+    if (d[0] != d[1]) { napi_throw_type_error(env, NULL, "position and velocity must have the same element type"); return NULL; }
+    if (t[2] != napi_uint32_array) { napi_throw_type_error(env, NULL, "expected a Uint32Array of ids"); return NULL; }
+    if (!check_len(env, "position", len[0], 3 * g_box->count[sp]) || !check_len(env, "velocity", len[1], 3 * g_box->count[sp]) ||
+        !check_len(env, "ids", len[2], g_box->count[sp]))
+        return NULL;
+    uint64_t n = 0;
+    if (fpic_domain_get_particles(h, sp, p[0], p[1], (uint32_t*)p[2], g_box->count[sp], &n, d[0]) != FPIC_OK) return throw_fpic(env, h);
+    napi_value out;
+    NAPI_OK(env, napi_create_double(env, (double)n, &out));
+    return out;
+}
+
+static napi_value n_domain_stats(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1]; fpic_handle* h;
+    if (!get_args(env, info, 1, argv, &h)) return NULL;
+    uint64_t migrated = 0, lost = 0;
+    if (fpic_domain_stats(h, &migrated, &lost) != FPIC_OK) return throw_fpic(env, h);
+    napi_value out, a, b;
+    NAPI_OK(env, napi_create_object(env, &out));
+    NAPI_OK(env, napi_create_double(env, (double)migrated, &a));
+    NAPI_OK(env, napi_create_double(env, (double)lost, &b));
+    NAPI_OK(env, napi_set_named_property(env, out, "migrated", a));
+    NAPI_OK(env, napi_set_named_property(env, out, "lost", b));
+    return out;
+}
+
 static napi_value n_build_arch(napi_env env, napi_callback_info info)
 {
     (void)info;
@@ -558,6 +630,8 @@ static napi_value init(napi_env env, napi_value exports)
         { "addSpecies", n_add_species }, { "setParticlesRange", n_set_particles_range }, { "getParticlesOf", n_get_particles_of },
         { "getCellsOf", n_get_cells_of }, { "addB", n_add_b }, { "setField3", n_set_field3 }, { "readField3", n_read_field3 },
         { "commUniqueId", n_comm_unique_id }, { "commInit", n_comm_init }, { "commDestroy", n_comm_destroy },
+        { "domainInit", n_domain_init }, { "domainSetParticles", n_domain_set_particles }, { "domainGetParticles", n_domain_get_particles },
+        { "domainStats", n_domain_stats },
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

@@ -492,3 +492,59 @@ def test_two_level_binning_at_a_million_particles_is_bit_exact(fp, eo):
     """2^20 + 777 electrons on a 64 x 64 x 32 grid (65 tiles: coarse groups of 9): the production size threshold, no
     override; push + integer deposit bit-exact against the oracle after a first binning and two re-binnings."""
     test_push_and_deposit_bit_exact_in_a_given_field(fp, eo, "fp32", (64, 64, 32), (1 << 20) + 777, True, 2)
+
+
+def test_decomposed_rank_through_the_javascript_host(fp, eo, tmp_path):
+    """The decomposition entry points through Node: this process is rank 0 of a world of one (the same calls every
+    rank of an N-process run makes: commInit, domainInit, domainSet with global indices, precalc, step, domainGet).
+    Against a plain handle on the same particles: the charge grid and, matched by index, every particle bit-identical."""
+    import base64
+    import json
+    import os
+    import shutil
+    import subprocess
+    from helpers import ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    rng = np.random.default_rng(5)
+    n = 5000
+    shape, L = (16, 16, 16), (0.016, 0.016, 0.016)
+    spec = box_spec(shape, L, count=n, dt=5e-12, macro_weight=1e15 * np.prod(L) / n)
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.02, (n, 3))
+    (tmp_path / "in.json").write_text(json.dumps(dict(spec=spec, pos=pos.tolist(), vel=vel.tolist())))
+    script = r"""
+const fs = require('fs');
+const empic = require(process.argv[1]);
+const inp = JSON.parse(fs.readFileSync(process.argv[2]));
+const sim = empic.makeCylindricalParticlePusher(inp.spec);
+sim.commInit(empic.commUniqueId(), 0, 1);
+sim.domainInit(0, 1, {ghost_planes: 2, migrate_every: 2});
+sim.domainSet({position: inp.pos, velocity: inp.vel}, 0);
+sim.precalc();
+for (let frame = 0; frame < 3; frame++) sim.step();
+const got = sim.domainGet();
+const b64 = a => Buffer.from(a.buffer, a.byteOffset, a.byteLength).toString('base64');
+let err = 'none';
+try { sim.domainSet({position: new Float32Array(9), velocity: new Float32Array(6)}, 0); } catch (x) { err = x.constructor.name; }
+console.log(JSON.stringify({n: got.n, pos: b64(got.position), vel: b64(got.velocity), ids: b64(got.ids), fixed: b64(sim.readField('rho_fixed')),
+  stats: sim.domainStats(), err: err}));
+sim.destroy();
+"""
+    shim = os.path.join(ROOT, "fusion-sim_amd", "js", "empic_native.js")
+    raw = subprocess.check_output([node, "-e", script, shim, str(tmp_path / "in.json")])
+    out = json.loads(raw.decode().strip().splitlines()[-1])
+    dec = lambda k, dt: np.frombuffer(base64.b64decode(out[k]), dtype=dt)
+    one = fp.makeCylindricalParticlePusher(spec)
+    one.set(position=pos, velocity=vel)
+    one.precalc()
+    one.step(3)
+    ref = one.getParticles()
+    ids = dec("ids", np.uint32)
+    assert out["n"] == n and np.array_equal(np.sort(ids), np.arange(n))
+    order = np.argsort(ids)
+    assert same_bits(dec("pos", np.float32).reshape(-1, 3)[order], ref["position"])
+    assert same_bits(dec("vel", np.float32).reshape(-1, 3)[order], ref["velocity"])
+    assert np.array_equal(dec("fixed", np.int64), one.readField(fp.F3_RHO_FIXED))
+    assert out["err"] == "RangeError" and out["stats"]["lost"] == 0
+    one.destroy()
