@@ -481,6 +481,82 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     return out
 
 
+def box_workload(args, rank, world, local_rank, dist):
+    """`--workload box`: BASELINE configs[3] (or, with --c4-solver yee, configs[4]'s shape) as ONE decomposed run over
+    the launcher's ranks — this process is rank `rank` of `world` z-slabs, the exchange (ghost planes, FFT transposes or
+    lattice halos, migrating particles) runs inside libfusionpic.so over its own RCCL communicator.  A fixed total
+    population: `"scaling": "strong"`.  (World of one = one handle holding everything.)"""
+    import fusionpic as fp
+    import torch
+    total, grid, ghost = int(args.c4_particles), args.c4_grid, args.c4_ghost
+    em = args.c4_solver == "yee"
+    spec, L, vth, mi, qi = c4_scene(total, grid, world)
+    nspecies = 1 if em else 2
+    share = total // nspecies // world
+    migrate_every = 2 * ghost
+    if em:
+        spec = dict(spec, solver="yee", dt=0.5 * (L / grid) / (2.998e8 * 3 ** 0.5), macro_weight=spec["macro_weight"] * 2)
+        migrate_every = 64
+    cap = share if world == 1 else int(share * 1.25)
+    sim = fp.makeCylindricalParticlePusher(dict(spec, count=cap), device=local_rank, precision=args.c4_precision)
+    if nspecies == 2:
+        sim.addSpecies(mi, qi, cap)
+    if dist is not None:
+        box = [fp.commUniqueId() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        sim.commInit(box[0], rank, world)
+    sim.domainInit(rank, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=not em and world > 1)
+    for sp in range(nspecies):
+        p, v = c4_rank_particles(rank, world, sp, share, L, vth, 1.0 if sp == 0 else mi / spec["particle_mass"], local_rank)
+        sim.domainSet(p, v, first_id=rank * share, species=sp)
+        del p, v
+    torch.cuda.empty_cache()
+
+    def fence():
+        sim.sync(); torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(); torch.cuda.synchronize()
+    sim.precalc()
+    for _ in range(args.warmup):
+        sim.step()
+    fence()
+    sim.resetStats(); sim.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st, dom = sim.stats(), sim.domainStats()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sim.destroy()
+    if rank != 0:
+        return
+    sub = 2 * args.steps
+    n_all = nspecies * share * world
+    esz = 4 if args.c4_precision == "fp32" else 8
+    push_ms = st["ms_push"] / sub
+    algo = 12.0 * esz * nspecies * share     # one read and one write of the six coordinates per particle and sub-step
+    print(json.dumps({
+        "metric": "particle-updates/sec (push+deposit+solve)", "value": n_all * sub / elapsed, "unit": "particle-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32" if esz == 4 else "f64", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[4] shape: %d^3 Yee lattice, %.1e electrons in total, full EM" if em else
+                                "BASELINE configs[3]: %d^3 periodic grid, %.1e particles in total (electrons + protons), Poisson solve every sub-step")
+                               % (grid, n_all) + "; EXTENSION, parity unpinned (no reference counterpart); one step = 2 sub-steps",
+                   "parallelism": "z-slab decomposition x%d inside libfusionpic.so over RCCL (ghost planes %d, migration every %d sub-steps%s)"
+                                  % (world, ghost, migrate_every, "" if em or world == 1 else ", slab-decomposed FFT")},
+        "roofline": {"bound": "hbm", "kernel": "em_push_tiles_kernel" if em else "push3_tiles_kernel", "achieved": algo / (push_ms * 1e-3) / 1e9 if push_ms else 0.0,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if push_ms else 0.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo, "avg_launch_ms": push_ms, "note": "rank 0's push of all its species per sub-step"},
+        "kernel_ms_per_substep_rank0": {"push": push_ms, "field_solve": st["ms_solve"] / sub, "rebinning_and_migration": st["ms_sort"] / sub},
+        "migrated_rank0": dom["migrated"], "lost_rank0": dom["lost"], "cpu_baseline": None,
+    }), flush=True)
+
+
 def es3d_cpu_port(seconds_target=5.0):
     """The build's own CPU oracle of the same cycle (oracle/es3d_oracle.c, OpenMP) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -542,6 +618,9 @@ def main():
     ap.add_argument("--only-c3", action="store_true", help="development: measure extensions.c3 alone and print it")
     ap.add_argument("--only-em", action="store_true", help="development: measure the full-EM extension alone (--c3-particles, --c3-grid, --em-precision)")
     ap.add_argument("--em-precision", choices=["fp32", "fp64"], default="fp64")
+    ap.add_argument("--workload", choices=["rz", "box"], default="rz",
+                    help="rz = the headline (reference-parity pusher, particle shards); box = BASELINE configs[3]/[4] as one z-slab-decomposed "
+                         "run over the ranks (strong scaling; --c4-particles, --c4-grid, --c4-solver, --c4-precision, --c4-ghost)")
     ap.add_argument("--only-c4", action="store_true", help="development: BASELINE configs[3] shape on one GPU (one handle, then the in-process decomposition)")
     ap.add_argument("--c4-particles", type=float, default=2e9, help="--only-c4: total particles (two species, half each)")
     ap.add_argument("--c4-grid", type=int, default=512)
@@ -577,6 +656,12 @@ def main():
         except (AttributeError, TypeError):
             pass
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+
+    if args.workload == "box":
+        box_workload(args, rank, world, local_rank, dist if distributed else None)
+        if distributed:
+            dist.destroy_process_group()
+        return
 
     if args.only_c3:
         print(json.dumps({"c3": es3d_line(local_rank, args.c3_particles, args.c3_grid, args.steps, args.warmup, cpu=not args.no_cpu_baseline)}), flush=True)
