@@ -13,7 +13,7 @@ for f in sorted(glob.glob(root + "/*/runc/*counter_collection.csv")):
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("==", f.split("/")[-3])
     for k in sorted(acc):
-        if not any(s in k for s in ("push", "cell_sums", "bin_scatter", "stamp", "bin_count")):
+        if not any(s in k for s in ("push", "cell_sums", "bin_scatter", "stamp", "bin_count", "sort_scatter")):
             continue
         parts = []
         for c, v in sorted(acc[k].items()):
