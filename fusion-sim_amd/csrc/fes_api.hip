@@ -1207,7 +1207,11 @@ int migrate(Ranks& rk)
                 s.rebin_pending = true;
                 s.tail_first = s.n; s.tail_count = in;
                 s.n_after = s.n - out + in;
-                if (s.n_after == 0) { s.n = 0; s.rebin_pending = false; s.tail_count = 0; } // (an emptied rank: nothing to push)
+                if (s.n_after == 0) { // an emptied rank: nothing to push; what arrives later is binned by the separate passes
+                    s.n = 0;
+                    s.rebin_pending = s.census_fresh = s.binned = false;
+                    s.tail_first = s.tail_count = 0;
+                }
             } else {
                 // the binning runs over the old slots (dead ones skipped) and the arrivals, and leaves a compact array
                 const size_t slots = s.n + in;

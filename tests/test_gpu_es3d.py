@@ -548,3 +548,62 @@ sim.destroy();
     assert np.array_equal(dec("fixed", np.int64), one.readField(fp.F3_RHO_FIXED))
     assert out["err"] == "RangeError" and out["stats"]["lost"] == 0
     one.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_decomposition_with_an_empty_and_an_emptied_rank(fp, eo, precision):
+    """Two species in a 3-rank decomposition: the electrons all start in slab 0 and stream upwards (slab 0 empties, slab 1
+    — empty at first — fills, later slab 2), the ions sit in slab 2 only.  Ranks without particles of a species, ranks
+    that lose all of them and ranks whose first particles arrive by migration, against one handle: bit-identical."""
+    rng = np.random.default_rng(3)
+    world, shape = 3, (16, 16, 24)
+    L = (0.016, 0.016, 0.024)
+    n, ni = 9000, 2000
+    dt = 5e-12
+    spec = box_spec(shape, L, count=n, dt=dt, solver="none", macro_weight=1e4)
+    nzl = shape[2] // world
+    cell_per_substep = 0.3                                               # along z, every electron
+    vz = cell_per_substep * (L[2] / shape[2]) / (dt * 2.998e8)
+    pos = rng.random((n, 3)) * (L[0], L[1], L[2] * 5.0 / shape[2]) + (0, 0, L[2] * 1.0 / shape[2])   # planes 1..6 of slab 0
+    vel = np.concatenate([rng.normal(0, 0.01, (n, 2)), np.full((n, 1), vz)], axis=1)
+    pi = rng.random((ni, 3)) * (L[0], L[1], L[2] / world) + (0, 0, 2 * L[2] / world)
+    vi = rng.normal(0, 1e-4, (ni, 3))
+    E = rng.normal(0, 1e3, shape + (3,))
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.addSpecies(MP, -QE, ni)
+    one.set(position=pos, velocity=vel, E=E); one.set(position=pi, velocity=vi, species=1)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(spec, precision=precision)
+        s.addSpecies(MP, -QE, ni)
+        s.domainInit(r, world, ghost_planes=2, migrate_every=2)
+        s.set(E=E)
+        if r == 0:
+            s.domainSet(pos, vel, first_id=0)
+        if r == 2:
+            s.domainSet(pi, vi, first_id=0, species=1)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+    held = []
+    for frame in range(24):                                               # 48 sub-steps x 0.3 cells = 14.4 cells: through slab 1 into slab 2
+        one.step(); group.step()
+        f1 = one.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+        for r, s in enumerate(ranks):
+            fr = s.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+            assert np.array_equal(fr[r * nzl:(r + 1) * nzl], f1[r * nzl:(r + 1) * nzl]), (frame, r)
+        for sp, total in ((0, n), (1, ni)):
+            parts = [s.domainGet(species=sp) for s in ranks]
+            if sp == 0:
+                held.append([len(p["ids"]) for p in parts])
+            ids = np.concatenate([p["ids"] for p in parts])
+            assert np.array_equal(np.sort(ids), np.arange(total)), (frame, sp)
+            ref = one.getParticles(species=sp)
+            assert same_bits(np.concatenate([p["position"] for p in parts])[np.argsort(ids)], ref["position"]), (frame, sp)
+            assert same_bits(np.concatenate([p["velocity"] for p in parts])[np.argsort(ids)], ref["velocity"]), (frame, sp)
+    held = np.array(held)
+    assert held[0, 0] > 0 and held[-1, 0] == 0, "slab 0 must have emptied"
+    assert held[0, 1] < n // 2 and held[:, 1].max() > n // 2 and held[-1, 2] > 0, "slab 1 fills from nothing, slab 2 receives later"
+    assert all(s.domainStats()["lost"] == 0 for s in ranks)
+    for s in ranks + [one]:
+        s.destroy()
