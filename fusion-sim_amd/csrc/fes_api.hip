@@ -957,6 +957,176 @@ int get_cells(fpic_handle* h, int species, int32_t* cells)
     return h->prec == FPIC_F32 ? download_cells<float>(h, s, cells) : download_cells<double>(h, s, cells);
 }
 
+// ---- checkpoint of an undecomposed box: header, per species the raw particle state in the caller's order, the fields
+namespace {
+
+struct BoxCheckpointHeader {
+    char magic[8];        // "FPICBOX1"
+    uint32_t version;     // 1
+    uint32_t precision, solver, nspecies;
+    int32_t nx, ny, nz;
+    uint32_t fields_ready;
+    double B0[3];
+    fpic_spec spec;
+};
+struct BoxCheckpointSpecies {
+    uint64_t n;
+    double mass, charge;
+};
+
+struct BoxFile {
+    FILE* f;
+    ~BoxFile() { if (f) std::fclose(f); }
+};
+
+// the device arrays a checkpoint carries besides the particles
+std::vector<std::pair<void*, size_t>> checkpoint_fields(const fpic_handle* h)
+{
+    const State* st = h->es;
+    const size_t t = h->prec == FPIC_F32 ? 4 : 8;
+    std::vector<std::pair<void*, size_t>> out;
+    out.push_back({ st->E4, st->nodes * 4 * t });
+    if (st->solver == FPIC_SOLVER_YEE) {
+        out.push_back({ st->Ey, st->nodes * 4 * t });
+        out.push_back({ st->By, st->nodes * 4 * t });
+        out.push_back({ st->B4n, st->nodes * 4 * t });
+    }
+    return out;
+}
+
+constexpr size_t kCkptChunk = size_t(4) << 20; // particles per staging round (96 / 192 MB)
+
+template <typename T>
+int checkpoint_particles(fpic_handle* h, FILE* f, bool save)
+{
+    State* st = h->es;
+    T* stage = nullptr;
+    size_t most = 0;
+    for (const Species& s : st->sp) most = std::max(most, std::min(kCkptChunk, s.n));
+    if (!most) return FPIC_OK;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), most * 6 * sizeof(T)));
+    std::vector<T> host(most * 6);
+    int rc = FPIC_OK;
+    for (Species& s : st->sp) {
+        for (size_t first = 0; first < s.n && rc == FPIC_OK; first += kCkptChunk) {
+            const size_t m = std::min(kCkptChunk, s.n - first);
+            hipError_t e = hipSuccess;
+            if (save) {
+                ckpt_gather_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(static_cast<const T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, first, m, stage);
+                if ((e = hipGetLastError()) == hipSuccess) e = hipMemcpyAsync(host.data(), stage, m * 6 * sizeof(T), hipMemcpyDeviceToHost, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                if (e == hipSuccess && std::fwrite(host.data(), sizeof(T), m * 6, f) != m * 6) rc = fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+            } else {
+                if (std::fread(host.data(), sizeof(T), m * 6, f) != m * 6) { rc = fail(h, FPIC_ERR_STATE, "checkpoint read failed"); break; }
+                e = hipMemcpyAsync(stage, host.data(), m * 6 * sizeof(T), hipMemcpyHostToDevice, h->stream);
+                if (e == hipSuccess) {
+                    ckpt_scatter_kernel<T><<<blocks_for(m), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], first, m, stage);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            }
+            if (e != hipSuccess) rc = fail(h, FPIC_ERR_HIP, "checkpoint transfer failed: %s", hipGetErrorString(e));
+        }
+        if (rc) break;
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
+int checkpoint_arrays(fpic_handle* h, FILE* f, bool save)
+{
+    std::vector<unsigned char> host(size_t(64) << 20);
+    for (const auto& a : checkpoint_fields(h)) {
+        for (size_t off = 0; off < a.second; off += host.size()) {
+            const size_t m = std::min(host.size(), a.second - off);
+            if (save) {
+                HIP_TRY(h, hipMemcpyAsync(host.data(), static_cast<const char*>(a.first) + off, m, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                if (std::fwrite(host.data(), 1, m, f) != m) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+            } else {
+                if (std::fread(host.data(), 1, m, f) != m) return fail(h, FPIC_ERR_STATE, "checkpoint read failed");
+                HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(a.first) + off, host.data(), m, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+            }
+        }
+    }
+    return FPIC_OK;
+}
+
+} // namespace
+
+int save_checkpoint(fpic_handle* h, const char* path)
+{
+    State* st = h->es;
+    if (st->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle is not checkpointed as a whole: save what fpic_domain_get_particles returns on every rank");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    BoxFile bf{ std::fopen(path, "wb") };
+    if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
+    BoxCheckpointHeader hd{};
+    std::memcpy(hd.magic, "FPICBOX1", 8);
+    hd.version = 1; hd.precision = static_cast<uint32_t>(h->prec); hd.solver = static_cast<uint32_t>(st->solver);
+    hd.nspecies = static_cast<uint32_t>(st->sp.size());
+    hd.nx = st->nx; hd.ny = st->ny; hd.nz = st->nz; hd.fields_ready = st->fields_ready ? 1 : 0;
+    for (int a = 0; a < 3; ++a) hd.B0[a] = st->B0[a];
+    hd.spec = h->spec;
+    if (std::fwrite(&hd, sizeof hd, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+    for (const Species& s : st->sp) {
+        const BoxCheckpointSpecies bs{ s.n, s.mass, s.charge };
+        if (std::fwrite(&bs, sizeof bs, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+    }
+    if (int rc = h->prec == FPIC_F32 ? checkpoint_particles<float>(h, bf.f, true) : checkpoint_particles<double>(h, bf.f, true)) return rc;
+    return checkpoint_arrays(h, bf.f, true);
+}
+
+int load_checkpoint(fpic_handle* h, const char* path)
+{
+    State* st = h->es;
+    if (st->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle is not restored from a checkpoint: hand every rank its particles through fpic_domain_set_particles");
+    BoxFile bf{ std::fopen(path, "rb") };
+    if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
+    BoxCheckpointHeader hd{};
+    if (std::fread(&hd, sizeof hd, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICBOX1", 8) != 0 || hd.version != 1)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a box (version 1)", path);
+    if (static_cast<int>(hd.precision) != h->prec || static_cast<int>(hd.solver) != st->solver || hd.nspecies != st->sp.size() || hd.nx != st->nx || hd.ny != st->ny ||
+        hd.nz != st->nz)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint holds %u species on %d x %d x %d, precision %u, solver %u; the pusher was made for %zu on %d x %d x %d, precision %d, solver %d",
+                    hd.nspecies, hd.nx, hd.ny, hd.nz, hd.precision, hd.solver, st->sp.size(), st->nx, st->ny, st->nz, h->prec, st->solver);
+    if (hd.spec.radius != h->spec.radius || hd.spec.length_y != h->spec.length_y || hd.spec.height != h->spec.height || hd.spec.dt != h->spec.dt ||
+        hd.spec.macro_weight != h->spec.macro_weight)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint was written with different lengths / dt / macro_weight");
+    const size_t t = h->prec == FPIC_F32 ? 4 : 8;
+    unsigned long long want = sizeof hd + hd.nspecies * sizeof(BoxCheckpointSpecies);
+    for (size_t k = 0; k < st->sp.size(); ++k) {
+        BoxCheckpointSpecies bs{};
+        if (std::fread(&bs, sizeof bs, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
+        if (bs.n != st->sp[k].n || bs.mass != st->sp[k].mass || bs.charge != st->sp[k].charge)
+            return fail(h, FPIC_ERR_INVALID_ARG, ".species <- species %zu of the checkpoint (%llu particles, mass %g, charge %g) is not the pusher's", k,
+                        static_cast<unsigned long long>(bs.n), bs.mass, bs.charge);
+        want += 6ull * bs.n * t;
+    }
+    for (const auto& a : checkpoint_fields(h)) want += a.second;
+    // the whole payload must be there before any device state is touched
+    const long at = std::ftell(bf.f);
+    if (at < 0 || std::fseek(bf.f, 0, SEEK_END) != 0) return fail(h, FPIC_ERR_STATE, "cannot seek in %s", path);
+    const long long have = std::ftell(bf.f);
+    if (have < 0 || static_cast<unsigned long long>(have) < want) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated: %lld bytes, %llu expected", have, want);
+    if (std::fseek(bf.f, at, SEEK_SET) != 0) return fail(h, FPIC_ERR_STATE, "cannot seek in %s", path);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (Species& s : st->sp) { // the arrays are about to hold the caller's order: bins and census are void
+        s.binned = s.census_fresh = s.rebin_pending = false;
+        s.tail_first = s.tail_count = s.n_after = 0;
+    }
+    st->spill_pending[0] = st->spill_pending[1] = false;
+    st->last_spill = 0;
+    st->substeps_since_bin = 0;
+    st->fields_ready = false;
+    if (int rc = h->prec == FPIC_F32 ? checkpoint_particles<float>(h, bf.f, false) : checkpoint_particles<double>(h, bf.f, false)) return rc;
+    if (int rc = checkpoint_arrays(h, bf.f, false)) return rc;
+    for (int a = 0; a < 3; ++a) st->B0[a] = hd.B0[a];
+    st->fields_ready = hd.fields_ready != 0;
+    return FPIC_OK;
+}
+
 int add_b(fpic_handle* h, double bx, double by, double bz)
 {
     if (!std::isfinite(bx) || !std::isfinite(by) || !std::isfinite(bz)) return fail(h, FPIC_ERR_INVALID_ARG, ".B <- must be finite");

@@ -21,6 +21,8 @@ int density(fpic_handle* h);
 int step(fpic_handle* h, int ncalls);
 int sort(fpic_handle* h);
 int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
+int save_checkpoint(fpic_handle* h, const char* path);
+int load_checkpoint(fpic_handle* h, const char* path);
 // z-slab decomposition
 int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve);
 int domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype);

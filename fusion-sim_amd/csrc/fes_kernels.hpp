@@ -1479,6 +1479,30 @@ __global__ __launch_bounds__(256) void gradient_planes_kernel(const T* __restric
 }
 
 // ids of a freshly uploaded population: first + slot
+// checkpoint: the raw state of the caller's particles [first, first + m) <-> an AoS staging buffer (6 T per particle)
+template <typename T>
+__global__ __launch_bounds__(256) void ckpt_gather_kernel(const T* __restrict__ slab, size_t stride, const uint32_t* __restrict__ id, size_t n, size_t first, size_t m,
+                                                          T* __restrict__ stage)
+{
+    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t i = static_cast<size_t>(id[s]) - first; // (unsigned: below `first` wraps past m)
+    if (i >= m) return;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) stage[6 * i + f] = slab[f * stride + s];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ckpt_scatter_kernel(T* __restrict__ slab, size_t stride, uint32_t* __restrict__ id, size_t first, size_t m,
+                                                           const T* __restrict__ stage)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) slab[f * stride + first + i] = stage[6 * i + f];
+    id[first + i] = static_cast<uint32_t>(first + i);
+}
+
 static __global__ __launch_bounds__(256) void iota3_kernel(uint32_t* id, size_t n, uint32_t first)
 {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -1230,8 +1230,8 @@ int fpic_get_stream(fpic_handle* h, void** hip_stream)
 int fpic_save_checkpoint(fpic_handle* h, const char* path)
 {
     CHECK_HANDLE(h);
-    RZ_ONLY(h, "fpic_save_checkpoint");
     if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
+    if (h->es) return fes::save_checkpoint(h, path);
     if (int rc = wait_external_finish(h)) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     FileCloser fc{ std::fopen(path, "wb") };
@@ -1247,8 +1247,8 @@ int fpic_save_checkpoint(fpic_handle* h, const char* path)
 int fpic_load_checkpoint(fpic_handle* h, const char* path)
 {
     CHECK_HANDLE(h);
-    RZ_ONLY(h, "fpic_load_checkpoint");
     if (!path) return fail(h, FPIC_ERR_INVALID_ARG, ".path <- Non-optional property is undefined!");
+    if (h->es) return fes::load_checkpoint(h, path);
     if (int rc = wait_external_finish(h)) return rc;
     FileCloser fc{ std::fopen(path, "rb") };
     if (!fc.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);

@@ -532,6 +532,13 @@ class ElectrostaticBoxPusher:
                                                         out["ids"].ctypes.data, m, ctypes.byref(n), code))
         return out
 
+    def saveCheckpoint(self, path):
+        """particles of every species (raw state, caller's order) and the fields; not for a decomposed handle"""
+        self._check(self._lib.fpic_save_checkpoint(self._h, os.fsencode(path)))
+
+    def loadCheckpoint(self, path):
+        self._check(self._lib.fpic_load_checkpoint(self._h, os.fsencode(path)))
+
     def domainStats(self):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
         self._check(self._lib.fpic_domain_stats(self._h, ctypes.byref(a), ctypes.byref(b)))

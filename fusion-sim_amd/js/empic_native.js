@@ -192,6 +192,8 @@ function makeBox(spec, lib) {
         return { n: n, position: position.subarray(0, 3 * n), velocity: velocity.subarray(0, 3 * n), ids: ids.subarray(0, n) };
     };
     out.domainStats = function () { return lib.domainStats(h); };
+    out.saveCheckpoint = function (path) { lib.saveCheckpoint(h, String(path)); };   // fpic_save_checkpoint: particles of every species + fields
+    out.loadCheckpoint = function (path) { lib.loadCheckpoint(h, String(path)); };
     out.sort = function () { lib.sort(h); };
     out.sync = function () { lib.sync(h); };
     out.profile = function (on) { lib.profile(h, on ? 1 : 0); };

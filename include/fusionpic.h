@@ -346,7 +346,9 @@ int fpic_sort(fpic_handle* h);
 /* Read-back / resume (the reference can only display its state,
  * utilities.js:701-711 is unused): a flat binary dump of the particle arrays in the caller's
  * order and of the grid tables, and its inverse.  The target handle of a load must have been
- * created from the same spec.  A run resumed from a checkpoint continues bit-identically. */
+ * created from the same spec.  A run resumed from a checkpoint continues bit-identically.
+ * A box (spec.geometry = CART3D) saves the raw state of every species and its fields (its own file layout); the
+ * target handle must have the same species added.  Not for a rank of a decomposition. */
 int fpic_save_checkpoint(fpic_handle* h, const char* path);
 int fpic_load_checkpoint(fpic_handle* h, const char* path);
 

@@ -607,3 +607,70 @@ def test_decomposition_with_an_empty_and_an_emptied_rank(fp, eo, precision):
     assert all(s.domainStats()["lost"] == 0 for s in ranks)
     for s in ranks + [one]:
         s.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("solver", ["poisson_fft", "none", "yee"])
+def test_box_checkpoint_resume_is_bit_identical(fp, eo, tmp_path, precision, solver):
+    """save after 3 frames, 3 more frames; a fresh handle restored from the file and stepped 3 frames: particles of both
+    species, the charge (or current) grid and the fields are bit-identical.  A truncated file, a file of another box and
+    a decomposed handle are refused, the handle unchanged."""
+    rng = np.random.default_rng(21)
+    shape, L = (20, 16, 24), (0.02, 0.016, 0.024)
+    n, ni = 30000, 8000
+    dt = 5e-12
+    if solver == "yee":
+        d = [L[a] / shape[a] for a in range(3)]
+        dt = 0.5 / (2.998e8 * np.sqrt(sum(1 / x ** 2 for x in d)))
+    spec = box_spec(shape, L, count=n, dt=dt, solver=solver, macro_weight=1e15 * np.prod(L) / n)
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.02, (n, 3))
+    pi, vi = rng.random((ni, 3)) * L, rng.normal(0, 1e-3, (ni, 3))
+    E = rng.normal(0, 3e4, shape + (3,))
+
+    def build():
+        s = fp.makeCylindricalParticlePusher(spec, precision=precision, sort_interval=2 if solver != "yee" else 0)
+        s.addSpecies(MP, -QE, ni)
+        return s
+
+    a = build()
+    a.set(position=pos, velocity=vel); a.set(position=pi, velocity=vi, species=1)
+    if solver == "none":
+        a.set(E=E)
+    a.addB(0.01, -0.02, 0.05)
+    a.precalc()
+    a.step(3)
+    path = tmp_path / "box.ckpt"
+    a.saveCheckpoint(path)
+    a.step(3)
+
+    b = build()
+    b.set(position=pos[::-1], velocity=vel[::-1])     # something else, to be overwritten
+    b.loadCheckpoint(path)
+    b.step(3)
+    for sp in (0, 1):
+        ga, gb = a.getParticles(species=sp), b.getParticles(species=sp)
+        assert same_bits(ga["position"], gb["position"]) and same_bits(ga["velocity"], gb["velocity"]), sp
+    fields = [fp.F3_RHO_FIXED, fp.F3_E] + ([fp.F3_EDGE_E, fp.F3_FACE_B, fp.F3_J_FIXED] if solver == "yee" else [])
+    if solver == "yee":
+        a.density(); b.density()
+    for which in fields:
+        fa, fb = a.readField(which), b.readField(which)
+        assert np.array_equal(fa, fb) if fa.dtype == np.int64 else same_bits(fa, fb), which
+
+    # refusals
+    data = path.read_bytes()
+    (tmp_path / "short.ckpt").write_bytes(data[:len(data) - 1000])
+    before = b.getParticles()
+    with pytest.raises(fp.FusionPicError, match="truncated"):
+        b.loadCheckpoint(tmp_path / "short.ckpt")
+    other = fp.makeCylindricalParticlePusher(dict(spec, nz=shape[2] + 8), precision=precision)
+    with pytest.raises(fp.FusionPicError):
+        other.loadCheckpoint(path)                       # one species, another grid
+    assert same_bits(b.getParticles()["position"], before["position"])
+    dec = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    if solver != "yee":
+        dec.domainInit(0, 2, ghost_planes=2, migrate_every=2)
+        with pytest.raises(fp.FusionPicError):
+            dec.saveCheckpoint(tmp_path / "no.ckpt")
+    for s in (a, b, other, dec):
+        s.destroy()
