@@ -674,3 +674,20 @@ def test_box_checkpoint_resume_is_bit_identical(fp, eo, tmp_path, precision, sol
             dec.saveCheckpoint(tmp_path / "no.ckpt")
     for s in (a, b, other, dec):
         s.destroy()
+
+
+def test_plasma_box_example_from_node():
+    """examples/plasma_box_node.js: a cold plasma oscillation in the box, driven from Node; the frequency read off the
+    field's zero crossings is the scheme's omega_p cos(k dx / 2) within 1 %."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    from helpers import ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    out = subprocess.check_output([node, os.path.join(ROOT, "examples", "plasma_box_node.js"), "--grid", "16", "--perCell", "8", "--frames", "150"])
+    res = json.loads(out.decode().strip().splitlines()[-1])
+    assert res["particles"] == 16 ** 3 * 8 and res["updates"] == 300 * res["particles"]
+    assert res["relative_error"] < 1e-2, res
