@@ -21,7 +21,7 @@
  *   getParticles()      -> {position, velocity, rand, alive} in the caller's order
  *   setRandomState({entropy, rand}) -> reproducible runs (the reference seeds from
  *                          window.crypto and Math.random, empic.js:148-173)
- * Extension keys of spec (all optional): precision 'fp32'|'fp64', device, count,
+ * Extension keys of spec (all optional): precision 'fp32'|'fp64', device (or devices: [d]), count,
  * compat (default true: keep quirk Q1 of empic.js:645), sort_interval, fuse_deposit
  * (default true; 'census' keeps only the tile census and re-binning in step()), rng 'reference'|'counter' + seed (counter = Philox4x32-10 per particle
  * and sub-step instead of the reference's entropy-table generator; not the reference's
@@ -119,6 +119,27 @@ function flattenParticles(value, n, name) {
     return out;
 }
 
+// stepAsync(ncalls) -> Promise (SURVEY 8(b), threading): the step runs on a worker thread of Node's pool; the handle is
+// not thread-safe, so every other method of the simulation throws until the promise has settled.
+function addStepAsync(out, lib, handle) {
+    let busy = false;
+    for (const name of Object.keys(out)) {
+        const f = out[name];
+        if (typeof f !== 'function') continue;
+        out[name] = function () {
+            if (busy) throw new Error('.' + name + ' <- a stepAsync() of this simulation is still running');
+            return f.apply(this, arguments);
+        };
+    }
+    out.stepAsync = function (ncalls) {
+        if (busy) return Promise.reject(new Error('.stepAsync <- a stepAsync() of this simulation is still running'));
+        busy = true;
+        const done = () => { busy = false; };
+        return lib.stepAsync(handle(), ncalls === undefined ? 1 : ncalls).then(v => { done(); return v; }, e => { done(); throw e; });
+    };
+    return out;
+}
+
 const FIELD3 = { E: 0, rho: 1, phi: 2, rho_fixed: 3, B: 4, edge_E: 5, face_B: 6 };   // B, edge_E, face_B: full EM (solver 'yee')
 
 // spec.geometry === 'cart3d': the electrostatic box behind the same method names
@@ -201,7 +222,7 @@ function makeBox(spec, lib) {
     out.resetStats = function () { lib.resetStats(h); };
     out.destroy = function () { if (h) { lib.destroy(h); h = null; } };
     out.nparticles = n0;
-    return out;
+    return addStepAsync(out, lib, () => h);
 }
 
 exports.makeCylindricalParticlePusher = function (spec) {
@@ -211,6 +232,12 @@ exports.makeCylindricalParticlePusher = function (spec) {
         precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
         sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'], geometry: [, 'string'], shape: [, 'string'],
     });
+    if (spec.devices !== undefined) {   // SURVEY 8(b) extension key: one process drives one GPU here; N GPUs are N processes (commInit)
+        if (!Array.isArray(spec.devices) || spec.devices.length !== 1 || typeof spec.devices[0] !== 'number') {
+            throw new Error(".devices <- one process drives one GPU: name one device and start one process per GPU (commUniqueId / commInit)");
+        }
+        spec = Object.assign({}, spec, { device: spec.devices[0] });
+    }
     if (spec.geometry !== undefined && spec.geometry !== 'cyl_rz' && spec.geometry !== 'cart3d') throw new Error(".geometry <- must be 'cyl_rz' or 'cart3d'");
     if (spec.shape !== undefined && spec.shape !== 'ref11' && spec.shape !== 'cic') throw new Error(".shape <- must be 'ref11' or 'cic'");
     if (spec.geometry === 'cart3d') return makeBox(spec, addon());
@@ -289,7 +316,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
     out.resetStats = function () { lib.resetStats(h); };
     out.destroy = function () { if (h) { lib.destroy(h); h = null; } };
     out.nparticles = n;
-    return out;
+    return addStepAsync(out, lib, () => h);
 };
 
 exports.validate_object = validate_object;

@@ -281,6 +281,63 @@ static napi_value n_step(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+/* stepAsync(h, ncalls) -> Promise: fpic_step + fpic_sync on a libuv worker thread, so that Node's loop is not blocked
+ * while the GPU works ("Threading").  The handle is not thread-safe: the shim refuses other calls on the
+ * simulation until the promise has settled. */
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    fpic_handle* h;
+    int ncalls, rc;
+    char message[512];
+} step_job;
+
+static void step_execute(napi_env env, void* data)
+{
+    (void)env;
+    step_job* j = (step_job*)data;
+    j->rc = fpic_step(j->h, j->ncalls);
+    if (j->rc == FPIC_OK) j->rc = fpic_sync(j->h);
+    if (j->rc != FPIC_OK) {
+        const char* m = fpic_last_error(j->h);
+        strncpy(j->message, m ? m : "fpic_step failed", sizeof j->message - 1);
+        j->message[sizeof j->message - 1] = 0;
+    }
+}
+
+static void step_complete(napi_env env, napi_status status, void* data)
+{
+    step_job* j = (step_job*)data;
+    napi_value v;
+    if (status == napi_ok && j->rc == FPIC_OK) {
+        napi_get_undefined(env, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg;
+        napi_create_string_utf8(env, status == napi_ok ? j->message : "the step was cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &v);
+        napi_reject_deferred(env, j->deferred, v);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+
+static napi_value n_step_async(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2]; fpic_handle* h; double n;
+    if (!get_args(env, info, 2, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &n)) return NULL;
+    step_job* j = (step_job*)calloc(1, sizeof *j);
+    if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    j->h = h; j->ncalls = (int)n;
+    napi_value promise, name;
+    NAPI_OK(env, napi_create_promise(env, &j->deferred, &promise));
+    NAPI_OK(env, napi_create_string_utf8(env, "fusionpic.step", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(env, napi_create_async_work(env, NULL, name, step_execute, step_complete, j, &j->work));
+    NAPI_OK(env, napi_queue_async_work(env, j->work));
+    return promise;
+}
+
 static napi_value n_profile(napi_env env, napi_callback_info info)
 {
     napi_value argv[2]; fpic_handle* h; double on;
@@ -623,7 +680,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "create", n_create }, { "destroy", n_destroy }, { "setParticles", n_set_particles },
         { "setGrid", n_set_grid }, { "setRandomState", n_set_random_state }, { "addCurrentLoop", n_add_current_loop },
         { "addCurrentZ", n_add_current_z }, { "addBZ", n_add_bz }, { "addBTheta", n_add_btheta },
-        { "precalc", n_precalc }, { "step", n_step }, { "density", n_density }, { "deposit", n_deposit },
+        { "precalc", n_precalc }, { "step", n_step }, { "stepAsync", n_step_async }, { "density", n_density }, { "deposit", n_deposit },
         { "densityFinish", n_density_finish }, { "readGrid", n_read_grid }, { "getParticles", n_get_particles },
         { "getCells", n_get_cells }, { "sort", n_sort }, { "sync", n_sync }, { "profile", n_profile },
         { "getStats", n_get_stats }, { "saveCheckpoint", n_save_checkpoint }, { "loadCheckpoint", n_load_checkpoint }, { "resetStats", n_reset_stats }, { "buildArch", n_build_arch },
