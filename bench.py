@@ -629,6 +629,7 @@ def main():
     ap.add_argument("--c4-solver", choices=["poisson_fft", "yee"], default="poisson_fft", help="--only-c4: 'yee' rehearses the full-EM decomposition (configs[4])")
     ap.add_argument("--c4-precision", choices=["fp32", "fp64"], default="fp32")
     ap.add_argument("--c4-ghost", type=int, default=4)
+    ap.add_argument("--sort-interval", type=int, default=0, help="development: fixed re-binning period in frames (0 = the adaptive trigger)")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
 
@@ -696,7 +697,7 @@ def main():
     def build(rng_mode, shape="ref11"):
         # counter mode: no gather hides the LDS atomics of the fused sums, so only the tile census and
         # the re-binning stay in the push there (spec.unfused_deposit = 2)
-        s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051, count=n_local if strong else 0,
+        s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051, count=n_local if strong else 0, sort_interval=args.sort_interval,
                                               fuse_deposit="census" if (rng_mode == "counter" or shape == "cic") else True, shape=shape)
         s_.setStream(stream.cuda_stream)
         s_.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
