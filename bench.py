@@ -629,6 +629,7 @@ def main():
     ap.add_argument("--c4-solver", choices=["poisson_fft", "yee"], default="poisson_fft", help="--only-c4: 'yee' rehearses the full-EM decomposition (configs[4])")
     ap.add_argument("--c4-precision", choices=["fp32", "fp64"], default="fp32")
     ap.add_argument("--c4-ghost", type=int, default=4)
+    ap.add_argument("--no-sink", action="store_true", help="development: no sink cells, hence no re-injected particles (ablation of the re-binning trigger)")
     ap.add_argument("--sort-interval", type=int, default=0, help="development: fixed re-binning period in frames (0 = the adaptive trigger)")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     args = ap.parse_args()
@@ -691,6 +692,8 @@ def main():
     if distributed:  # replicated tables must be identical on every rank
         _, _, entropy, _ = synthetic_inputs(1, spec, 0x5EEDF051)
     sink, pdf = scene_grids(spec["nr"], spec["nz"])
+    if args.no_sink:
+        sink = np.ones_like(sink)
 
     stream = torch.cuda.Stream(device=local_rank)
 
