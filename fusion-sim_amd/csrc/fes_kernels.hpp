@@ -1218,8 +1218,16 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
                         T e[4], bb[4];
                         if (s0 >= 0) {
                             const int sl = s0 + aa + W * b + W * W * c;
+#if defined(FES_ABL_EM) && (FES_ABL_EM & 2)   // development probe (timing only): no E gather
+                            e[0] = e[1] = e[2] = e[3] = static_cast<T>(sl);
+#else
                             load4_lds3(lE + 4 * sl, e);
+#endif
+#if defined(FES_ABL_EM) && (FES_ABL_EM & 1)   // development probe (timing only): no B gather
+                            bb[0] = bb[1] = bb[2] = bb[3] = static_cast<T>(0);
+#else
                             load4_lds3(lB + 4 * sl, bb);
+#endif
                         } else {
                             const int ii = (i + aa == a.nx) ? 0 : i + aa, jj = (j + b == a.ny) ? 0 : j + b, kk = (k + c == a.nz) ? 0 : k + c;
                             const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(a.nx) * (static_cast<size_t>(jj) + static_cast<size_t>(a.ny) * kk);
@@ -1280,7 +1288,11 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
             };
             if (same) {
                 // both half-segments lie in one cell: their fluxes add up to the whole segment's, exactly
+#if defined(FES_ABL_EM) && (FES_ABL_EM & 4)       // development probe (timing only): no current deposit in the common case
+                if (sa >= 0) { if (from[0] == 0x7fffffff) lJ[sa] = 1ull; }
+#else
                 if (sa >= 0) current_cell_fast<T>(from, to, ca, sa, a.Z, lJ);
+#endif
                 else global_segment(from, to, ca);
             } else {
                 const int sb = em_slot<T>(cb[0], cb[1], cb[2], ox, oy, oz, a.nx, a.ny, a.nz);
