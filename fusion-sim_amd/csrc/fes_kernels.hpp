@@ -1270,17 +1270,17 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
             bool same = true;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                const int box = nn[m] * S;
+                const int box = nn[m] * S, half = nn[m] * (S / 2); // (2 dd > box  <=>  dd > box / 2: box is even)
                 int dd = to[m] - from[m];
-                if (2 * static_cast<long long>(dd) > box) dd -= box;
-                else if (2 * static_cast<long long>(dd) < -static_cast<long long>(box)) dd += box;
+                if (dd > half) dd -= box;
+                else if (dd < -half) dd += box;
                 to[m] = from[m] + dd;
                 ca[m] = from[m] >> 15;   // floor division by S (arithmetic shift)
                 cb[m] = to[m] >> 15;
                 same &= ca[m] == cb[m];
-                r[m] = (ca[m] == cb[m]) ? (from[m] + to[m]) / 2 : (ca[m] > cb[m] ? ca[m] : cb[m]) * S;
             }
-            const int sa = em_slot<T>(ca[0], ca[1], ca[2], ox, oy, oz, a.nx, a.ny, a.nz);
+            // (the cell the particle was gathered in, unless a weight rounded up to a whole cell)
+            const int sa = (ca[0] == i && ca[1] == j && ca[2] == k) ? s0 : em_slot<T>(ca[0], ca[1], ca[2], ox, oy, oz, a.nx, a.ny, a.nz);
             auto global_segment = [&](const int (&p1)[3], const int (&p2)[3], const int (&cell)[3]) {
                 const long long q1[3] = { p1[0], p1[1], p1[2] }, q2[3] = { p2[0], p2[1], p2[2] }, cc[3] = { cell[0], cell[1], cell[2] };
                 current_segment(q1, q2, cc, a.nx, a.ny, a.nz, a.Z, a.Jfix);
@@ -1295,6 +1295,8 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
 #endif
                 else global_segment(from, to, ca);
             } else {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) r[m] = (ca[m] == cb[m]) ? (from[m] + to[m]) / 2 : (ca[m] > cb[m] ? ca[m] : cb[m]) * S;
                 const int sb = em_slot<T>(cb[0], cb[1], cb[2], ox, oy, oz, a.nx, a.ny, a.nz);
                 if (sa >= 0) current_cell<T>(from, r, ca, sa, a.Z, lJ);
                 else global_segment(from, r, ca);
