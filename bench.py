@@ -722,10 +722,30 @@ def main():
         # the library's own communicator: rank 0 draws the RCCL id, the host hands it round (here over the
         # launcher's process group; a JavaScript host uses a file or its own channel), and density() then
         # all-reduces the per-cell sums inside libfusionpic.so on a side stream, overlapped with the next push
-        box = [fp.commUniqueId() if rank == 0 else None]
+        comm_note = None
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = fp.commUniqueId()
+            except Exception as e:  # e.g. no RCCL to bind: every rank falls back together
+                box[0] = "error: %s" % e
         dist.broadcast_object_list(box, src=0)
-        sim.commInit(box[0], rank, world, overlap=not args.no_overlap)
-    elif distributed:
+        ok = 0
+        if isinstance(box[0], bytes):
+            try:
+                sim.commInit(box[0], rank, world, overlap=not args.no_overlap)
+                ok = 1
+            except Exception as e:
+                comm_note = str(e)
+        else:
+            comm_note = box[0]
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:  # the same exchange through torch.distributed (fusionpic.multi), on every rank
+            if ok:
+                sim.commDestroy()
+            args.comm = "torch (the library communicator could not be set up: %s)" % (comm_note or "on another rank")
+    if distributed and args.comm != "lib":
         from fusionpic.multi import ShardedPusher, device_tensor_view
         ptr, nbytes = sim.deviceBuffer()
         sums = device_tensor_view(ptr, nbytes, torch.device("cuda", local_rank))
@@ -785,7 +805,7 @@ def main():
                 "particles_per_gpu": n_local, "grid": [spec["nr"], spec["nz"]],
                 "parallelism": "particle shards x%d (%s), replicated grid, one all-reduce of the per-cell sums per frame (%s)"
                                % (world, "fixed total of %d" % n_total if strong else "fixed per GPU",
-                                  "library RCCL communicator" if args.comm == "lib" else "torch.distributed"),
+                                  "library RCCL communicator" if args.comm == "lib" else "torch.distributed: " + args.comm),
             },
             "roofline": {
                 "bound": "hbm",
