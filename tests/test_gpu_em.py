@@ -317,3 +317,52 @@ def test_slab_decomposed_em_from_precalc(fp, eo, precision):
         ranks[0].density()
     for s in ranks + [one]:
         s.destroy()
+
+
+def test_large_decomposed_em_is_bit_identical_to_one_handle(fp, eo):
+    """1.2e7 electrons on a 64 x 64 x 128 Yee lattice over 8 in-process ranks (1.5e6 per rank: the staged two-level
+    binning of the 8^3-cell tiles), migration every 4 sub-steps, from precalc(): after 4 frames the current grid and both
+    lattice fields on every rank's planes and every particle are bit-identical to one handle's."""
+    world, shape = 8, (64, 64, 128)
+    L = (0.064, 0.064, 0.128)
+    n = 12_000_000
+    dt = cfl_dt(shape, L, 0.5)
+    dens = (0.05 / dt) ** 2 * eo.EPS0 * ME / QE ** 2
+    spec = em_spec(shape, L, n, dt, macro_weight=dens * np.prod(L) / n)
+    rng = np.random.Generator(np.random.Philox(5))
+    nzl = shape[2] // world
+    z = np.sort(rng.random(n, dtype=np.float32)) * np.float32(L[2] * (1 - 1e-6))
+    pos = np.stack([rng.random(n, dtype=np.float32) * np.float32(L[0]), rng.random(n, dtype=np.float32) * np.float32(L[1]), z], axis=1)
+    vel = rng.standard_normal((n, 3), dtype=np.float32) * np.float32(0.2)          # 0.06 cells per sub-step
+    counts = np.bincount(np.floor(z.astype(np.float64) / L[2] * shape[2]).astype(int) // nzl, minlength=world)
+    one = fp.makeCylindricalParticlePusher(spec)
+    one.set(position=pos, velocity=vel)
+    one.addB(0.0, 0.0, 0.02)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=int(counts.max() * 1.2)))
+        s.domainInit(r, world, ghost_planes=2, migrate_every=4)
+        first = int(counts[:r].sum())
+        s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
+        s.addB(0.0, 0.0, 0.02)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+    for _ in range(4):
+        one.step(); group.step()
+    for which in (fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B):
+        ref = one.readField(which).reshape(shape[2], -1)
+        for r, s in enumerate(ranks):
+            got = s.readField(which).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl]
+            assert (np.array_equal if which == fp.F3_J_FIXED else same_bits)(got, ref[r * nzl:(r + 1) * nzl]), (which, r)
+    parts = [s.domainGet() for s in ranks]
+    ids = np.concatenate([p["ids"] for p in parts])
+    order = np.argsort(ids)
+    assert np.array_equal(ids[order], np.arange(n, dtype=np.uint32))
+    ref = one.getParticles()
+    assert same_bits(np.concatenate([p["position"] for p in parts])[order], ref["position"])
+    assert same_bits(np.concatenate([p["velocity"] for p in parts])[order], ref["velocity"])
+    stats = [s.domainStats() for s in ranks]
+    assert sum(s["migrated"] for s in stats) > 1000 and all(s["lost"] == 0 for s in stats)
+    for s in ranks + [one]:
+        s.destroy()

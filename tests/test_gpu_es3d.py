@@ -691,3 +691,62 @@ def test_plasma_box_example_from_node():
     res = json.loads(out.decode().strip().splitlines()[-1])
     assert res["particles"] == 16 ** 3 * 8 and res["updates"] == 300 * res["particles"]
     assert res["relative_error"] < 1e-2, res
+
+
+def test_large_decomposed_box_is_bit_identical_to_one_handle(fp, eo):
+    """2e7 electrons + 4e6 ions on 128^3 nodes over 8 in-process ranks (each rank's population is above the 2^20 limit of
+    the staged two-level binning, migration rides on the fused re-binning, slab-decomposed solve off so that the fields
+    are bit-comparable): after 6 frames the charge grid on every rank's planes, the field and every particle are
+    bit-identical to one handle's; particles migrated, none outran the ghost planes."""
+    world, shape = 8, (128, 128, 128)
+    L = (0.128, 0.128, 0.128)
+    n, ni = 20_000_000, 4_000_000
+    spec = box_spec(shape, L, count=n, dt=2e-12, macro_weight=1e15 * np.prod(L) / n)
+    rng = np.random.Generator(np.random.Philox(77))
+    nzl = shape[2] // world
+
+    def population(m, vth):
+        # sorted by slab so that global indices are contiguous per rank
+        z = np.sort(rng.random(m, dtype=np.float32)) * np.float32(L[2] * (1 - 1e-6))
+        p = np.stack([rng.random(m, dtype=np.float32) * np.float32(L[0]), rng.random(m, dtype=np.float32) * np.float32(L[1]), z], axis=1)
+        v = rng.standard_normal((m, 3), dtype=np.float32) * np.float32(vth)
+        counts = np.bincount(np.floor(z.astype(np.float64) / L[2] * shape[2]).astype(int) // nzl, minlength=world)
+        return p, v, counts
+
+    pe, ve, ce = population(n, 0.02)          # ~0.12 cells per sub-step along z
+    pi, vi, ci = population(ni, 5e-4)
+    one = fp.makeCylindricalParticlePusher(spec)
+    one.addSpecies(MP, -QE, ni)
+    one.set(position=pe, velocity=ve); one.set(position=pi, velocity=vi, species=1)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=int(ce.max() * 1.2)))
+        s.addSpecies(MP, -QE, int(ci.max() * 1.2))
+        s.domainInit(r, world, ghost_planes=2, migrate_every=4)
+        fe, fi = int(ce[:r].sum()), int(ci[:r].sum())
+        s.domainSet(pe[fe:fe + ce[r]], ve[fe:fe + ce[r]], first_id=fe)
+        s.domainSet(pi[fi:fi + ci[r]], vi[fi:fi + ci[r]], first_id=fi, species=1)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+    for _ in range(6):
+        one.step(); group.step()
+    f1 = one.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+    e1 = one.readField(fp.F3_E)
+    for r, s in enumerate(ranks):
+        fr = s.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+        assert np.array_equal(fr[r * nzl:(r + 1) * nzl], f1[r * nzl:(r + 1) * nzl]), r
+        assert same_bits(s.readField(fp.F3_E), e1), r
+    for sp, total in ((0, n), (1, ni)):
+        parts = [s.domainGet(species=sp) for s in ranks]
+        ids = np.concatenate([p["ids"] for p in parts])
+        order = np.argsort(ids)
+        assert len(ids) == total and np.array_equal(ids[order], np.arange(total, dtype=np.uint32)), sp
+        ref = one.getParticles(species=sp)
+        assert same_bits(np.concatenate([p["position"] for p in parts])[order], ref["position"]), sp
+        assert same_bits(np.concatenate([p["velocity"] for p in parts])[order], ref["velocity"]), sp
+    stats = [s.domainStats() for s in ranks]
+    assert sum(s["migrated"] for s in stats) > 10000 and all(s["lost"] == 0 for s in stats)
+    assert int(f1.astype(object).sum()) == (n - ni) * eo.FIXED_ONE
+    for s in ranks + [one]:
+        s.destroy()
