@@ -1725,6 +1725,10 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     if (st->nz % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d planes along z do not divide into %d slabs", st->nz, world);
     const int nzl = st->nz / world;
     if (ghost_planes < 1 || ghost_planes >= nzl) return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- must lie in [1, %d)", nzl);
+    // two slabs are each other's lower AND upper neighbour: the G planes below and the G + 1 planes above a slab must be
+    // different planes of the other one
+    if (world == 2 && 2 * ghost_planes + 1 > nzl)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- with two slabs of %d planes at most %d ghost planes", nzl, (nzl - 1) / 2);
     if (migrate_every < 1) return fail(h, FPIC_ERR_INVALID_ARG, ".migrate_every <- must be at least 1");
     if (st->solver == FPIC_SOLVER_YEE && world > 1 && 2 * (ghost_planes + 2) > nzl)
         return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- the full-EM mode keeps ghost_planes + 2 halo planes per side: a slab of %d planes holds at most %d ghost planes",

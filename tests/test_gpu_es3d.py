@@ -750,3 +750,89 @@ def test_large_decomposed_box_is_bit_identical_to_one_handle(fp, eo):
     assert int(f1.astype(object).sum()) == (n - ni) * eo.FIXED_ONE
     for s in ranks + [one]:
         s.destroy()
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_decomposition_randomised(fp, eo, monkeypatch, seed):
+    """Random decompositions against one handle, frame by frame: world 2..8, 1..3 ghost planes, migration every 1..5
+    sub-steps, one or two species, with or without B, either precision, populations spread unevenly over the slabs (some
+    slabs nearly empty), the staged binning forced on half of the cases.  Velocities are bounded so that no particle can
+    outrun the ghost planes between two migrations; everything must stay bit-identical."""
+    rng = np.random.default_rng(1000 + seed)
+    if seed % 2:
+        monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    precision = "fp32" if rng.random() < 0.6 else "fp64"
+    world = int(rng.choice([2, 3, 4, 6, 8]))
+    G = int(rng.integers(1, 4))
+    every = int(rng.integers(1, 6))
+    nzl = int(rng.integers((2 * G + 1) if world == 2 else (G + 1), 12))   # (two slabs: ghost ranges must not overlap)
+    shape = (int(rng.integers(6, 40)), int(rng.integers(6, 40)), world * nzl)
+    L = tuple(1e-3 * s for s in shape)
+    dt = 5e-12
+    n = int(rng.integers(2000, 40000))
+    spec = box_spec(shape, L, count=n, dt=dt, macro_weight=1e15 * np.prod(L) / n, solver="poisson_fft" if rng.random() < 0.7 else "none")
+    # |v_z| dt c * every < G cells  (with a margin); x and y are free
+    vmax = 0.8 * G * 1e-3 / (every * dt * 2.998e8)
+    two = rng.random() < 0.5
+    pops = []
+    for m in ((n, n // 3) if two else (n,)):
+        # uneven over the slabs: a power of a uniform deviate piles the particles up at low z
+        z = (rng.random(m) ** float(rng.choice([1.0, 2.5, 6.0]))) * L[2] * (1 - 1e-9)
+        p = np.stack([rng.random(m) * L[0], rng.random(m) * L[1], z], axis=1)
+        v = np.stack([rng.normal(0, 0.05, m), rng.normal(0, 0.05, m), rng.uniform(-vmax, vmax, m)], axis=1)
+        owner = np.floor(p[:, 2] / L[2] * shape[2]).astype(int) // nzl
+        order = np.argsort(owner, kind="stable")
+        pops.append((p[order], v[order], np.bincount(owner, minlength=world)))
+    E = rng.normal(0, 2e4, shape + (3,))
+    with_b = rng.random() < 0.5
+
+    def build(count, r=None):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=count), precision=precision)
+        if two:
+            s.addSpecies(MP, -QE, n // 3)
+        if r is not None:
+            s.domainInit(r, world, ghost_planes=G, migrate_every=every, distributed_solve=False)
+        if spec["solver"] == "none":
+            s.set(E=E)
+        if with_b:
+            s.addB(0.02, -0.01, 0.05)
+        return s
+
+    one = build(n)
+    for sp, (p, v, _) in enumerate(pops):
+        one.set(position=p, velocity=v, species=sp)
+    ranks = []
+    for r in range(world):
+        s = build(4 * n, r)      # (capacity; the migration messages hold a quarter of it)
+        for sp, (p, v, c) in enumerate(pops):
+            first = int(c[:r].sum())
+            if c[r]:
+                s.domainSet(p[first:first + c[r]], v[first:first + c[r]], first_id=first, species=sp)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+    for frame in range(5):
+        one.step(); group.step()
+        f1 = one.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+        for r, s in enumerate(ranks):
+            fr = s.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+            assert np.array_equal(fr[r * nzl:(r + 1) * nzl], f1[r * nzl:(r + 1) * nzl]), (frame, r)
+        for sp, (p, _, _) in enumerate(pops):
+            parts = [s.domainGet(species=sp) for s in ranks]
+            ids = np.concatenate([q["ids"] for q in parts])
+            order = np.argsort(ids)
+            assert np.array_equal(ids[order], np.arange(len(p))), (frame, sp)
+            ref = one.getParticles(species=sp)
+            assert same_bits(np.concatenate([q["position"] for q in parts])[order], ref["position"]), (frame, sp)
+            assert same_bits(np.concatenate([q["velocity"] for q in parts])[order], ref["velocity"]), (frame, sp)
+    assert all(s.domainStats()["lost"] == 0 for s in ranks)
+    for s in ranks + [one]:
+        s.destroy()
+
+
+def test_two_slabs_refuse_overlapping_ghost_ranges(fp):
+    s = fp.makeCylindricalParticlePusher(box_spec((8, 8, 8), (1.0, 1.0, 1.0), count=10))
+    with pytest.raises(fp.FusionPicError, match="at most 1 ghost planes"):
+        s.domainInit(0, 2, ghost_planes=2, migrate_every=1)          # slabs of 4 planes: 2 below + 3 above do not fit
+    s.domainInit(0, 2, ghost_planes=1, migrate_every=1)
+    s.destroy()
