@@ -366,3 +366,73 @@ def test_large_decomposed_em_is_bit_identical_to_one_handle(fp, eo):
     assert sum(s["migrated"] for s in stats) > 1000 and all(s["lost"] == 0 for s in stats)
     for s in ranks + [one]:
         s.destroy()
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_em_decomposition_randomised(fp, eo, seed):
+    """Random full-EM decompositions against one handle: world 2..6, 1..3 ghost planes, migration every 1..6 sub-steps,
+    one or two species, uneven populations, either precision, random lattice fields; currents, fields and particles
+    bit-identical after every frame."""
+    rng = np.random.default_rng(2000 + seed)
+    precision = "fp32" if rng.random() < 0.5 else "fp64"
+    world = int(rng.choice([2, 3, 4, 6]))
+    G = int(rng.integers(1, 4))
+    every = int(rng.integers(1, 7))
+    nzl = int(rng.integers(2 * (G + 2), 2 * (G + 2) + 6))
+    shape = (int(rng.integers(6, 24)), int(rng.integers(6, 24)), world * nzl)
+    L = tuple(1e-3 * s for s in shape)
+    dt = cfl_dt(shape, L, 0.5)
+    n = int(rng.integers(3000, 30000))
+    spec = em_spec(shape, L, n, dt, macro_weight=1e6)
+    vmax = min(0.9, 0.8 * G * 1e-3 / (every * dt * C))
+    two = rng.random() < 0.5
+    pops = []
+    for m in ((n, n // 4) if two else (n,)):
+        z = (rng.random(m) ** float(rng.choice([1.0, 3.0]))) * L[2] * (1 - 1e-9)
+        p = np.stack([rng.random(m) * L[0], rng.random(m) * L[1], z], axis=1)
+        v = np.stack([rng.normal(0, 0.2, m), rng.normal(0, 0.2, m), rng.uniform(-vmax, vmax, m)], axis=1)
+        owner = np.floor(p[:, 2] / L[2] * shape[2]).astype(int) // nzl
+        order = np.argsort(owner, kind="stable")
+        pops.append((p[order], v[order], np.bincount(owner, minlength=world)))
+    E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
+
+    def build(count, r=None):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=count), precision=precision)
+        if two:
+            s.addSpecies(1836 * ME, -2 * QE, n // 4)
+        if r is not None:
+            s.domainInit(r, world, ghost_planes=G, migrate_every=every)
+        return s
+
+    one = build(n)
+    for sp, (p, v, _) in enumerate(pops):
+        one.set(position=p, velocity=v, species=sp)
+    one.set(edge_E=E, face_B=B)
+    ranks = []
+    for r in range(world):
+        s = build(4 * n, r)
+        for sp, (p, v, c) in enumerate(pops):
+            first = int(c[:r].sum())
+            if c[r]:
+                s.domainSet(p[first:first + c[r]], v[first:first + c[r]], first_id=first, species=sp)
+        s.set(edge_E=E, face_B=B)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    for frame in range(4):
+        one.step(); group.step()
+        for which in (fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B):
+            ref = one.readField(which).reshape(shape[2], -1)
+            for r, s in enumerate(ranks):
+                got = s.readField(which).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl]
+                assert (np.array_equal if which == fp.F3_J_FIXED else same_bits)(got, ref[r * nzl:(r + 1) * nzl]), (frame, which, r)
+        for sp, (p, _, _) in enumerate(pops):
+            parts = [s.domainGet(species=sp) for s in ranks]
+            ids = np.concatenate([q["ids"] for q in parts])
+            order = np.argsort(ids)
+            assert np.array_equal(ids[order], np.arange(len(p))), (frame, sp)
+            ref = one.getParticles(species=sp)
+            assert same_bits(np.concatenate([q["position"] for q in parts])[order], ref["position"]), (frame, sp)
+            assert same_bits(np.concatenate([q["velocity"] for q in parts])[order], ref["velocity"]), (frame, sp)
+    assert all(s.domainStats()["lost"] == 0 for s in ranks)
+    for s in ranks + [one]:
+        s.destroy()
