@@ -1216,3 +1216,24 @@ function scene(s) {
     assert out["ticks"] >= 3, "the event loop must have run while the step was in flight"
     assert "stepAsync() of this simulation is still running" in out["guard"]
     assert "precalc" in out["rejected"] and "one process drives one GPU" in out["devs"]
+
+
+@pytest.mark.parametrize("nr,nz,n", [(1, 1, 5), (31, 33, 4096), (33, 31, 4097), (1100, 40, 60000), (40, 1100, 60001), (1100, 1100, 250000)])
+def test_staged_binning_keeps_every_particle_rz(fp, monkeypatch, nr, nz, n):
+    """sort() of the (r,z) pusher through the staged scatter (forced): one tile, chunk size +- 1, long thin grids, and
+    1225 tiles (35 coarse groups of 35): read-back in the caller's order unchanged bit for bit, alive flags and cells too."""
+    monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    spec = make_spec(nr, nz, 2)
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=n)
+    sim = fp.makeCylindricalParticlePusher(spec, count=n)
+    sim.set(position=pos, velocity=vel)
+    sim.setRandomState(entropy, rand)
+    before, cells = sim.getParticles(rand=True), sim.getCells()
+    sim.sort()
+    after = sim.getParticles(rand=True)
+    for k in before:
+        assert same_bits(before[k], after[k]), k
+    assert np.array_equal(cells, sim.getCells())
+    sim.precalc(); sim.step(); sim.sort(); sim.step()
+    assert sim.getParticles()["position"].shape == (n, 3)
+    sim.destroy()
