@@ -863,3 +863,54 @@ def test_staged_binning_keeps_every_particle(fp, monkeypatch, shape, n):
     sim.sort()
     assert sim.getParticles()["position"].shape == (n, 3)
     sim.destroy()
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_distributed_solve_randomised(fp, eo, seed):
+    """Random slab-decomposed solves: world 2..8, grids whose rows divide over the ranks, odd and even nx, 1..3 ghost
+    planes, either precision.  Against one handle: the charge grid exact; phi and E within the two transforms' rounding;
+    particles after three frames within 1e-4 / 1e-9 of a cell."""
+    rng = np.random.default_rng(3000 + seed)
+    precision = "fp32" if rng.random() < 0.5 else "fp64"
+    world = int(rng.choice([2, 3, 4, 8]))
+    G = int(rng.integers(1, 4))
+    nzl = int(rng.integers(max(G + 2, 2 * G + 1 if world == 2 else 0), 11))   # (the decomposed solve needs G + 2 planes per slab)
+    shape = (int(rng.integers(5, 30)), world * int(rng.integers(1, 6)), world * nzl)
+    L = tuple(1e-3 * s for s in shape)
+    n = int(rng.integers(3000, 30000))
+    spec = box_spec(shape, L, count=n, dt=5e-12, macro_weight=1e15 * np.prod(L) / n)
+    pos = rng.random((n, 3)) * L
+    vel = rng.normal(0, 0.01, (n, 3))
+    owner = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
+    order = np.argsort(owner, kind="stable")
+    pos, vel, counts = pos[order], vel[order], np.bincount(owner, minlength=world)
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.set(position=pos, velocity=vel)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=2 * n), precision=precision)
+        s.domainInit(r, world, ghost_planes=G, migrate_every=2, distributed_solve=True)
+        first = int(counts[:r].sum())
+        s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+    tol = 5e-5 if precision == "fp32" else 1e-10
+    e1 = one.readField(fp.F3_E, np.float64).reshape(shape[2], -1, 4)
+    scale = np.abs(e1[..., :3]).max()
+    for r, s in enumerate(ranks):
+        assert np.array_equal(s.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl],
+                              one.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl])
+        er = s.readField(fp.F3_E, np.float64).reshape(shape[2], -1, 4)[r * nzl:(r + 1) * nzl]
+        assert np.abs(er[..., :3] - e1[r * nzl:(r + 1) * nzl, :, :3]).max() <= tol * scale, r
+    for _ in range(3):
+        one.step(); group.step()
+    parts = [s.domainGet(np.float64) for s in ranks]
+    ids = np.concatenate([p["ids"] for p in parts])
+    idx = np.argsort(ids)
+    assert np.array_equal(ids[idx], np.arange(n))
+    d = np.abs(np.concatenate([p["position"] for p in parts])[idx] - one.getParticles(np.float64)["position"])
+    d = np.minimum(d, 1 - d)
+    assert d.max() <= (1e-4 if precision == "fp32" else 1e-9)
+    for s in ranks + [one]:
+        s.destroy()
