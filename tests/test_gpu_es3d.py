@@ -914,3 +914,45 @@ def test_distributed_solve_randomised(fp, eo, seed):
     assert d.max() <= (1e-4 if precision == "fp32" else 1e-9)
     for s in ranks + [one]:
         s.destroy()
+
+
+@pytest.mark.parametrize("seed", list(range(14)))
+def test_box_randomised_against_the_oracle(fp, eo, monkeypatch, seed):
+    """Random boxes in a given field (solver 'none': everything integer or bit-comparable): grids from 2 x 2 x 2 to sizes
+    that are no multiple of the 16 x 16 x 8 tile, 1..3 species of random charge number and mass, with or without B,
+    sort_interval 0..3, either precision, fast particles (several cells per sub-step for some), the staged binning forced
+    on every third case; particles, cells and the int64 charge grid bit-identical to the oracle's after every frame."""
+    rng = np.random.default_rng(4000 + seed)
+    if seed % 3 == 0:
+        monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    precision = "fp32" if rng.random() < 0.5 else "fp64"
+    dtype = np.float32 if precision == "fp32" else np.float64
+    shape = tuple(int(x) for x in rng.integers(2, [70, 50, 40]))
+    L = tuple(float(x) for x in rng.uniform(0.5e-3, 2e-3, 3) * shape)
+    n = int(rng.integers(1, 30000))
+    spec = box_spec(shape, L, count=n, dt=float(rng.uniform(1e-12, 2e-11)), solver="none", macro_weight=float(rng.uniform(1, 1e5)))
+    sort_interval = int(rng.integers(0, 4))
+    sim = fp.makeCylindricalParticlePusher(spec, precision=precision, sort_interval=sort_interval)
+    ora = eo.OracleES3D(spec, dtype)
+    counts = [n]
+    for _ in range(int(rng.integers(0, 3))):
+        m, z, mass = int(rng.integers(1, 8000)), int(rng.choice([-2, -1, 1, 2, 3])), float(rng.choice([ME, MP, 4 * MP]))
+        assert sim.addSpecies(mass, z * QE, m) == ora.add_species(mass, z * QE, m)
+        counts.append(m)
+    for sp, m in enumerate(counts):
+        p = rng.random((m, 3)) * L
+        v = rng.normal(0, 0.02, (m, 3)) + rng.normal(0, 0.4, (m, 3)) * (rng.random((m, 1)) < 0.2)
+        sim.set(position=p, velocity=v, species=sp); ora.set(position=p, velocity=v, species=sp)
+    E = rng.normal(0, 5e4, shape + (3,))
+    sim.set(E=E); ora.set(E=E)
+    if rng.random() < 0.6:
+        b = rng.normal(0, 0.3, 3)
+        sim.addB(*b); ora.add_b(*b)
+    sim.precalc(); ora.precalc()
+    assert np.array_equal(sim.readField(fp.F3_RHO_FIXED), ora.rho_fixed)
+    for frame in range(4):
+        sim.step(); ora.step()
+        for sp in range(len(counts)):
+            assert_same_particles(sim, ora, species=sp, what="seed %d frame %d species %d" % (seed, frame, sp))
+        assert np.array_equal(sim.readField(fp.F3_RHO_FIXED), ora.rho_fixed), (seed, frame)
+    sim.destroy()
