@@ -436,3 +436,45 @@ def test_em_decomposition_randomised(fp, eo, seed):
     assert all(s.domainStats()["lost"] == 0 for s in ranks)
     for s in ranks + [one]:
         s.destroy()
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_em_randomised_against_the_oracle(fp, eo, monkeypatch, seed):
+    """Random full-EM runs in random lattice fields against the oracle: grids from 3 x 3 x 3 to sizes that are no multiple
+    of the 8^3 tile, 1..3 species, time steps up to the CFL limit, fast particles (every face-crossing pattern), either
+    precision, the staged binning forced on every other case: particles, the integer current, both lattice fields
+    bit-identical after every frame, and the lattice continuity equation exact."""
+    rng = np.random.default_rng(5000 + seed)
+    if seed % 2:
+        monkeypatch.setenv("FPIC_TWO_LEVEL_MIN", "1")
+    precision = "fp32" if rng.random() < 0.5 else "fp64"
+    dtype = np.float32 if precision == "fp32" else np.float64
+    shape = tuple(int(x) for x in rng.integers(3, [30, 26, 22]))
+    L = tuple(float(x) for x in rng.uniform(0.5e-3, 2e-3, 3) * shape)
+    n = int(rng.integers(1, 15000))
+    spec = em_spec(shape, L, n, cfl_dt(shape, L, float(rng.uniform(0.2, 0.95))), macro_weight=float(rng.uniform(1e3, 1e7)))
+    sim, ora = fp.makeCylindricalParticlePusher(spec, precision=precision), eo.OracleES3D(spec, dtype)
+    counts = [n]
+    for _ in range(int(rng.integers(0, 3))):
+        m, z, mass = int(rng.integers(1, 4000)), int(rng.choice([-2, -1, 1, 2])), float(rng.choice([ME, 1836 * ME]))
+        assert sim.addSpecies(mass, z * QE, m) == ora.add_species(mass, z * QE, m)
+        counts.append(m)
+    for sp, m in enumerate(counts):
+        p, v = rng.random((m, 3)) * L, rng.normal(0, float(rng.uniform(0.01, 0.5)), (m, 3))
+        sim.set(position=p, velocity=v, species=sp); ora.set(position=p, velocity=v, species=sp)
+    E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
+    sim.set(edge_E=E, face_B=B); ora.set_lattice(E=E, B=B)
+    sim.density(); ora.deposit()
+    for frame in range(3):
+        before = ora.rho_fixed.copy()
+        sim.step(); ora.step()
+        for sp in range(len(counts)):
+            got = sim.getParticles(species=sp)
+            assert same_bits(got["position"], ora.positions(sp)) and same_bits(got["velocity"], ora.velocities(sp)), (seed, frame, sp)
+        J = sim.readField(fp.F3_J_FIXED).ravel()
+        assert np.array_equal(J, ora.J_fixed), (seed, frame)
+        assert same_bits(sim.readField(fp.F3_EDGE_E).ravel(), ora.Ey) and same_bits(sim.readField(fp.F3_FACE_B).ravel(), ora.By), (seed, frame)
+        sim.density(); ora.deposit()
+        fixed = sim.readField(fp.F3_RHO_FIXED)
+        assert np.array_equal(fixed, ora.rho_fixed), (seed, frame)
+    sim.destroy()
