@@ -64,7 +64,14 @@ const Rccl& rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         static const char* const names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr };
-        void* lib = open_first(names, r.why);
+        void* lib = nullptr;
+        // FPIC_RCCL_LIBRARY names the RCCL build to bind (the tests bind an in-process stand-in, tests/fake_rccl)
+        if (const char* over = std::getenv("FPIC_RCCL_LIBRARY"); over && *over) {
+            lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) { const char* e = dlerror(); r.why = std::string(over) + ": " + (e ? e : "dlopen failed"); }
+        } else {
+            lib = open_first(names, r.why);
+        }
         if (!lib) return;
         bool ok = bind(lib, "ncclGetUniqueId", r.GetUniqueId, r.why);
         ok &= bind(lib, "ncclCommInitRank", r.CommInitRank, r.why);

@@ -1,0 +1,224 @@
+// fake_rccl.cpp — TEST INFRASTRUCTURE: an in-process stand-in for the ten RCCL entry points libfusionpic.so binds
+// (csrc/fpic_dyn.cpp), so that the library's RCCL transport — one handle per rank, grouped ncclSend/ncclRecv of the
+// decomposition, ncclAllGather / ncclAllReduce — can be driven by N threads of ONE process on ONE GPU, where the real
+// RCCL refuses two ranks on one device.  Bound through FPIC_RCCL_LIBRARY by tests/test_gpu_fake_rccl.py only.
+//
+// Semantics kept: ranks of a communicator meet by its unique id; between a pair of ranks the k-th send matches the k-th
+// receive in issue order; operations of a group take effect at ncclGroupEnd; every call is collective in the sense that
+// all ranks issue the same sequence.  Simplification: operations complete synchronously (the caller's stream is drained
+// first, the copy is a blocking device-to-device copy), which is stricter than stream-ordered execution.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Message {
+    const void* ptr;
+    size_t bytes;
+};
+
+struct World {
+    int nranks = 0, joined = 0, left = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long generation = 0;
+    std::map<std::pair<int, int>, std::deque<Message>> mailbox; // (from, to) -> sends in issue order
+    std::vector<const void*> published;                          // collectives: every rank's send buffer
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long g = generation;
+        if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
+struct Comm {
+    World* w;
+    int rank;
+};
+
+std::mutex g_m;
+std::map<std::string, World*> g_worlds;
+
+struct Op {
+    bool send;
+    const void* sptr;
+    void* rptr;
+    size_t bytes;
+    int peer;
+    Comm* comm;
+    hipStream_t stream;
+};
+thread_local int t_depth = 0;
+thread_local std::vector<Op> t_ops;
+
+size_t type_size(ncclDataType_t t)
+{
+    switch (t) {
+    case ncclInt8: case ncclUint8: return 1;
+    case ncclFloat16: case ncclBfloat16: return 2;
+    case ncclInt32: case ncclUint32: case ncclFloat32: return 4;
+    default: return 8;
+    }
+}
+
+ncclResult_t run(std::vector<Op>& ops)
+{
+    if (ops.empty()) return ncclSuccess;
+    Comm* c = ops[0].comm;
+    World* w = c->w;
+    for (const Op& o : ops)
+        if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        for (const Op& o : ops)
+            if (o.send) w->mailbox[{ c->rank, o.peer }].push_back({ o.sptr, o.bytes });
+    }
+    w->barrier();
+    ncclResult_t rc = ncclSuccess;
+    for (const Op& o : ops) {
+        if (o.send) continue;
+        Message msg{};
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            auto& q = w->mailbox[{ o.peer, c->rank }];
+            if (q.empty()) { rc = ncclInvalidUsage; continue; }   // a receive nobody sent for
+            msg = q.front();
+            q.pop_front();
+        }
+        if (msg.bytes != o.bytes) { rc = ncclInvalidArgument; continue; }
+        if (hipMemcpy(o.rptr, msg.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+    }
+    w->barrier();
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id)
+{
+    std::random_device rd;
+    std::memset(id, 0, sizeof *id);
+    for (int k = 0; k < 16; ++k) id->internal[k] = static_cast<char>('a' + rd() % 26);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank)
+{
+    if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    World* w;
+    {
+        std::lock_guard<std::mutex> lk(g_m);
+        World*& slot = g_worlds[std::string(id.internal, 16)];
+        if (!slot) { slot = new World(); slot->nranks = nranks; }
+        w = slot;
+        if (w->nranks != nranks) return ncclInvalidArgument;
+        ++w->joined;
+    }
+    Comm* c = new Comm{ w, rank };
+    w->barrier(); // every rank has joined
+    *comm = reinterpret_cast<ncclComm_t>(c);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm)
+{
+    delete reinterpret_cast<Comm*>(comm);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupStart() { ++t_depth; return ncclSuccess; }
+
+ncclResult_t ncclGroupEnd()
+{
+    if (t_depth <= 0) return ncclInvalidUsage;
+    if (--t_depth) return ncclSuccess;
+    std::vector<Op> ops;
+    ops.swap(t_ops);
+    return run(ops);
+}
+
+ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    t_ops.push_back({ true, buf, nullptr, count * type_size(type), peer, reinterpret_cast<Comm*>(comm), stream });
+    if (t_depth) return ncclSuccess;
+    std::vector<Op> ops;
+    ops.swap(t_ops);
+    return run(ops);
+}
+
+ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    t_ops.push_back({ false, nullptr, buf, count * type_size(type), peer, reinterpret_cast<Comm*>(comm), stream });
+    if (t_depth) return ncclSuccess;
+    std::vector<Op> ops;
+    ops.swap(t_ops);
+    return run(ops);
+}
+
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t type, ncclComm_t comm, hipStream_t stream)
+{
+    Comm* c = reinterpret_cast<Comm*>(comm);
+    World* w = c->w;
+    const size_t bytes = sendcount * type_size(type);
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->published.resize(w->nranks);
+        w->published[c->rank] = sendbuff;
+    }
+    w->barrier();
+    ncclResult_t rc = ncclSuccess;
+    for (int q = 0; q < w->nranks; ++q) {
+        char* dst = static_cast<char*>(recvbuff) + q * bytes;
+        if (dst == w->published[q]) continue; // in place
+        if (hipMemcpy(dst, w->published[q], bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+    }
+    w->barrier();
+    return rc;
+}
+
+// sum of float / double buffers, through the host (tests only: sizes of a few megabytes)
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream)
+{
+    if (op != ncclSum || (type != ncclFloat32 && type != ncclFloat64)) return ncclInvalidArgument;
+    Comm* c = reinterpret_cast<Comm*>(comm);
+    World* w = c->w;
+    const size_t bytes = count * type_size(type);
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->published.resize(w->nranks);
+        w->published[c->rank] = sendbuff;
+    }
+    w->barrier();
+    std::vector<char> acc(bytes), one(bytes);
+    ncclResult_t rc = ncclSuccess;
+    for (int q = 0; q < w->nranks; ++q) { // rank order: every rank forms the same sum
+        if (hipMemcpy(one.data(), w->published[q], bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = ncclUnhandledCudaError;
+        if (q == 0) acc = one;
+        else if (type == ncclFloat32) for (size_t i = 0; i < count; ++i) reinterpret_cast<float*>(acc.data())[i] += reinterpret_cast<float*>(one.data())[i];
+        else for (size_t i = 0; i < count; ++i) reinterpret_cast<double*>(acc.data())[i] += reinterpret_cast<double*>(one.data())[i];
+    }
+    w->barrier(); // everybody has read the inputs: in-place outputs may be written now
+    if (hipMemcpy(recvbuff, acc.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+    w->barrier();
+    return rc;
+}
+
+const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake_rccl: error"; }
+
+} // extern "C"

@@ -1,0 +1,200 @@
+"""The library's RCCL TRANSPORT (one handle per rank, fpic_comm_init + fpic_domain_init, every exchange issued by
+fpic_precalc / fpic_step as grouped ncclSend/ncclRecv, ncclAllGather, ncclAllReduce) with more than one rank — on one
+GPU.  The real RCCL refuses two ranks on one device, so the ranks are THREADS of one process and the ten RCCL entry
+points are served by an in-process stand-in (tests/fake_rccl/fake_rccl.cpp, bound through FPIC_RCCL_LIBRARY) that keeps
+RCCL's matching rule (k-th send of a pair meets its k-th receive, groups take effect at ncclGroupEnd).  What this
+checks is the library's side: message lists, sizes, order, in-place halos, world of two where both neighbours are the
+same rank.  Results must be bit-identical to one handle's (and to the in-process group transport's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+DRIVER = r'''
+import json, os, sys, threading
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "fusion-sim_amd"))
+import fusionpic as fp
+case = json.loads(sys.argv[2])
+world, shape, G, every = case["world"], tuple(case["shape"]), case["ghost"], case["every"]
+em, dist_solve, precision = case["em"], case["distributed_solve"], case["precision"]
+rng = np.random.default_rng(case["seed"])
+n = case["n"]
+L = tuple(1e-3 * s for s in shape)
+C = 2.998e8
+if em:
+    d = [L[a] / shape[a] for a in range(3)]
+    dt = 0.5 / (C * np.sqrt(sum(1 / x ** 2 for x in d)))
+else:
+    dt = 5e-12
+spec = dict(radius=L[0], length_y=L[1], height=L[2], nr=shape[0], ny=shape[1], nz=shape[2], dt=dt, nparticles=0, count=n,
+            particle_mass=9.109e-31, particle_charge=-1.602e-19, geometry="cart3d", solver="yee" if em else "poisson_fft",
+            macro_weight=1e15 * np.prod(L) / n)
+nzl = shape[2] // world
+pos = rng.random((n, 3)) * L
+vz = 0.7 * G * 1e-3 / (every * dt * C)
+vel = np.stack([rng.normal(0, 0.05, n), rng.normal(0, 0.05, n), rng.uniform(-min(vz, 0.9), min(vz, 0.9), n)], axis=1)
+owner = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
+order = np.argsort(owner, kind="stable")
+pos, vel, counts = pos[order], vel[order], np.bincount(owner, minlength=world)
+E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
+
+one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+one.set(position=pos, velocity=vel)
+if em:
+    one.set(edge_E=E, face_B=B)
+else:
+    one.precalc()
+frames = 4
+for _ in range(frames):
+    one.step()
+ref = one.getParticles()
+fields = [fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B] if em else [fp.F3_RHO_FIXED] + ([] if dist_solve else [fp.F3_E])
+ref_f = {w: one.readField(w).reshape(shape[2], -1) for w in fields}
+
+uid = fp.commUniqueId()
+out, err = [None] * world, [None] * world
+def rank_main(r):
+    try:
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=3 * n), precision=precision)
+        s.commInit(uid, r, world)
+        s.domainInit(r, world, ghost_planes=G, migrate_every=every, distributed_solve=dist_solve)
+        first = int(counts[:r].sum())
+        s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
+        if em:
+            s.set(edge_E=E, face_B=B)
+        else:
+            s.precalc()
+        for _ in range(frames):
+            s.step()
+        got = s.domainGet()
+        out[r] = (got, {w: s.readField(w).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl].copy() for w in fields}, s.domainStats())
+        s.destroy()
+    except Exception as e:  # a failed rank leaves the others waiting: the test's timeout ends them
+        err[r] = repr(e)
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+for t in threads: t.start()
+for t in threads: t.join()
+if any(err):
+    print(json.dumps({"error": err})); sys.exit(0)
+ids = np.concatenate([o[0]["ids"] for o in out])
+idx = np.argsort(ids)
+same = lambda a, b: a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+res = {"ids_ok": bool(np.array_equal(ids[idx], np.arange(n))),
+       "pos_same": bool(same(np.concatenate([o[0]["position"] for o in out])[idx], ref["position"])),
+       "vel_same": bool(same(np.concatenate([o[0]["velocity"] for o in out])[idx], ref["velocity"])),
+       "migrated": int(sum(o[2]["migrated"] for o in out)), "lost": int(sum(o[2]["lost"] for o in out)), "fields": {}}
+d = np.abs(np.concatenate([o[0]["position"] for o in out])[idx].astype(np.float64) - ref["position"].astype(np.float64)); d = np.minimum(d, 1 - d)
+res["pos_err"] = float(d.max())
+for w in fields:
+    res["fields"][str(w)] = all(bool(same(out[r][1][w], ref_f[w][r * nzl:(r + 1) * nzl])) for r in range(world))
+print(json.dumps(res))
+'''
+
+
+def build_fake(tmp_path):
+    so = tmp_path / "libfakerccl.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp"), "-o", str(so), "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    return so
+
+
+def run_case(tmp_path, **case):
+    so = build_fake(tmp_path)
+    env = dict(os.environ, FPIC_RCCL_LIBRARY=str(so))
+    raw = subprocess.check_output([sys.executable, "-c", DRIVER, ROOT, json.dumps(case)], env=env, timeout=300)
+    res = json.loads(raw.decode().strip().splitlines()[-1])
+    assert "error" not in res, res
+    return res
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape,ghost,every", [(2, (16, 12, 16), 2, 2), (3, (12, 16, 18), 1, 1), (4, (20, 12, 32), 3, 3)])
+def test_rccl_transport_electrostatic_replicated_solve(tmp_path, precision, world, shape, ghost, every):
+    res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=every, em=False, distributed_solve=False, precision=precision, n=20000, seed=world)
+    assert res["ids_ok"] and res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
+    assert res["migrated"] > 0 and res["lost"] == 0
+
+
+@pytest.mark.parametrize("world,shape,ghost", [(2, (16, 12, 16), 2), (4, (18, 16, 24), 2)])
+def test_rccl_transport_slab_decomposed_solve(tmp_path, world, shape, ghost):
+    res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=2, em=False, distributed_solve=True, precision="fp32", n=20000, seed=7)
+    assert res["ids_ok"] and all(res["fields"].values()) and res["pos_err"] <= 1e-4, res      # (another summation order in the solve)
+    assert res["migrated"] > 0 and res["lost"] == 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape,ghost,every", [(2, (12, 10, 16), 2, 2), (3, (10, 12, 30), 3, 4)])
+def test_rccl_transport_full_em(tmp_path, precision, world, shape, ghost, every):
+    res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=every, em=True, distributed_solve=False, precision=precision, n=15000, seed=11)
+    assert res["ids_ok"] and res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
+    assert res["migrated"] > 0 and res["lost"] == 0
+
+
+RZ_DRIVER = r'''
+import json, os, sys, threading
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "fusion-sim_amd"))
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import fusionpic as fp
+from helpers import make_spec, uniform_plasma, frame_sink
+world, overlap = int(sys.argv[2]), sys.argv[3] == "1"
+spec = make_spec(96, 80, 2, radius=1.0, height=2.0)
+n = 60000
+pos, vel, entropy, rand = uniform_plasma(n, spec, seed=5, v_th=5e-3)
+sink = frame_sink(96, 80)
+def build(lo, hi):
+    s = fp.makeCylindricalParticlePusher(spec, count=hi - lo)
+    s.set(position=pos[lo:hi], velocity=vel[lo:hi], sink_mask=sink, source_pdf=sink)
+    s.setRandomState(entropy, rand[lo:hi]); s.addBZ(0.02); s.precalc()
+    return s
+one = build(0, n)
+for _ in range(3):
+    one.step(); one.density()
+want, wantp = one.readDensity(np.float64), one.getParticles()
+uid = fp.commUniqueId()
+bounds = [n * r // world for r in range(world + 1)]
+out, err = [None] * world, [None] * world
+def rank_main(r):
+    try:
+        s = build(bounds[r], bounds[r + 1])
+        s.commInit(uid, r, world, overlap=overlap)
+        for _ in range(3):
+            s.step(); s.density()
+        out[r] = (s.readDensity(np.float64), s.getParticles()["position"])
+        s.destroy()
+    except Exception as e:
+        err[r] = repr(e)
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+for t in threads: t.start()
+for t in threads: t.join()
+if any(err):
+    print(json.dumps({"error": err})); sys.exit(0)
+g = out[0][0].reshape(-1, 4); w = want.reshape(-1, 4)
+ok = ~np.isnan(w[:, 3])
+res = {"count_err": float(np.abs(g[ok, 3] - w[ok, 3]).max() / np.abs(w[ok, 3]).max()),
+       "ranks_agree": bool(all(np.array_equal(np.nan_to_num(out[r][0]), np.nan_to_num(out[0][0])) for r in range(world))),
+       "particles_same": bool(np.array_equal(np.concatenate([o[1] for o in out]).view(np.uint8), wantp["position"].view(np.uint8)))}
+print(json.dumps(res))
+'''
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_transport_parity_mode_all_reduce(tmp_path, world, overlap):
+    """(r,z) reference-parity mode, SURVEY 8(e) row 1, with the library's communicator and `world` ranks as threads: every
+    rank ends up with the density of the WHOLE population (one ncclAllReduce of the per-cell sums per frame, on the side
+    stream when overlapping), equal on all ranks bit for bit and equal to one handle's up to the summation order; the
+    particles are those of one handle."""
+    so = build_fake(tmp_path)
+    env = dict(os.environ, FPIC_RCCL_LIBRARY=str(so))
+    raw = subprocess.check_output([sys.executable, "-c", RZ_DRIVER, ROOT, str(world), "1" if overlap else "0"], env=env, timeout=300)
+    res = json.loads(raw.decode().strip().splitlines()[-1])
+    assert "error" not in res, res
+    assert res["ranks_agree"] and res["particles_same"] and res["count_err"] <= 1e-5, res
