@@ -287,6 +287,7 @@ static napi_value n_step(napi_env env, napi_callback_info info)
 typedef struct {
     napi_async_work work;
     napi_deferred deferred;
+    napi_ref keep;   /* the handle's JS object stays alive (no finaliser) while the step runs */
     fpic_handle* h;
     int ncalls, rc;
     char message[512];
@@ -318,6 +319,7 @@ static void step_complete(napi_env env, napi_status status, void* data)
         napi_create_error(env, NULL, msg, &v);
         napi_reject_deferred(env, j->deferred, v);
     }
+    napi_delete_reference(env, j->keep);
     napi_delete_async_work(env, j->work);
     free(j);
 }
@@ -331,6 +333,7 @@ static napi_value n_step_async(napi_env env, napi_callback_info info)
     if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     j->h = h; j->ncalls = (int)n;
     napi_value promise, name;
+    if (napi_create_reference(env, argv[0], 1, &j->keep) != napi_ok) { free(j); napi_throw_error(env, NULL, "cannot reference the handle"); return NULL; }
     NAPI_OK(env, napi_create_promise(env, &j->deferred, &promise));
     NAPI_OK(env, napi_create_string_utf8(env, "fusionpic.step", NAPI_AUTO_LENGTH, &name));
     NAPI_OK(env, napi_create_async_work(env, NULL, name, step_execute, step_complete, j, &j->work));
