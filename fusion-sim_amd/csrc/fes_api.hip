@@ -94,6 +94,7 @@ struct Domain {
     // neighbours' current ghost planes arrive (3 int64 per node)
     int H = 0;
     long long* j_recv[2] = {};
+    bool halos_stale = false;           // lattice fields restored from a checkpoint: the halo planes are refreshed before the next sub-step
     unsigned* counts_dev = nullptr;     // down, up, lost, overflow | received from above, from below
     unsigned* counts_host = nullptr;    // pinned copy
     uint64_t migrated = 0, lost = 0;
@@ -1055,10 +1056,151 @@ int checkpoint_arrays(fpic_handle* h, FILE* f, bool save)
 
 } // namespace
 
+// ---- checkpoint of ONE RANK of a decomposition (every rank writes its own file): header, per species the particles the
+// rank holds now — global indices and raw state in slot order — and the state that cannot be recomputed: the lattice
+// fields of the rank's own planes (full EM) or the given field (solver 'none').  An electrostatic run with the Poisson
+// solve stores no field: after the load precalc() recomputes it from the particles, bit for bit.
+namespace {
+
+struct RankCheckpointHeader {
+    char magic[8];        // "FPICRNK1"
+    uint32_t version, precision, solver, nspecies;
+    int32_t nx, ny, nz, rank, world, ghost_planes;
+    uint32_t fields_ready, reserved;
+    double B0[3];
+    fpic_spec spec;
+};
+
+int rank_io(fpic_handle* h, FILE* f, void* dev, size_t bytes, bool save)
+{
+    std::vector<unsigned char> host(std::min<size_t>(bytes, size_t(64) << 20));
+    for (size_t off = 0; off < bytes; off += host.size()) {
+        const size_t m = std::min(host.size(), bytes - off);
+        if (save) {
+            HIP_TRY(h, hipMemcpyAsync(host.data(), static_cast<const char*>(dev) + off, m, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (std::fwrite(host.data(), 1, m, f) != m) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+        } else {
+            if (std::fread(host.data(), 1, m, f) != m) return fail(h, FPIC_ERR_STATE, "checkpoint read failed");
+            HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(dev) + off, host.data(), m, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+    }
+    return FPIC_OK;
+}
+
+// the field arrays a rank's file carries: (device pointer, first byte, bytes)
+std::vector<std::pair<char*, size_t>> rank_fields(const fpic_handle* h)
+{
+    const State* st = h->es;
+    const Domain& d = *st->dom;
+    const size_t t = h->prec == FPIC_F32 ? 4 : 8, plane = static_cast<size_t>(st->nx) * st->ny;
+    std::vector<std::pair<char*, size_t>> out;
+    if (st->solver == FPIC_SOLVER_YEE) {
+        out.push_back({ static_cast<char*>(st->Ey) + 4 * t * plane * d.z0, 4 * t * plane * d.nzl });
+        out.push_back({ static_cast<char*>(st->By) + 4 * t * plane * d.z0, 4 * t * plane * d.nzl });
+    } else if (st->solver == FPIC_SOLVER_NONE) {
+        out.push_back({ static_cast<char*>(st->E4), 4 * t * st->nodes });
+    }
+    return out;
+}
+
+int save_rank_checkpoint(fpic_handle* h, const char* path)
+{
+    State* st = h->es;
+    const Domain& d = *st->dom;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    BoxFile bf{ std::fopen(path, "wb") };
+    if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
+    RankCheckpointHeader hd{};
+    std::memcpy(hd.magic, "FPICRNK1", 8);
+    hd.version = 1; hd.precision = static_cast<uint32_t>(h->prec); hd.solver = static_cast<uint32_t>(st->solver);
+    hd.nspecies = static_cast<uint32_t>(st->sp.size());
+    hd.nx = st->nx; hd.ny = st->ny; hd.nz = st->nz; hd.rank = d.rank; hd.world = d.world; hd.ghost_planes = d.G;
+    hd.fields_ready = st->fields_ready ? 1 : 0;
+    for (int a = 0; a < 3; ++a) hd.B0[a] = st->B0[a];
+    hd.spec = h->spec;
+    if (std::fwrite(&hd, sizeof hd, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+    const size_t t = h->prec == FPIC_F32 ? 4 : 8;
+    for (const Species& s : st->sp) {
+        const BoxCheckpointSpecies bs{ s.n, s.mass, s.charge };
+        if (std::fwrite(&bs, sizeof bs, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
+    }
+    for (const Species& s : st->sp) {
+        if (!s.n) continue;
+        if (int rc = rank_io(h, bf.f, s.id[s.cur], s.n * sizeof(uint32_t), true)) return rc;
+        for (int f = 0; f < 6; ++f)
+            if (int rc = rank_io(h, bf.f, static_cast<char*>(s.slab[s.cur]) + f * s.n_pad * t, s.n * t, true)) return rc;
+    }
+    for (const auto& a : rank_fields(h))
+        if (int rc = rank_io(h, bf.f, a.first, a.second, true)) return rc;
+    return FPIC_OK;
+}
+
+int load_rank_checkpoint(fpic_handle* h, const char* path)
+{
+    State* st = h->es;
+    Domain& d = *st->dom;
+    BoxFile bf{ std::fopen(path, "rb") };
+    if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
+    RankCheckpointHeader hd{};
+    if (std::fread(&hd, sizeof hd, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICRNK1", 8) != 0 || hd.version != 1)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a rank of a decomposed box (version 1)", path);
+    if (static_cast<int>(hd.precision) != h->prec || static_cast<int>(hd.solver) != st->solver || hd.nspecies != st->sp.size() || hd.nx != st->nx || hd.ny != st->ny ||
+        hd.nz != st->nz || hd.rank != d.rank || hd.world != d.world)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint of rank %d of %d, %u species on %d x %d x %d, precision %u, solver %u; this is rank %d of %d, %zu species on %d x %d x %d, precision %d, solver %d",
+                    hd.rank, hd.world, hd.nspecies, hd.nx, hd.ny, hd.nz, hd.precision, hd.solver, d.rank, d.world, st->sp.size(), st->nx, st->ny, st->nz, h->prec, st->solver);
+    if (hd.spec.radius != h->spec.radius || hd.spec.length_y != h->spec.length_y || hd.spec.height != h->spec.height || hd.spec.dt != h->spec.dt ||
+        hd.spec.macro_weight != h->spec.macro_weight)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint was written with different lengths / dt / macro_weight");
+    const size_t t = h->prec == FPIC_F32 ? 4 : 8;
+    std::vector<BoxCheckpointSpecies> bs(st->sp.size());
+    unsigned long long want = sizeof hd + bs.size() * sizeof(BoxCheckpointSpecies);
+    for (size_t k = 0; k < bs.size(); ++k) {
+        if (std::fread(&bs[k], sizeof bs[k], 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
+        if (bs[k].mass != st->sp[k].mass || bs[k].charge != st->sp[k].charge)
+            return fail(h, FPIC_ERR_INVALID_ARG, ".species <- species %zu of the checkpoint (mass %g, charge %g) is not the pusher's", k, bs[k].mass, bs[k].charge);
+        if (bs[k].n > st->sp[k].cap)
+            return fail(h, FPIC_ERR_INVALID_ARG, ".species <- the checkpoint holds %llu particles of species %zu, the rank's capacity is %zu", static_cast<unsigned long long>(bs[k].n), k, st->sp[k].cap);
+        want += bs[k].n * (sizeof(uint32_t) + 6ull * t);
+    }
+    for (const auto& a : rank_fields(h)) want += a.second;
+    const long at = std::ftell(bf.f);
+    if (at < 0 || std::fseek(bf.f, 0, SEEK_END) != 0) return fail(h, FPIC_ERR_STATE, "cannot seek in %s", path);
+    const long long have = std::ftell(bf.f);
+    if (have < 0 || static_cast<unsigned long long>(have) < want) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated: %lld bytes, %llu expected", have, want);
+    if (std::fseek(bf.f, at, SEEK_SET) != 0) return fail(h, FPIC_ERR_STATE, "cannot seek in %s", path);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t k = 0; k < bs.size(); ++k) {
+        Species& s = st->sp[k];
+        s.n = static_cast<size_t>(bs[k].n);
+        s.binned = s.census_fresh = s.rebin_pending = false; // slot order of the file: the first sub-step bins
+        s.tail_first = s.tail_count = s.n_after = 0;
+        if (!s.n) continue;
+        if (int rc = rank_io(h, bf.f, s.id[s.cur], s.n * sizeof(uint32_t), false)) return rc;
+        for (int f = 0; f < 6; ++f)
+            if (int rc = rank_io(h, bf.f, static_cast<char*>(s.slab[s.cur]) + f * s.n_pad * t, s.n * t, false)) return rc;
+    }
+    for (const auto& a : rank_fields(h))
+        if (int rc = rank_io(h, bf.f, a.first, a.second, false)) return rc;
+    for (int a = 0; a < 3; ++a) st->B0[a] = hd.B0[a];
+    st->spill_pending[0] = st->spill_pending[1] = false;
+    st->last_spill = 0;
+    st->substeps_since_bin = 0;
+    d.substeps_since_migration = 0;
+    // full EM: only the own planes were stored, the halos come from the neighbours before the next sub-step; the
+    // electrostatic cycle recomputes its field from the particles: precalc() (every rank) before the next step()
+    d.halos_stale = st->solver == FPIC_SOLVER_YEE;
+    st->fields_ready = st->solver == FPIC_SOLVER_POISSON_FFT ? false : hd.fields_ready != 0;
+    return FPIC_OK;
+}
+
+} // namespace
+
 int save_checkpoint(fpic_handle* h, const char* path)
 {
     State* st = h->es;
-    if (st->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle is not checkpointed as a whole: save what fpic_domain_get_particles returns on every rank");
+    if (st->dom) return save_rank_checkpoint(h, path);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     BoxFile bf{ std::fopen(path, "wb") };
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
@@ -1081,7 +1223,7 @@ int save_checkpoint(fpic_handle* h, const char* path)
 int load_checkpoint(fpic_handle* h, const char* path)
 {
     State* st = h->es;
-    if (st->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle is not restored from a checkpoint: hand every rank its particles through fpic_domain_set_particles");
+    if (st->dom) return load_rank_checkpoint(h, path);
     BoxFile bf{ std::fopen(path, "rb") };
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
     BoxCheckpointHeader hd{};
@@ -1551,6 +1693,11 @@ int dom_em_substep(Ranks& rk)
     } else if (unbinned || s0->substeps_since_bin >= 64) {
         for (fpic_handle* h : rk.hs)
             if (int e = bin_all<T>(h, true)) return e;
+    }
+    if (multi && s0->dom->halos_stale) { // fields restored from the ranks' checkpoints: own planes only
+        if (int e = exchange<T>(rk, X_EM_E)) return e;
+        if (int e = exchange<T>(rk, X_EM_B)) return e;
+        for (fpic_handle* h : rk.hs) h->es->dom->halos_stale = false;
     }
     for (fpic_handle* h : rk.hs) {
         State* st = h->es;

@@ -348,7 +348,9 @@ int fpic_sort(fpic_handle* h);
  * order and of the grid tables, and its inverse.  The target handle of a load must have been
  * created from the same spec.  A run resumed from a checkpoint continues bit-identically.
  * A box (spec.geometry = CART3D) saves the raw state of every species and its fields (its own file layout); the
- * target handle must have the same species added.  Not for a rank of a decomposition. */
+ * target handle must have the same species added.  A rank of a decomposition writes / reads its own file (the particles
+ * it holds with their global indices; full EM: the lattice fields of its planes; the electrostatic field is recomputed
+ * by fpic_precalc after the load). */
 int fpic_save_checkpoint(fpic_handle* h, const char* path);
 int fpic_load_checkpoint(fpic_handle* h, const char* path);
 

@@ -668,10 +668,9 @@ def test_box_checkpoint_resume_is_bit_identical(fp, eo, tmp_path, precision, sol
         other.loadCheckpoint(path)                       # one species, another grid
     assert same_bits(b.getParticles()["position"], before["position"])
     dec = fp.makeCylindricalParticlePusher(spec, precision=precision)
-    if solver != "yee":
-        dec.domainInit(0, 2, ghost_planes=2, migrate_every=2)
-        with pytest.raises(fp.FusionPicError):
-            dec.saveCheckpoint(tmp_path / "no.ckpt")
+    dec.domainInit(0, 2, ghost_planes=2, migrate_every=2)
+    with pytest.raises(fp.FusionPicError):
+        dec.loadCheckpoint(path)                         # a rank of a decomposition reads a rank's file, not a whole box
     for s in (a, b, other, dec):
         s.destroy()
 
@@ -956,3 +955,78 @@ def test_box_randomised_against_the_oracle(fp, eo, monkeypatch, seed):
             assert_same_particles(sim, ora, species=sp, what="seed %d frame %d species %d" % (seed, frame, sp))
         assert np.array_equal(sim.readField(fp.F3_RHO_FIXED), ora.rho_fixed), (seed, frame)
     sim.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("solver", ["poisson_fft", "yee"])
+def test_decomposed_checkpoint_resume_is_bit_identical(fp, eo, tmp_path, precision, solver):
+    """Every rank of a 3-rank decomposition writes its own file after 3 frames; the run goes on for 4 frames.  A fresh
+    group restored from the files (electrostatic: precalc() recomputes the field from the particles; full EM: the own
+    planes come from the file, the halos from the neighbours) and stepped 4 frames holds the same particles — by global
+    index, bit for bit — and the same fields on every rank's planes.  A rank refuses another rank's file."""
+    rng = np.random.default_rng(8)
+    world, shape = 3, (14, 12, 30)
+    L = tuple(1e-3 * s for s in shape)
+    n, ni = 20000, 5000
+    em = solver == "yee"
+    dt = 5e-12
+    if em:
+        d = [L[a] / shape[a] for a in range(3)]
+        dt = 0.5 / (2.998e8 * np.sqrt(sum(1 / x ** 2 for x in d)))
+    spec = box_spec(shape, L, count=2 * n, dt=dt, solver=solver, macro_weight=1e15 * np.prod(L) / n)
+    nzl = shape[2] // world
+    pops = []
+    for m, vth in ((n, 0.03), (ni, 1e-3)):
+        p, v = rng.random((m, 3)) * L, rng.normal(0, vth, (m, 3))
+        owner = np.floor(p[:, 2] / L[2] * shape[2]).astype(int) // nzl
+        order = np.argsort(owner, kind="stable")
+        pops.append((p[order], v[order], np.bincount(owner, minlength=world)))
+
+    def build(fill):
+        ranks = []
+        for r in range(world):
+            s = fp.makeCylindricalParticlePusher(spec, precision=precision)
+            s.addSpecies(MP, -QE, 2 * ni)
+            s.domainInit(r, world, ghost_planes=2, migrate_every=2)
+            if fill:
+                for sp, (p, v, c) in enumerate(pops):
+                    first = int(c[:r].sum())
+                    s.domainSet(p[first:first + c[r]], v[first:first + c[r]], first_id=first, species=sp)
+            s.addB(0.0, 0.01, 0.03)
+            ranks.append(s)
+        return ranks, fp.BoxGroup(ranks)
+
+    a, ga = build(True)
+    ga.precalc()
+    ga.step(3)
+    for r, s in enumerate(a):
+        s.saveCheckpoint(tmp_path / ("rank%d.ckpt" % r))
+    ga.step(4)
+
+    b, gb = build(False)
+    with pytest.raises(fp.FusionPicError, match="rank 1 of 3"):
+        b[0].loadCheckpoint(tmp_path / "rank1.ckpt")
+    for r, s in enumerate(b):
+        s.loadCheckpoint(tmp_path / ("rank%d.ckpt" % r))
+    if not em:
+        with pytest.raises(fp.FusionPicError, match="precalc"):
+            gb.step()
+        gb.precalc()
+    gb.step(4)
+    fields = [fp.F3_EDGE_E, fp.F3_FACE_B] if em else [fp.F3_RHO_FIXED, fp.F3_E]
+    for r in range(world):
+        for sp in (0, 1):
+            pa, pb = a[r].domainGet(species=sp), b[r].domainGet(species=sp)
+            ia, ib = np.argsort(pa["ids"]), np.argsort(pb["ids"])
+            assert np.array_equal(pa["ids"][ia], pb["ids"][ib]), (r, sp)
+            assert same_bits(pa["position"][ia], pb["position"][ib]) and same_bits(pa["velocity"][ia], pb["velocity"][ib]), (r, sp)
+        for which in fields:
+            fa = a[r].readField(which).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl]
+            fb = b[r].readField(which).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl]
+            assert np.array_equal(fa, fb) if fa.dtype == np.int64 else same_bits(fa, fb), (r, which)
+    data = (tmp_path / "rank0.ckpt").read_bytes()
+    (tmp_path / "short.ckpt").write_bytes(data[:-100])
+    with pytest.raises(fp.FusionPicError, match="truncated"):
+        b[0].loadCheckpoint(tmp_path / "short.ckpt")
+    for s in a + b:
+        s.destroy()
