@@ -140,7 +140,7 @@ function addStepAsync(out, lib, handle) {
     return out;
 }
 
-const FIELD3 = { E: 0, rho: 1, phi: 2, rho_fixed: 3, B: 4, edge_E: 5, face_B: 6 };   // B, edge_E, face_B: full EM (solver 'yee')
+const FIELD3 = { E: 0, rho: 1, phi: 2, rho_fixed: 3, B: 4, edge_E: 5, face_B: 6, J_fixed: 7 };   // B, edge_E, face_B, J_fixed: full EM (solver 'yee')
 
 // spec.geometry === 'cart3d': the electrostatic box behind the same method names
 function makeBox(spec, lib) {
@@ -178,8 +178,8 @@ function makeBox(spec, lib) {
     out.density = function () { lib.density(h); };                             // empic.js:1471: the charge density is always current
     out.readField = function (name, buf) {
         if (!(name in FIELD3)) throw new Error('.name <- unknown field ' + name);
-        const len = nodes * (name === 'rho' || name === 'phi' || name === 'rho_fixed' ? 1 : 4);
-        const fresh = name === 'rho_fixed' ? new BigInt64Array(len) : new Real(len);
+        const len = nodes * (name === 'rho' || name === 'phi' || name === 'rho_fixed' ? 1 : (name === 'J_fixed' ? 3 : 4));
+        const fresh = name === 'rho_fixed' || name === 'J_fixed' ? new BigInt64Array(len) : new Real(len);   // the exact integer grids
         return lib.readField3(h, FIELD3[name], checkLength(buf, len, 'out') || fresh);
     };
     out.getParticles = function (into, species) {

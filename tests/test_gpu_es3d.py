@@ -690,6 +690,9 @@ def test_plasma_box_example_from_node():
     res = json.loads(out.decode().strip().splitlines()[-1])
     assert res["particles"] == 16 ** 3 * 8 and res["updates"] == 300 * res["particles"]
     assert res["relative_error"] < 1e-2, res
+    out = subprocess.check_output([node, os.path.join(ROOT, "examples", "plasma_box_node.js"), "--grid", "16", "--perCell", "8", "--frames", "400", "--solver", "yee"])
+    res = json.loads(out.decode().strip().splitlines()[-1])
+    assert res["relative_error"] < 1e-2 and res["nonzero_current_entries"] > 0, res       # full EM, J_fixed through the addon
 
 
 def test_large_decomposed_box_is_bit_identical_to_one_handle(fp, eo):
