@@ -211,3 +211,37 @@ console.log(JSON.stringify(out));
         assert out["vec_length"] == 16
     else:
         assert "no CPU fallback" in out["create_error"]
+
+
+def test_upload_buffers_host_and_device(fp):
+    """fusionpic._device_or_host: numpy arrays (converted like JavaScript numbers) and device tensors (anything with
+    data_ptr(): passed on as they are, float32 / float64, contiguous)."""
+    import numpy as np
+    b = fp._device_or_host(np.arange(6, dtype=np.int64).reshape(2, 3))
+    assert b.shape == (2, 3) and b.code == fp.F64 and b.ptr == b.keep.ctypes.data
+    b = fp._device_or_host(np.zeros((4, 3), dtype=np.float32)[::2])          # not contiguous: copied
+    assert b.shape == (2, 3) and b.code == fp.F32 and b.keep.flags["C_CONTIGUOUS"]
+
+    class FakeTensor:
+        def __init__(self, dtype, contiguous=True):
+            self.dtype, self.shape, self._c = dtype, (5, 3), contiguous
+        def data_ptr(self):
+            return 0xDEAD0000
+        def is_contiguous(self):
+            return self._c
+    b = fp._device_or_host(FakeTensor("torch.float32"))
+    assert b.ptr == 0xDEAD0000 and b.code == fp.F32 and b.shape == (5, 3)
+    assert fp._device_or_host(FakeTensor("torch.float64")).code == fp.F64
+    for bad in (FakeTensor("torch.float16"), FakeTensor("torch.float32", contiguous=False)):
+        with pytest.raises(fp.FusionPicError):
+            fp._device_or_host(bad)
+
+
+def test_rccl_library_override_is_reported(fp, monkeypatch):
+    """FPIC_RCCL_LIBRARY names the RCCL build to bind: a path that does not exist is an error with that path in it, not
+    a silent fall back to another library (and nothing here needs a GPU)."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import fusionpic as fp\n"
+            "try:\n    fp.commUniqueId()\n    print('bound')\nexcept fp.FusionPicError as e:\n    print('ERR', e)\n") % os.path.join(ROOT, "fusion-sim_amd")
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, FPIC_RCCL_LIBRARY="/nonexistent/librccl.so")).decode()
+    assert out.startswith("ERR") and "/nonexistent/librccl.so" in out
