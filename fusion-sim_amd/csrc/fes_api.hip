@@ -39,6 +39,7 @@ struct Species {
     // a migration rides on the next re-binning push: arrivals appended at [tail_first, tail_first + tail_count) of the
     // current set, n_after = the population once that push has compacted the set
     size_t tail_first = 0, tail_count = 0, n_after = 0;
+    bool ids_identity = true;   // slot s still holds the caller's particle s (no binning yet): uploads go straight to their slots
     uint32_t *tile_start2[2] = {}, *nwork2[2] = {};
     BlockWork* work2[2] = {};
     int wl = 0;
@@ -302,6 +303,7 @@ int launch_bin(fpic_handle* h, Species& s)
     if (!two_level) s.cur ^= 1;
     s.wl = nw;
     s.binned = true;
+    s.ids_identity = false;
     s.census_fresh = s.rebin_pending = false; // tile_count now describes this binning, not a push
     return FPIC_OK;
 }
@@ -602,8 +604,12 @@ int upload_pos(fpic_handle* h, Species& s, const In* host, size_t first, size_t 
         const size_t m = std::min(chunk, count - b);
         hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyDefault, h->stream); // host or device memory
         if (e == hipSuccess) {
-            set_pos3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1 / st->lx, 1 / st->ly, 1 / st->lz, a, a + s.n_pad,
-                                                                         a + 2 * s.n_pad, s.id[s.cur], s.n);
+            if (s.ids_identity)
+                set_pos3_kernel<T, In><<<blocks_for(m), 256, 0, h->stream>>>(stage, first + b, m, 1 / st->lx, 1 / st->ly, 1 / st->lz, a, a + s.n_pad, a + 2 * s.n_pad,
+                                                                           nullptr, first + b + m, first + b);
+            else
+                set_pos3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1 / st->lx, 1 / st->ly, 1 / st->lz, a, a + s.n_pad,
+                                                                             a + 2 * s.n_pad, s.id[s.cur], s.n);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -625,8 +631,12 @@ int upload_vel(fpic_handle* h, Species& s, const In* host, size_t first, size_t 
         hipError_t e = hipMemcpyAsync(stage, host + 3 * b, m * 3 * sizeof(In), hipMemcpyDefault, h->stream); // host or device memory
         if (e == hipSuccess) {
             // velocities stay in units of c, unscaled
-            set_vec3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1.0, 1.0, a + 3 * s.n_pad, a + 4 * s.n_pad,
-                                                                         a + 5 * s.n_pad, nullptr, s.id[s.cur], s.n);
+            if (s.ids_identity)
+                set_vec3_kernel<T, In><<<blocks_for(m), 256, 0, h->stream>>>(stage, first + b, m, 1.0, 1.0, a + 3 * s.n_pad, a + 4 * s.n_pad, a + 5 * s.n_pad,
+                                                                           nullptr, nullptr, first + b + m, first + b);
+            else
+                set_vec3_kernel<T, In><<<blocks_for(s.n), 256, 0, h->stream>>>(stage, first + b, m, 1.0, 1.0, a + 3 * s.n_pad, a + 4 * s.n_pad,
+                                                                             a + 5 * s.n_pad, nullptr, s.id[s.cur], s.n);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1175,6 +1185,7 @@ int load_rank_checkpoint(fpic_handle* h, const char* path)
         Species& s = st->sp[k];
         s.n = static_cast<size_t>(bs[k].n);
         s.binned = s.census_fresh = s.rebin_pending = false; // slot order of the file: the first sub-step bins
+        s.ids_identity = false;
         s.tail_first = s.tail_count = s.n_after = 0;
         if (!s.n) continue;
         if (int rc = rank_io(h, bf.f, s.id[s.cur], s.n * sizeof(uint32_t), false)) return rc;
@@ -1257,6 +1268,7 @@ int load_checkpoint(fpic_handle* h, const char* path)
     for (Species& s : st->sp) { // the arrays are about to hold the caller's order: bins and census are void
         s.binned = s.census_fresh = s.rebin_pending = false;
         s.tail_first = s.tail_count = s.n_after = 0;
+        s.ids_identity = true; // (ckpt_scatter_kernel writes slot = index)
     }
     st->spill_pending[0] = st->spill_pending[1] = false;
     st->last_spill = 0;
@@ -1958,8 +1970,10 @@ int domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* po
         if (n) iota3_kernel<<<blocks_for(s.n), 256, 0, h->stream>>>(s.id[k], s.n, 0u);
     }
     HIP_TRY(h, hipGetLastError());
+    s.ids_identity = true; // (both sets: slot = index, for the upload below)
     if (int rc = set_particles(h, species, pos_aos, vel_aos, 0, n, dtype)) return rc;
     if (n) iota3_kernel<<<blocks_for(s.n), 256, 0, h->stream>>>(s.id[s.cur], s.n, first_id);
+    s.ids_identity = first_id == 0;
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FPIC_OK;

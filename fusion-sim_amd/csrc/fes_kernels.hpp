@@ -655,11 +655,12 @@ __global__ __launch_bounds__(256) void gradient_kernel(const T* __restrict__ phi
 // out.set({position}) for the box: u = (T)(x * (1/L)) wrapped into [0,1) (es3d_normalise)
 template <typename T, typename In>
 __global__ __launch_bounds__(256) void set_pos3_kernel(const In* __restrict__ aos, size_t chunk_begin, size_t chunk_n, double fx, double fy, double fz,
-                                                       T* x, T* y, T* z, const uint32_t* __restrict__ id, size_t n)
+                                                       T* x, T* y, T* z, const uint32_t* __restrict__ id, size_t n, size_t slot0 = 0)
 {
-    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // (id == nullptr: identity order, only the chunk's own slots [slot0, n) are visited; see set_vec3_kernel)
+    const size_t s = slot0 + static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    const size_t i = id[s];
+    const size_t i = id ? id[s] : s;
     if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
     const In* v = aos + 3 * (i - chunk_begin);
     x[s] = wrap01(static_cast<T>(static_cast<double>(v[0]) * fx));

@@ -507,11 +507,13 @@ __global__ __launch_bounds__(256) void init_particles_kernel(ParticleArrays<T> p
 template <typename T, typename In>
 __global__ __launch_bounds__(256) void set_vec3_kernel(const In* __restrict__ aos, size_t chunk_begin, size_t chunk_n,
                                                        double fxy, double fz, T* a, T* b, T* c, uint8_t* alive,
-                                                       const uint32_t* __restrict__ id, size_t n)
+                                                       const uint32_t* __restrict__ id, size_t n, size_t slot0 = 0)
 {
-    const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // (id == nullptr: slot s holds the caller's particle s — nothing has been binned yet — and only the slots
+    // [slot0, n) of the chunk are visited instead of all of them)
+    const size_t s = slot0 + static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    const size_t i = id[s];
+    const size_t i = id ? id[s] : s;
     if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
     const In* v = aos + 3 * (i - chunk_begin);
     a[s] = static_cast<T>(static_cast<double>(v[0]) * fxy);
