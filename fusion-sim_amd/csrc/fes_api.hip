@@ -107,6 +107,7 @@ struct Domain {
     rocfft_plan p2f = nullptr, p2i = nullptr, pzf = nullptr, pzi = nullptr;
     rocfft_execution_info i2f = nullptr, i2i = nullptr, izf = nullptr, izi = nullptr;
     void* fft_work[4] = {};
+    void* hatZ = nullptr;               // hatB turned to [nyl * nxh][nz]: the z pass is contiguous there
 };
 
 namespace {
@@ -866,7 +867,7 @@ void release(fpic_handle* h)
                          d->mig_recv[1], static_cast<void*>(d->counts_dev), static_cast<void*>(d->j_recv[0]), static_cast<void*>(d->j_recv[1]) })
             if (p) (void)hipFree(p);
         if (d->counts_host) (void)hipHostFree(d->counts_host);
-        for (void* p : { d->hatA, d->hatB, d->xbuf, d->fft_work[0], d->fft_work[1], d->fft_work[2], d->fft_work[3] })
+        for (void* p : { d->hatA, d->hatB, d->xbuf, d->hatZ, d->fft_work[0], d->fft_work[1], d->fft_work[2], d->fft_work[3] })
             if (p) (void)hipFree(p);
         const fdyn::RocFFT& ffd = fdyn::rocfft();
         if (ffd.ok) {
@@ -1591,12 +1592,20 @@ int solve_distributed(Ranks& rk)
             State* st = h->es;
             Domain& d = *st->dom;
             const int nxh = st->nx / 2 + 1;
-            if (int e2 = run_fft(h, d.pzf, d.izf, d.hatB, d.hatB, "rocfft_execute (z forward)")) return e2;
-            const size_t modes = static_cast<size_t>(nxh) * d.nyl * st->nz;
-            kspace_slab_kernel<T><<<blocks_for(modes), 256, 0, h->stream>>>(static_cast<T*>(d.hatB), nxh, d.nyl, st->nz, d.rank * d.nyl, st->k2[0], st->k2[1], st->k2[2],
-                                                                           1.0 / (kEps0 * static_cast<double>(st->nodes)));
+            // hatB [nz][nyl][nxh] -> hatZ [nyl * nxh][nz], contiguous transforms along z, the k-space factor, and back
+            const int cols = d.nyl * nxh;
+            const dim3 gf((cols + 31) / 32, (st->nz + 31) / 32), gb((st->nz + 31) / 32, (cols + 31) / 32);
+            transpose_complex_kernel<T><<<gf, 256, 0, h->stream>>>(static_cast<const T*>(d.hatB), static_cast<T*>(d.hatZ), st->nz, cols);
             HIP_TRY(h, hipGetLastError());
-            return run_fft(h, d.pzi, d.izi, d.hatB, d.hatB, "rocfft_execute (z inverse)");
+            if (int e2 = run_fft(h, d.pzf, d.izf, d.hatZ, d.hatZ, "rocfft_execute (z forward)")) return e2;
+            const size_t modes = static_cast<size_t>(nxh) * d.nyl * st->nz;
+            kspace_zmajor_kernel<T><<<blocks_for(modes), 256, 0, h->stream>>>(static_cast<T*>(d.hatZ), nxh, d.nyl, st->nz, d.rank * d.nyl, st->k2[0], st->k2[1], st->k2[2],
+                                                                             1.0 / (kEps0 * static_cast<double>(st->nodes)));
+            HIP_TRY(h, hipGetLastError());
+            if (int e2 = run_fft(h, d.pzi, d.izi, d.hatZ, d.hatZ, "rocfft_execute (z inverse)")) return e2;
+            transpose_complex_kernel<T><<<gb, 256, 0, h->stream>>>(static_cast<const T*>(d.hatZ), static_cast<T*>(d.hatB), cols, st->nz);
+            HIP_TRY(h, hipGetLastError());
+            return FPIC_OK;
         })) return e;
     if (int e = exchange<T>(rk, X_TRANSPOSE_BACK)) return e;
     if (int e = each([&](fpic_handle* h) -> int {
@@ -1926,21 +1935,19 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
         d->nyl = st->ny / world;
         const size_t nxh = st->nx / 2 + 1, esz = h->esize;
         const size_t cbytes = nxh * st->ny * nzl * 2 * esz;
-        if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc))) return rc;
+        if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc)) ||
+            (rc = dev_alloc(h, &d->hatZ, cbytes, acc)))
+            return rc;
         const rocfft_precision prec = h->prec == FPIC_F32 ? rocfft_precision_single : rocfft_precision_double;
         const size_t len2[2] = { static_cast<size_t>(st->nx), static_cast<size_t>(st->ny) };
         const size_t lenz[1] = { static_cast<size_t>(st->nz) };
-        rocfft_plan_description desc = nullptr;
-        const size_t stride[1] = { static_cast<size_t>(d->nyl) * nxh }, off[1] = { 0 };
+        // the z pass runs on hatZ [nyl * nxh][nz]: nyl * nxh contiguous transforms of length nz
+        const size_t zbatch = static_cast<size_t>(d->nyl) * nxh;
         if ((rc = fft_status(h, ff.plan_create(&d->p2f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 2, len2, nzl, nullptr), "rocfft_plan_create (2-D forward)")) ||
             (rc = fft_status(h, ff.plan_create(&d->p2i, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 2, len2, nzl, nullptr), "rocfft_plan_create (2-D inverse)")) ||
-            (rc = fft_status(h, ff.plan_description_create(&desc), "rocfft_plan_description_create")) ||
-            (rc = fft_status(h, ff.plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, off, off, 1, stride, 1, 1,
-                                                                   stride, 1), "rocfft_plan_description_set_data_layout")) ||
-            (rc = fft_status(h, ff.plan_create(&d->pzf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 1, lenz, stride[0], desc), "rocfft_plan_create (z forward)")) ||
-            (rc = fft_status(h, ff.plan_create(&d->pzi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 1, lenz, stride[0], desc), "rocfft_plan_create (z inverse)")))
+            (rc = fft_status(h, ff.plan_create(&d->pzf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 1, lenz, zbatch, nullptr), "rocfft_plan_create (z forward)")) ||
+            (rc = fft_status(h, ff.plan_create(&d->pzi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 1, lenz, zbatch, nullptr), "rocfft_plan_create (z inverse)")))
             return rc;
-        (void)ff.plan_description_destroy(desc);
         rocfft_plan plans[4] = { d->p2f, d->p2i, d->pzf, d->pzi };
         rocfft_execution_info* infos[4] = { &d->i2f, &d->i2i, &d->izf, &d->izi };
         for (int k = 0; k < 4; ++k) {
