@@ -481,13 +481,16 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     return out
 
 
-def box_workload(args, rank, world, local_rank, dist):
-    """`--workload box`: BASELINE configs[3] (or, with --c4-solver yee, configs[4]'s shape) as ONE decomposed run over
-    the launcher's ranks — this process is rank `rank` of `world` z-slabs, the exchange (ghost planes, FFT transposes or
-    lattice halos, migrating particles) runs inside libfusionpic.so over its own RCCL communicator.  A fixed total
-    population: `"scaling": "strong"`.  (World of one = one handle holding everything.)"""
+def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, cpu=True):
+    """BASELINE configs[3] (or, with --c4-solver yee, configs[4]'s shape) as ONE decomposed run over the launcher's
+    ranks — this process is rank `rank` of `world` z-slabs, the exchange (ghost planes, FFT transposes or lattice halos,
+    migrating particles) runs inside libfusionpic.so over its own RCCL communicator.  A fixed total population:
+    `"scaling": "strong"`.  (World of one = one handle holding everything.)  Returns the block on rank 0, None elsewhere.
+    There is no other transport: if the library's communicator cannot be set up this raises on every rank."""
     import fusionpic as fp
     import torch
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     total, grid, ghost = int(args.c4_particles), args.c4_grid, args.c4_ghost
     em = args.c4_solver == "yee"
     spec, L, vth, mi, qi = c4_scene(total, grid, world)
@@ -501,10 +504,22 @@ def box_workload(args, rank, world, local_rank, dist):
     sim = fp.makeCylindricalParticlePusher(dict(spec, count=cap), device=local_rank, precision=args.c4_precision)
     if nspecies == 2:
         sim.addSpecies(mi, qi, cap)
+    comm = {"transport": "none (one process, one handle)", "rank": 0, "world": 1}
     if dist is not None:
-        box = [fp.commUniqueId() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = fp.commUniqueId()
+            except Exception as e:
+                box[0] = "error: %s" % e
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], bytes):
+            raise RuntimeError("the library's RCCL communicator cannot be set up (%s); the decomposed run has no other transport" % box[0])
         sim.commInit(box[0], rank, world)
+        r_, w_ = sim.commInfo()   # what the library itself reports (fpic_comm_info)
+        comm = {"transport": "libfusionpic.so's own RCCL communicator (fpic_comm_init)", "rank": r_, "world": w_}
+        if w_ != world:
+            raise RuntimeError("fpic_comm_info reports a world of %d, the launcher has %d ranks" % (w_, world))
     sim.domainInit(rank, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=not em and world > 1)
     for sp in range(nspecies):
         p, v = c4_rank_particles(rank, world, sp, share, L, vth, 1.0 if sp == 0 else mi / spec["particle_mass"], local_rank)
@@ -517,13 +532,13 @@ def box_workload(args, rank, world, local_rank, dist):
         if dist is not None:
             dist.barrier(); torch.cuda.synchronize()
     sim.precalc()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         sim.step()
     fence()
     sim.resetStats(); sim.profile(True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         sim.step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -533,28 +548,54 @@ def box_workload(args, rank, world, local_rank, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sim.destroy()
+    torch.cuda.empty_cache()
     if rank != 0:
-        return
-    sub = 2 * args.steps
+        return None
+    sub = 2 * steps
     n_all = nspecies * share * world
     esz = 4 if args.c4_precision == "fp32" else 8
     push_ms = st["ms_push"] / sub
     algo = 12.0 * esz * nspecies * share     # one read and one write of the six coordinates per particle and sub-step
-    print(json.dumps({
+    plane = grid * grid
+    if world == 1:
+        exchanges = {}
+    elif em:
+        exchanges = {"current_ghost_planes_int64_reduce": 2 * (ghost + 2) * plane * 3 * 8, "lattice_halo_copies_E_and_B": 2 * 2 * (ghost + 2) * plane * 4 * esz}
+    else:
+        exchanges = {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
+                     "fft_transposes_all_to_all": 2 * (grid // 2 + 1) * grid * (grid // world) * 2 * esz * (world - 1) // world,
+                     "potential_planes": (2 * ghost + 3) * plane * esz,
+                     "migration_records_32B": 32 * dom["migrated"] // max(1, sub)}
+    out = {
         "metric": "particle-updates/sec (push+deposit+solve)", "value": n_all * sub / elapsed, "unit": "particle-updates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32" if esz == 4 else "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[4] shape: %d^3 Yee lattice, %.1e electrons in total, full EM" if em else
                                 "BASELINE configs[3]: %d^3 periodic grid, %.1e particles in total (electrons + protons), Poisson solve every sub-step")
                                % (grid, n_all) + "; EXTENSION, parity unpinned (no reference counterpart); one step = 2 sub-steps",
                    "parallelism": "z-slab decomposition x%d inside libfusionpic.so over RCCL (ghost planes %d, migration every %d sub-steps%s)"
                                   % (world, ghost, migrate_every, "" if em or world == 1 else ", slab-decomposed FFT")},
+        "comm": comm,
         "roofline": {"bound": "hbm", "kernel": "em_push_tiles_kernel" if em else "push3_tiles_kernel", "achieved": algo / (push_ms * 1e-3) / 1e9 if push_ms else 0.0,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if push_ms else 0.0, "traffic": None,
                      "algorithmic_bytes_per_launch": algo, "avg_launch_ms": push_ms, "note": "rank 0's push of all its species per sub-step"},
         "kernel_ms_per_substep_rank0": {"push": push_ms, "field_solve": st["ms_solve"] / sub, "rebinning_and_migration": st["ms_sort"] / sub},
-        "migrated_rank0": dom["migrated"], "lost_rank0": dom["lost"], "cpu_baseline": None,
-    }), flush=True)
+        "exchange_bytes_per_rank_per_substep": exchanges,
+        "migrated_rank0": dom["migrated"], "lost_rank0": dom["lost"], "device_bytes_rank0": st["bytes_particle_state"] + st["bytes_grid_state"],
+        "cpu_baseline": None,
+    }
+    tr = measured_traffic({"workload": "c4", "particles_per_gpu": nspecies * share, "grid": grid, "dtype": out["dtype"], "solver": args.c4_solver})
+    if tr:
+        out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+        out["roofline"]["traffic_source"] = "%s: %s" % (tr.get("file"), tr.get("source"))
+    else:
+        out["roofline"]["traffic_source"] = "no committed PMC pass for this configuration (profiles/r*_traffic.json)"
+    if cpu and not em:
+        try:  # the build's CPU oracle of the same cycle on a bounded sample (kind "port": the reference has no such mode)
+            out["cpu_baseline"] = es3d_cpu_port()
+        except Exception as e:  # a report, never a reason to fail the bench
+            out["cpu_baseline"] = {"value": None, "note": str(e)}
+    return out
 
 
 def es3d_cpu_port(seconds_target=5.0):
@@ -632,6 +673,7 @@ def main():
     ap.add_argument("--no-sink", action="store_true", help="development: no sink cells, hence no re-injected particles (ablation of the re-binning trigger)")
     ap.add_argument("--sort-interval", type=int, default=0, help="development: fixed re-binning period in frames (0 = the adaptive trigger)")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
+    ap.add_argument("--no-strong-c4", action="store_true", help="development: skip the strong_c4 block (BASELINE configs[3] as one decomposed run over the ranks)")
     args = ap.parse_args()
 
     import torch
@@ -660,7 +702,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
     if args.workload == "box":
-        box_workload(args, rank, world, local_rank, dist if distributed else None)
+        line = box_workload(args, rank, world, local_rank, dist if distributed else None, cpu=not args.no_cpu_baseline)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
         if distributed:
             dist.destroy_process_group()
         return
@@ -718,6 +762,8 @@ def main():
     first_binning_ms = 1e3 * (time.perf_counter() - t_bin)
 
     sharded = None
+    comm_fallback = None
+    comm = {"transport": "none (one process, one handle)", "rank": 0, "world": 1}
     if distributed and args.comm == "lib":
         # the library's own communicator: rank 0 draws the RCCL id, the host hands it round (here over the
         # launcher's process group; a JavaScript host uses a file or its own channel), and density() then
@@ -727,7 +773,7 @@ def main():
         if rank == 0:
             try:
                 box[0] = fp.commUniqueId()
-            except Exception as e:  # e.g. no RCCL to bind: every rank falls back together
+            except Exception as e:  # e.g. no RCCL to bind
                 box[0] = "error: %s" % e
         dist.broadcast_object_list(box, src=0)
         ok = 0
@@ -741,15 +787,35 @@ def main():
             comm_note = box[0]
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:  # the same exchange through torch.distributed (fusionpic.multi), on every rank
+        if int(flag.item()) == 0:
+            # NEVER silently: a value measured over torch.distributed is not the product's transport.  With more than
+            # one GPU the run ends here, non-zero, with a line that says so; a world of one (a rehearsal on a one-GPU
+            # box) may go on through torch.distributed, and the line carries "comm_fallback"
+            comm_fallback = "the library's RCCL communicator could not be set up: %s" % (comm_note or "on another rank")
             if ok:
                 sim.commDestroy()
-            args.comm = "torch (the library communicator could not be set up: %s)" % (comm_note or "on another rank")
+            if world > 1:
+                if rank == 0:
+                    print(json.dumps({"metric": "particle-updates/sec (push+deposit+solve)", "value": None, "unit": "particle-updates/s", "n_gpus": world,
+                                      "comm_fallback": comm_fallback, "error": "no measurement: a multi-GPU value must come from libfusionpic.so's own communicator"}),
+                          flush=True)
+                sim.destroy()
+                dist.destroy_process_group()
+                raise SystemExit(3)
+            args.comm = "torch"
+        else:
+            r_, w_ = sim.commInfo()   # what the library itself reports (fpic_comm_info)
+            comm = {"transport": "libfusionpic.so's own RCCL communicator (fpic_comm_init)", "rank": r_, "world": w_}
+            if w_ != world:
+                raise SystemExit("fpic_comm_info reports a world of %d, the launcher has %d ranks" % (w_, world))
+    elif distributed:
+        comm_fallback = "--comm torch was asked for on the command line (development): torch.distributed all-reduce, not the product's transport"
     if distributed and args.comm != "lib":
         from fusionpic.multi import ShardedPusher, device_tensor_view
         ptr, nbytes = sim.deviceBuffer()
         sums = device_tensor_view(ptr, nbytes, torch.device("cuda", local_rank))
         sharded = ShardedPusher(sim, sums, stream=stream, overlap=not args.no_overlap)
+        comm = {"transport": "torch.distributed (NOT the product's transport)", "rank": rank, "world": world}
 
     def cycle():
         sim.precalc()
@@ -807,6 +873,7 @@ def main():
                                % (world, "fixed total of %d" % n_total if strong else "fixed per GPU",
                                   "library RCCL communicator" if args.comm == "lib" else "torch.distributed: " + args.comm),
             },
+            "comm": comm,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "push_tiles_kernel<float, fuse, rebin> (step(): K3+K1+K2 x2 sub-steps, with the scatter's "
@@ -817,6 +884,10 @@ def main():
                 "avg_launch_ms": push_ms,
                 "launches_timed": st["step_launches"],
                 "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
+                # north_star's wording: "% of HBM-read roofline for the push" — only the 24 B an update must READ (6 scalars,
+                # SURVEY 8(d)) over the peak: the same launch time priced at half the bytes
+                "frac_of_hbm_read_roofline": 0.5 * achieved / HBM_PEAK_GBS,
+                "hbm_read_roofline_updates_per_s": HBM_PEAK_GBS * 1e9 / 24.0,
             },
             "kernel_ms_per_step": {
                 "push_incl_fused_scatter_and_rebinning": st["ms_push"] / args.steps,
@@ -828,6 +899,9 @@ def main():
             "setup": {"first_binning_ms": first_binning_ms,
                       "what": "count + scan + two-level scatter of the randomly ordered upload (host clock, synchronised), outside the timed region"},
         }
+        out["roofline"]["cycle_frac_of_hbm_read_roofline"] = out["value"] / world * 24.0 / (HBM_PEAK_GBS * 1e9)
+        if comm_fallback:
+            out["comm_fallback"] = comm_fallback
         tr = measured_traffic({"particles_per_gpu": n_local, "grid": [spec["nr"], spec["nz"]], "rng": args.rng, "dtype": "f32"})
         if tr is None:
             out["roofline"]["traffic_source"] = "no committed PMC pass for this configuration (profiles/r*_traffic.json)"
@@ -898,6 +972,18 @@ def main():
         out["extensions"]["em"] = em_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, "fp64")
         out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, stream=stream,
                                             cpu=not args.no_cpu_baseline)
+    if not args.no_strong_c4:
+        # north_star's scaling target lives on another workload than the parity-pinned headline: BASELINE configs[3]
+        # (512^3 nodes, 2e9 particles, two species) as ONE decomposed run over the launcher's ranks — a fixed total, so
+        # N = 1, 2, 4, 8 of the driver's plain `bench.py --gpus N` trace the strong-scaling curve in this block, over the
+        # library's own RCCL communicator (there is no other transport here: a failure to set it up ends the run).
+        torch.cuda.empty_cache()
+        block = box_workload(args, rank, world, local_rank, dist if distributed else None, steps=max(2, args.steps // 5), warmup=1,
+                             cpu=not args.no_cpu_baseline)
+        if rank == 0:
+            block["what"] = ("north_star's strong-scaling workload (BASELINE configs[3]) measured in the same run at this N: value = total "
+                             "particle-updates/s of the whole decomposed job; the driver's ratio value(N)/value(1) of THIS block is the >= 6x curve")
+            out["strong_c4"] = block
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -98,7 +98,7 @@ struct Domain {
     bool halos_stale = false;           // lattice fields restored from a checkpoint: the halo planes are refreshed before the next sub-step
     unsigned* counts_dev = nullptr;     // down, up, lost, overflow | received from above, from below
     unsigned* counts_host = nullptr;    // pinned copy
-    uint64_t migrated = 0, lost = 0;
+    uint64_t migrated = 0, lost = 0, deferred = 0; // deferred: leavers that did not fit a message and left with a later one
     // slab-decomposed Poisson solve (distributed = true): 2-D transforms of the owned planes, transpose over the ranks,
     // transforms along z of the rank's share of the ky rows, and back; otherwise every rank transforms the whole grid
     bool distributed = false;
@@ -897,6 +897,8 @@ void release(fpic_handle* h)
 int add_species(fpic_handle* h, double mass, double charge, uint64_t count, int* index)
 {
     State* st = h->es;
+    if (st->dom)
+        return fail(h, FPIC_ERR_STATE, "fpic_add_species after fpic_domain_init: the decomposition sized its message buffers from the species it knew; add every species first");
     if (!(mass > 0) || !std::isfinite(mass)) return fail(h, FPIC_ERR_INVALID_ARG, ".mass <- must be positive");
     const double z = charge / h->spec.particle_charge;
     const double zr = std::nearbyint(z);
@@ -1419,14 +1421,16 @@ int exchange(Ranks& rk, int which)
         dom_xfers<T>(h, which, x);
         if (int e = fcomm::check(h, rc.GroupStart(), "ncclGroupStart")) return e;
         const int me = h->comm->rank;
+        int err = FPIC_OK; // (a group once opened is always closed: an error must not leave the communicator inside it)
         for (const Xfer& m : x) {
             if (m.to == me && m.from == me) continue; // to myself: a copy, below
-            if (m.send_bytes)
-                if (int e = fcomm::check(h, rc.Send(m.send, m.send_bytes, ncclChar, m.to, h->comm->nccl, h->stream), "ncclSend")) return e;
-            if (m.recv_bytes)
-                if (int e = fcomm::check(h, rc.Recv(m.recv, m.recv_bytes, ncclChar, m.from, h->comm->nccl, h->stream), "ncclRecv")) return e;
+            if (m.send_bytes && !err) err = fcomm::check(h, rc.Send(m.send, m.send_bytes, ncclChar, m.to, h->comm->nccl, h->stream), "ncclSend");
+            if (m.recv_bytes && !err) err = fcomm::check(h, rc.Recv(m.recv, m.recv_bytes, ncclChar, m.from, h->comm->nccl, h->stream), "ncclRecv");
         }
-        if (int e = fcomm::check(h, rc.GroupEnd(), "ncclGroupEnd")) return e;
+        const std::string first = h->err;
+        const int end = fcomm::check(h, rc.GroupEnd(), "ncclGroupEnd");
+        if (err) { h->err = first; return err; }
+        if (end) return end;
         for (const Xfer& m : x)
             if (m.to == me && m.from == me && m.send_bytes && m.recv != m.send)
                 HIP_TRY(h, hipMemcpyAsync(m.recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -1471,7 +1475,30 @@ int allgather_rho(Ranks& rk)
     return FPIC_OK;
 }
 
-// particles that have left the slab move to the neighbour that owns them; then every species is re-binned
+// One word agreed by every rank (maximum): an error that only one rank sees must stop them all at the same point of the
+// exchange sequence, or the others wait in the next send / receive for ever.
+int agree_max(Ranks& rk, unsigned mine_of_rank0, const std::vector<unsigned>& mine, unsigned& out)
+{
+    if (!rk.rccl) {
+        out = 0;
+        for (unsigned v : mine) out = std::max(out, v);
+        return FPIC_OK;
+    }
+    fpic_handle* h = rk.hs[0];
+    Domain& d = *h->es->dom;
+    d.counts_host[6] = mine_of_rank0;
+    HIP_TRY(h, hipMemcpyAsync(d.counts_dev + 6, d.counts_host + 6, sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+    if (int e = fcomm::check(h, fdyn::rccl().AllReduce(d.counts_dev + 6, d.counts_dev + 6, 1, ncclUint32, ncclMax, h->comm->nccl, h->stream), "ncclAllReduce")) return e;
+    HIP_TRY(h, hipMemcpyAsync(d.counts_host + 6, d.counts_dev + 6, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    out = d.counts_host[6];
+    return FPIC_OK;
+}
+
+// particles that have left the slab move to the neighbour that owns them; then every species is re-binned.
+// Every rank takes the same path through the exchanges: a leaver that does not fit the message stays where it is (it
+// still deposits on the ghost planes) and leaves with the next migration; a rank that cannot hold its arrivals is an
+// error that ALL ranks return, agreed before any payload moves, with the packed particles put back in their slots.
 template <typename T>
 int migrate(Ranks& rk)
 {
@@ -1490,17 +1517,55 @@ int migrate(Ranks& rk)
                 mig_pack_kernel<T><<<blocks_for(s.n, 256 * kMigPer), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
                                                                           static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]),
                                                                           d.mig_cap, d.counts_dev, riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty);
+            // the message counters counted every leaver; what the messages hold is at most mig_cap records each
+            mig_clamp_kernel<<<1, 64, 0, h->stream>>>(d.counts_dev, d.mig_cap);
             HIP_TRY(h, hipGetLastError());
         }
         if (int e = exchange<T>(rk, X_MIG_COUNTS)) return e;
+        std::vector<unsigned> verdict(rk.hs.size(), 0u);
+        for (size_t r = 0; r < rk.hs.size(); ++r) {
+            fpic_handle* h = rk.hs[r];
+            Domain& d = *h->es->dom;
+            const Species& s = h->es->sp[sp];
+            HIP_TRY(h, hipMemcpyAsync(d.counts_host, d.counts_dev, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            const size_t in = static_cast<size_t>(d.counts_host[4]) + d.counts_host[5];
+            const size_t out = static_cast<size_t>(d.counts_host[0]) + d.counts_host[1];
+            if (d.counts_host[4] > d.mig_cap || d.counts_host[5] > d.mig_cap) {
+                verdict[r] = 2;
+                fail(h, FPIC_ERR_STATE, "migration: rank %d would receive %u and %u records, its message buffers hold %u", d.rank, d.counts_host[4], d.counts_host[5], d.mig_cap);
+            } else if (s.n + in > s.n_pad || s.n - out + in > s.cap) {
+                verdict[r] = 1;
+                fail(h, FPIC_ERR_STATE, "migration: rank %d would hold %zu particles of species %zu, capacity %zu", d.rank, s.n - out + in, sp, s.cap);
+            }
+        }
+        unsigned worst = 0;
+        if (int e = agree_max(rk, verdict[0], verdict, worst)) return e;
+        if (worst) { // nothing has been delivered yet: every rank puts its packed particles back and returns the error
+            int first_bad = -1;
+            for (size_t r = 0; r < rk.hs.size(); ++r) {
+                fpic_handle* h = rk.hs[r];
+                State* st = h->es;
+                Domain& d = *st->dom;
+                Species& s = st->sp[sp];
+                const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
+                for (int k = 0; k < 2; ++k)
+                    if (d.counts_host[k])
+                        mig_restore_kernel<T><<<blocks_for(d.counts_host[k]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_send[k]), d.counts_host[k],
+                                                                                                  static_cast<T*>(s.slab[s.cur]), riding ? s.tile_count : nullptr, st->nx, st->ny,
+                                                                                                  st->nz, st->ntx, st->nty);
+                HIP_TRY(h, hipGetLastError());
+                if (verdict[r] && first_bad < 0) first_bad = static_cast<int>(r);
+                else if (!verdict[r]) fail(h, FPIC_ERR_STATE, "migration: another rank cannot hold its arrivals (species %zu); nothing was moved", sp);
+                timing_end(h);
+            }
+            if (first_bad > 0) rk.hs[0]->err = rk.hs[first_bad]->err; // (a group reports through its first member)
+            return FPIC_ERR_STATE;
+        }
         for (fpic_handle* h : rk.hs) {
             Domain& d = *h->es->dom;
-            HIP_TRY(h, hipMemcpyAsync(d.counts_host, d.counts_dev, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            if (d.counts_host[3])
-                return fail(h, FPIC_ERR_STATE, "migration: %u particles did not fit the message buffer of %u records: migrate more often", d.counts_host[3], d.mig_cap);
-            if (d.counts_host[4] > d.mig_cap || d.counts_host[5] > d.mig_cap) return fail(h, FPIC_ERR_STATE, "migration: incoming message exceeds the buffer");
             d.lost += d.counts_host[2];
+            d.deferred += d.counts_host[3];
             d.migrated += d.counts_host[0] + d.counts_host[1];
         }
         if (int e = exchange<T>(rk, X_MIG_PAYLOAD)) return e;
@@ -1510,8 +1575,6 @@ int migrate(Ranks& rk)
             Species& s = st->sp[sp];
             const size_t in = static_cast<size_t>(d.counts_host[4]) + d.counts_host[5];
             const size_t out = static_cast<size_t>(d.counts_host[0]) + d.counts_host[1];
-            if (s.n + in > s.n_pad || s.n - out + in > s.cap)
-                return fail(h, FPIC_ERR_STATE, "migration: rank %d would hold %zu particles of species %zu, capacity %zu", d.rank, s.n - out + in, sp, s.cap);
             T* slab = static_cast<T*>(s.slab[s.cur]);
             const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
             uint32_t* census = riding ? s.tile_count : nullptr;
@@ -1532,9 +1595,14 @@ int migrate(Ranks& rk)
                 s.rebin_pending = true;
                 s.tail_first = s.n; s.tail_count = in;
                 s.n_after = s.n - out + in;
-                if (s.n_after == 0) { // an emptied rank: nothing to push; what arrives later is binned by the separate passes
+                if (s.n_after == 0) {
+                    // an emptied rank: nothing to push.  It stays "binned" (an empty array is sorted; launch_bin says the
+                    // same for n == 0), so that the decision to migrate — which every rank must take alike, or their
+                    // exchanges no longer pair up — never depends on one rank's population; later arrivals are binned by
+                    // the separate passes of the next migration
                     s.n = 0;
-                    s.rebin_pending = s.census_fresh = s.binned = false;
+                    s.rebin_pending = s.census_fresh = false;
+                    s.binned = true;
                     s.tail_first = s.tail_count = 0;
                 }
             } else {
@@ -2036,6 +2104,46 @@ int domain_stats(fpic_handle* h, uint64_t* migrated, uint64_t* lost)
     return FPIC_OK;
 }
 
+namespace {
+
+// One queue for the whole group while it runs (the copies between members then need no further ordering): every
+// member's own stream — its own, or the caller's (fpic_set_stream) — is drained, is swapped for rank 0's,
+// and comes back afterwards, ordered behind what the group queued.
+struct GroupStreams {
+    std::vector<fpic_handle*> hs;
+    std::vector<hipStream_t> saved;
+    hipStream_t shared = nullptr;
+    int enter(fpic_handle** handles, int n)
+    {
+        shared = handles[0]->stream;
+        for (int r = 0; r < n; ++r) {
+            fpic_handle* h = handles[r];
+            if (h->stream != shared) HIP_TRY(h, hipStreamSynchronize(h->stream)); // work queued before the group call
+            hs.push_back(h);
+            saved.push_back(h->stream);
+            h->stream = shared;
+        }
+        return FPIC_OK;
+    }
+    ~GroupStreams()
+    {
+        hipEvent_t done = nullptr;
+        bool other = false;
+        for (size_t r = 0; r < hs.size(); ++r) other |= saved[r] != shared;
+        if (other && hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(done, shared);
+        for (size_t r = 0; r < hs.size(); ++r) {
+            hs[r]->stream = saved[r];
+            if (saved[r] != shared) {
+                if (done) (void)hipStreamWaitEvent(saved[r], done, 0);
+                else (void)hipStreamSynchronize(shared);
+            }
+        }
+        if (done) (void)hipEventDestroy(done);
+    }
+};
+
+} // namespace
+
 int group_run(fpic_handle** hs, int n, int what, int ncalls)
 {
     Ranks rk;
@@ -2051,11 +2159,20 @@ int group_run(fpic_handle** hs, int n, int what, int ncalls)
             return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d differs in precision, grid, device or species", r);
         if (h->comm) return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d has a communicator; a group is the in-process exchange", r);
         if (what != 0 && !h->es->fields_ready) return fail(h0, FPIC_ERR_STATE, "step() before precalc()");
-        h->stream = h0->stream; // one queue for the whole group: the copies between members need no further ordering
     }
-    if (what == 0) return h0->prec == FPIC_F32 ? dom_precalc<float>(rk) : dom_precalc<double>(rk);
+    GroupStreams streams;
+    if (int e = streams.enter(hs, n)) return e;
+    // a failure inside the group is recorded on the member it happened on: the group reports through its first member
+    auto report = [&](int rc) {
+        if (rc != FPIC_OK && h0->err.empty())
+            for (int r = 1; r < n; ++r)
+                if (!hs[r]->err.empty()) { h0->err = hs[r]->err; break; }
+        return rc;
+    };
+    for (int r = 0; r < n; ++r) hs[r]->err.clear();
+    if (what == 0) return report(h0->prec == FPIC_F32 ? dom_precalc<float>(rk) : dom_precalc<double>(rk));
     for (int k = 0; k < 2 * ncalls; ++k)
-        if (int rc = h0->prec == FPIC_F32 ? dom_substep<float>(rk) : dom_substep<double>(rk)) return rc;
+        if (int rc = h0->prec == FPIC_F32 ? dom_substep<float>(rk) : dom_substep<double>(rk)) return report(rc);
     return FPIC_OK;
 }
 

@@ -59,6 +59,14 @@ template <typename T> __device__ __forceinline__ T floor_(T v);
 template <> __device__ __forceinline__ float floor_<float>(float v) { return floorf(v); }
 template <> __device__ __forceinline__ double floor_<double>(double v) { return floor(v); }
 
+// The fused multiply-adds the oracle's definition writes out (es3d_oracle_impl.h: fma(w, E_node, E_p), fma(p, q, -(r*s)),
+// fma(dt c / L, v, u)); nothing else is contracted (-ffp-contract=off).
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// two float accumulators at once (v_pk_fma_f32): (acc.x, acc.y) += w * (e.x, e.y), each with one rounding
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2_(float w, f32x2 e, f32x2 acc) { return __builtin_elementwise_fma(f32x2{ w, w }, e, acc); }
+
 // cell and upper weight of a normalised coordinate (es3d_axis)
 template <typename T>
 __device__ __forceinline__ void axis(T u, int n, int& i, int& w1)
@@ -134,9 +142,9 @@ struct GlobalGrid {
                     T e[4];
                     fpic::load4(E4 + 4 * (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)), e);
                     const T w = (fx[a] * fy[b]) * fz[c];
-                    Ex = Ex + w * e[0];
-                    Ey = Ey + w * e[1];
-                    Ez = Ez + w * e[2];
+                    Ex = fma_(w, e[0], Ex);
+                    Ey = fma_(w, e[1], Ey);
+                    Ez = fma_(w, e[2], Ez);
                 }
     }
     __device__ __forceinline__ void deposit(int i, int j, int k, const int (&wx)[2], const int (&wy)[2], const int (&wz)[2], int Z) const
@@ -196,19 +204,38 @@ struct WindowGrid {
         if (s < 0) { g.gather(i, j, k, fx, fy, fz, Ex, Ey, Ez); return; }
         Ex = Ey = Ez = static_cast<T>(0);
         if constexpr ((ABL & 2) != 0) { Ex = fx[0] * fy[1]; Ey = fy[0] * fz[1]; Ez = fz[0] * fx[1]; return; }
+        if constexpr (sizeof(T) == 4) {
+            // float: the record (Ex, Ey, Ez, phi) of a ds_read_b128 is two register pairs; (Ex, Ey) and (Ez, phi) are
+            // accumulated by one v_pk_fma_f32 each (the phi lane is not used)
+            f32x2 xy = { 0.f, 0.f }, zp = { 0.f, 0.f };
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    T e[4];
-                    load4_lds3(lE + 4 * (s + a + Win<T>::X * b + Win<T>::X * Win<T>::Y * c), e);
-                    const T w = (fx[a] * fy[b]) * fz[c];
-                    Ex = Ex + w * e[0];
-                    Ey = Ey + w * e[1];
-                    Ez = Ez + w * e[2];
-                }
+                    for (int a = 0; a < 2; ++a) {
+                        using V = typename NatVec16<T>::type;
+                        const V v = *reinterpret_cast<const FPIC_LDS V*>(lE + 4 * (s + a + Win<T>::X * b + Win<T>::X * Win<T>::Y * c));
+                        const T w = (fx[a] * fy[b]) * fz[c];
+                        xy = fma2_(w, f32x2{ v.x, v.y }, xy);
+                        zp = fma2_(w, f32x2{ v.z, v.w }, zp);
+                    }
+            Ex = xy.x; Ey = xy.y; Ez = zp.x;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        T e[4];
+                        load4_lds3(lE + 4 * (s + a + Win<T>::X * b + Win<T>::X * Win<T>::Y * c), e);
+                        const T w = (fx[a] * fy[b]) * fz[c];
+                        Ex = fma_(w, e[0], Ex);
+                        Ey = fma_(w, e[1], Ey);
+                        Ez = fma_(w, e[2], Ez);
+                    }
+        }
     }
     __device__ __forceinline__ void deposit(int i, int j, int k, const int (&wx)[2], const int (&wy)[2], const int (&wz)[2], int Z) const
     {
@@ -244,18 +271,18 @@ __device__ __forceinline__ void substep3(P3<T>& q, const Push3Args<T>& a, const 
     const T ax = a.hc * Ex, ay = a.hc * Ey, az = a.hc * Ez;
     T ux = q.vx + ax, uy = q.vy + ay, uz = q.vz + az;
     if constexpr (HAS_B) {
-        const T px = ux + (uy * a.tz - uz * a.ty);
-        const T py = uy + (uz * a.tx - ux * a.tz);
-        const T pz = uz + (ux * a.ty - uy * a.tx);
-        const T qx = ux + (py * a.sz - pz * a.sy);
-        const T qy = uy + (pz * a.sx - px * a.sz);
-        const T qz = uz + (px * a.sy - py * a.sx);
+        const T px = ux + fma_(uy, a.tz, -(uz * a.ty));
+        const T py = uy + fma_(uz, a.tx, -(ux * a.tz));
+        const T pz = uz + fma_(ux, a.ty, -(uy * a.tx));
+        const T qx = ux + fma_(py, a.sz, -(pz * a.sy));
+        const T qy = uy + fma_(pz, a.sx, -(px * a.sz));
+        const T qz = uz + fma_(px, a.sy, -(py * a.sx));
         ux = qx; uy = qy; uz = qz;
     }
     q.vx = ux + ax; q.vy = uy + ay; q.vz = uz + az;
-    q.x = wrap01(q.x + a.dx * q.vx);
-    q.y = wrap01(q.y + a.dy * q.vy);
-    q.z = wrap01(q.z + a.dz * q.vz);
+    q.x = wrap01(fma_(a.dx, q.vx, q.x));
+    q.y = wrap01(fma_(a.dy, q.vy, q.y));
+    q.z = wrap01(fma_(a.dz, q.vz, q.z));
     int wx[2], wy[2], wz[2];
     axis(q.x, a.nx, ni, wx[1]); wx[0] = 16384 - wx[1];
     axis(q.y, a.ny, nj, wy[1]); wy[0] = 16384 - wy[1];
@@ -980,25 +1007,41 @@ struct EmPushArgs {
     int Z;
 };
 
-// em_push + em_current for every particle: gathers through L2 (the particles are kept in tile order), the current with
-// 8-byte global atomics.  (First form of the mode: correct and complete; an LDS-staged form as in push3_tiles_kernel
-// needs 8x8x8-cell tiles for the six field components and the three accumulators to fit.)
+// em_push after the gather: Boris with the particle's own t = hB, s = 2t / (1 + t^2), drift, wrap
 template <typename T>
-__global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
+__device__ __forceinline__ void em_boris_move(P3<T>& p, T E0, T E1, T E2, T B0, T B1, T B2, T h, T hc, T dx, T dy, T dz)
 {
-    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (p >= a.n) return;
+    const T ax = hc * E0, ay = hc * E1, az = hc * E2;
+    const T tx = h * B0, ty = h * B1, tz = h * B2;
+    const T f = static_cast<T>(2) / (static_cast<T>(1) + fma_(tz, tz, fma_(ty, ty, tx * tx)));
+    const T sx = f * tx, sy = f * ty, sz = f * tz;
+    const T ux = p.vx + ax, uy = p.vy + ay, uz = p.vz + az;
+    const T px = ux + fma_(uy, tz, -(uz * ty));
+    const T py = uy + fma_(uz, tx, -(ux * tz));
+    const T pz = uz + fma_(ux, ty, -(uy * tx));
+    const T qx = ux + fma_(py, sz, -(pz * sy));
+    const T qy = uy + fma_(pz, sx, -(px * sz));
+    const T qz = uz + fma_(px, sy, -(py * sx));
+    p.vx = qx + ax; p.vy = qy + ay; p.vz = qz + az;
+    p.x = wrap01(fma_(dx, p.vx, p.x));
+    p.y = wrap01(fma_(dy, p.vy, p.y));
+    p.z = wrap01(fma_(dz, p.vz, p.z));
+}
+
+// em_push + es3d_current of ONE particle against global memory: gathers through L2, the current with 8-byte global
+// atomics.  The body of the flat kernel, and the out-of-line rare path of the tiled kernel.
+template <typename T>
+__device__ __forceinline__ void em_particle_global(P3<T>& p, const T* __restrict__ E4n, const T* __restrict__ B4n, unsigned long long* Jfix, int nx, int ny, int nz, T h, T hc,
+                                                   T dx, T dy, T dz, int Z)
+{
     const T q14 = static_cast<T>(1.0 / 16384.0);
-    T x = a.slab[p], y = a.slab[a.stride + p], z = a.slab[2 * a.stride + p];
-    T vx = a.slab[3 * a.stride + p], vy = a.slab[4 * a.stride + p], vz = a.slab[5 * a.stride + p];
-    if (x < static_cast<T>(0)) return; // a migrated slot
     int i, j, k, w1;
     T fx[2], fy[2], fz[2];
-    axis(x, a.nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14;
+    axis(p.x, nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14;
     const long long hx0 = 2 * (static_cast<long long>(i) * 16384 + w1);
-    axis(y, a.ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14;
+    axis(p.y, ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14;
     const long long hy0 = 2 * (static_cast<long long>(j) * 16384 + w1);
-    axis(z, a.nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14;
+    axis(p.z, nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14;
     const long long hz0 = 2 * (static_cast<long long>(k) * 16384 + w1);
     T E[3] = { 0, 0, 0 }, B[3] = { 0, 0, 0 };
 #pragma unroll
@@ -1007,44 +1050,45 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
-                const int ii = (i + aa == a.nx) ? 0 : i + aa, jj = (j + b == a.ny) ? 0 : j + b, kk = (k + c == a.nz) ? 0 : k + c;
-                const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(a.nx) * (static_cast<size_t>(jj) + static_cast<size_t>(a.ny) * kk);
+                const int ii = (i + aa == nx) ? 0 : i + aa, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
+                const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk);
                 T e[4], bb[4];
-                fpic::load4(a.E4n + 4 * node, e);
-                fpic::load4(a.B4n + 4 * node, bb);
+                fpic::load4(E4n + 4 * node, e);
+                fpic::load4(B4n + 4 * node, bb);
                 const T w = (fx[aa] * fy[b]) * fz[c];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    E[m] = E[m] + w * e[m];
-                    B[m] = B[m] + w * bb[m];
+                    E[m] = fma_(w, e[m], E[m]);
+                    B[m] = fma_(w, bb[m], B[m]);
                 }
             }
-    const T ax = a.hc * E[0], ay = a.hc * E[1], az = a.hc * E[2];
-    const T tx = a.h * B[0], ty = a.h * B[1], tz = a.h * B[2];
-    const T f = static_cast<T>(2) / (static_cast<T>(1) + ((tx * tx + ty * ty) + tz * tz));
-    const T sx = f * tx, sy = f * ty, sz = f * tz;
-    const T ux = vx + ax, uy = vy + ay, uz = vz + az;
-    const T px = ux + (uy * tz - uz * ty);
-    const T py = uy + (uz * tx - ux * tz);
-    const T pz = uz + (ux * ty - uy * tx);
-    const T qx = ux + (py * sz - pz * sy);
-    const T qy = uy + (pz * sx - px * sz);
-    const T qz = uz + (px * sy - py * sx);
-    vx = qx + ax; vy = qy + ay; vz = qz + az;
-    x = wrap01(x + a.dx * vx);
-    y = wrap01(y + a.dy * vy);
-    z = wrap01(z + a.dz * vz);
-    a.slab[p] = x; a.slab[a.stride + p] = y; a.slab[2 * a.stride + p] = z;
-    a.slab[3 * a.stride + p] = vx; a.slab[4 * a.stride + p] = vy; a.slab[5 * a.stride + p] = vz;
+    em_boris_move<T>(p, E[0], E[1], E[2], B[0], B[1], B[2], h, hc, dx, dy, dz);
     const long long from[3] = { hx0, hy0, hz0 };
-    const long long to[3] = { em_coord(x, a.nx), em_coord(y, a.ny), em_coord(z, a.nz) };
-    current_deposit(from, to, a.nx, a.ny, a.nz, a.Z, a.Jfix);
+    const long long to[3] = { em_coord(p.x, nx), em_coord(p.y, ny), em_coord(p.z, nz) };
+    current_deposit(from, to, nx, ny, nz, Z, Jfix);
+}
+
+// Flat form (any particle order; used until the particles have been binned)
+template <typename T>
+__global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    P3<T> q;
+    q.x = a.slab[p]; q.y = a.slab[a.stride + p]; q.z = a.slab[2 * a.stride + p];
+    q.vx = a.slab[3 * a.stride + p]; q.vy = a.slab[4 * a.stride + p]; q.vz = a.slab[5 * a.stride + p];
+    if (q.x < static_cast<T>(0)) return; // a migrated slot
+    em_particle_global<T>(q, a.E4n, a.B4n, a.Jfix, a.nx, a.ny, a.nz, a.h, a.hc, a.dx, a.dy, a.dz, a.Z);
+    a.slab[p] = q.x; a.slab[a.stride + p] = q.y; a.slab[2 * a.stride + p] = q.z;
+    a.slab[3 * a.stride + p] = q.vx; a.slab[4 * a.stride + p] = q.vy; a.slab[5 * a.stride + p] = q.vz;
 }
 
 // Tiled form of the full-EM push: 8x8x8-cell tiles, so that both node-centred fields (2 x 4 T per node) and the three
-// int64 current accumulators of a tile and its halo fit in LDS (11^3 nodes x 56 B = 74.5 KB float, x 88 B = 117 KB double).  A particle's gather is 16 ds_read_b128 (float), its current 12 ds_add_u64 when
-// it stays in its cell (the two half-segments of es3d_current are merged: their sum equals the whole segment's fluxes
-// exactly, see current_cell) and 24 when it crosses a face.  Out-of-window particles take the global path.
+// int64 current accumulators of a tile and its halo fit in LDS (11^3 nodes x 56 B = 74.5 KB float, x 88 B = 117 KB double).
+// A particle's gather is 16 ds_read_b128 (float), its current 12 ds_add_u64 when it stays in its cell (the two
+// half-segments of es3d_current are merged: their sum equals the whole segment's fluxes exactly).  Everything else — a
+// face crossing, a cell outside the window, a weight rounded up to a whole cell — is an out-of-line call with its
+// arguments BY VALUE, so that the common path keeps no state in memory.
 constexpr int kEL = 3;                 // log2 of the EM tile edge
 constexpr int kET = 1 << kEL;
 constexpr int kEmThreads = 512;
@@ -1087,8 +1131,7 @@ __device__ __forceinline__ int em_slot(int i, int j, int k, int ox, int oy, int 
 
 // fluxes of one straight segment inside the cell whose window slot is s (current_segment, LDS accumulators)
 template <typename T>
-__device__ __attribute__((noinline)) void current_cell(const int (&p1)[3], const int (&p2)[3], const int (&cell)[3], int s, int Z,
-                                                       FPIC_LDS unsigned long long* lJ)
+__device__ __forceinline__ void current_cell(const int (&p1)[3], const int (&p2)[3], const int (&cell)[3], int s, int Z, FPIC_LDS unsigned long long* lJ)
 {
     constexpr int S = 32768;
     constexpr int W = EmWin<T>::W;
@@ -1117,42 +1160,90 @@ __device__ __attribute__((noinline)) void current_cell(const int (&p1)[3], const
 }
 
 // The common case — the particle stays in its cell — in 32-bit arithmetic.  In single (not doubled) units g = H/2 the
-// whole-segment flux is 8 Z D [3 s_u s_v +- d_u d_v] with s = g1 + g2 <= 2^15, |d| <= 2^14: the bracket is a
-// non-negative number below 2^32 formed with full-rate 24-bit multiplies, and one 32 x 32 -> 64 multiply finishes it
-// (generic 64-bit products were most of this kernel's VALU work).  Equal to the oracle's two half-segments: see above.
+// whole-segment flux along m is 8 Z d_m [3 s_u s_v +- d_u d_v] with s = g1 + g2 <= 2^15, |d| < 2^14: the bracket is a
+// non-negative number below 2^32 formed by ONE 24-bit multiply-add ((3 s_u) s_v + cross), and one 32 x 32 -> 64
+// multiply-add finishes it: for a negative factor f = 8 Z d_m, taken as the unsigned word f + 2^32,
+// f * t = (f + 2^32) * t - 2^32 * t, i.e. the addend's high word is -t (generic 64-bit products and the conditional
+// negation were most of this kernel's VALU work).  Equal to the oracle's two half-segments: all terms are integers.
+// g1 = (wx, wy, wz): the start inside the cell, d: the move, s: the cell's window slot.  A zero move along m adds
+// zeros (no branch: it is rare for a thermal particle and the atomics issue for the wave anyway).
 template <typename T>
-__device__ __forceinline__ void current_cell_fast(const int (&p1)[3], const int (&p2)[3], const int (&cell)[3], int s, int Z,
-                                                  FPIC_LDS unsigned long long* lJ)
+__device__ __forceinline__ void current_cell_fast(int wx, int wy, int wz, int d0, int d1, int d2, int s, int Z, FPIC_LDS unsigned long long* lJ)
 {
-    constexpr int Sg = 16384;
     constexpr int W = EmWin<T>::W;
     const int step[3] = { 1, W, W * W };
-    int d[3];
-    unsigned A0[3], A1[3];
+    const int d[3] = { d0, d1, d2 };
+    const unsigned A1[3] = { static_cast<unsigned>(2 * wx + d0), static_cast<unsigned>(2 * wy + d1), static_cast<unsigned>(2 * wz + d2) };
+    unsigned A[3][2], A3[3][2];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const int g1 = (p1[m] >> 1) - cell[m] * Sg, g2 = (p2[m] >> 1) - cell[m] * Sg;
-        d[m] = g2 - g1;
-        A1[m] = static_cast<unsigned>(g1 + g2);
-        A0[m] = static_cast<unsigned>(2 * Sg) - A1[m];
+        A[m][1] = A1[m]; A[m][0] = 32768u - A1[m];
+        A3[m][0] = 3u * A[m][0]; A3[m][1] = 3u * A[m][1];
     }
+    FPIC_LDS unsigned long long* cell = lJ + 3 * s;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        if (d[m] == 0) continue;
         const int u = (m + 1) % 3, v = (m + 2) % 3;
-        const int cross = __mul24(d[u], d[v]);
-        const int dz8 = 8 * Z * d[m];
-        const unsigned mag = static_cast<unsigned>(dz8 < 0 ? -dz8 : dz8);
+        const unsigned cross = static_cast<unsigned>(__mul24(d[u], d[v]));
+        const unsigned f = static_cast<unsigned>(__mul24(8 * Z, d[m]));
+        const unsigned neg = static_cast<unsigned>(static_cast<int>(f) >> 31); // all ones for a negative factor
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const unsigned term = 3u * __umul24(b ? A1[u] : A0[u], c ? A1[v] : A0[v]) + static_cast<unsigned>(b == c ? cross : -cross);
-                const unsigned long long pos = static_cast<unsigned long long>(mag) * term; // one v_mad_u64_u32
-                const unsigned long long flux = dz8 < 0 ? 0ull - pos : pos;
-                __hip_atomic_fetch_add(lJ + 3 * (s + b * step[u] + c * step[v]) + m, flux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned term = __umul24(A3[u][b], A[v][c]) + (b == c ? cross : 0u - cross);
+                const unsigned long long flux = static_cast<unsigned long long>(f) * term + (static_cast<unsigned long long>((0u - term) & neg) << 32);
+                __hip_atomic_fetch_add(cell + 3 * (b * step[u] + c * step[v]) + m, flux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
     }
+}
+
+// The rare moves of the tiled kernel, out of line, everything by value: from (f*) to (t*, nearest image) in single
+// fixed-point units (cell * 2^14 + weight).  es3d_current in doubled coordinates: the relay point, one segment per
+// cell, each into the LDS window when its cell lies inside and into global memory otherwise.  Returns the number of
+// segments that went to global memory.
+template <typename T>
+__device__ __attribute__((noinline)) unsigned em_current_rare(int f0, int f1, int f2, int t0, int t1, int t2, int ox, int oy, int oz, int nx, int ny, int nz, int Z,
+                                                              FPIC_LDS unsigned long long* lJ, unsigned long long* Jfix)
+{
+    constexpr int S = 32768;
+    const int from[3] = { 2 * f0, 2 * f1, 2 * f2 }, to[3] = { 2 * t0, 2 * t1, 2 * t2 };
+    int ca[3], cb[3], r[3];
+    bool same = true;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        ca[m] = from[m] >> 15;   // floor division by S (arithmetic shift)
+        cb[m] = to[m] >> 15;
+        same &= ca[m] == cb[m];
+        r[m] = (ca[m] == cb[m]) ? (from[m] + to[m]) / 2 : (ca[m] > cb[m] ? ca[m] : cb[m]) * S;
+    }
+    unsigned spilled = 0;
+    auto segment = [&](const int (&p1)[3], const int (&p2)[3], const int (&cell)[3]) {
+        const int s = em_slot<T>(cell[0], cell[1], cell[2], ox, oy, oz, nx, ny, nz);
+        if (s >= 0) {
+            current_cell<T>(p1, p2, cell, s, Z, lJ);
+        } else {
+            const long long q1[3] = { p1[0], p1[1], p1[2] }, q2[3] = { p2[0], p2[1], p2[2] }, cc[3] = { cell[0], cell[1], cell[2] };
+            current_segment(q1, q2, cc, nx, ny, nz, Z, Jfix);
+            ++spilled;
+        }
+    };
+    if (same) { // one cell (outside the window, or reached by a weight that rounded up to a whole cell): the whole segment at once
+        segment(from, to, ca);
+    } else {
+        segment(from, r, ca);
+        segment(r, to, cb);
+    }
+    return spilled;
+}
+
+// a particle whose cell is not inside the window: the whole sub-step against global memory, out of line
+template <typename T>
+__device__ __attribute__((noinline)) P3<T> em_particle_rare(P3<T> p, const T* E4n, const T* B4n, unsigned long long* Jfix, int nx, int ny, int nz, T h, T hc, T dx, T dy,
+                                                            T dz, int Z)
+{
+    em_particle_global<T>(p, E4n, B4n, Jfix, nx, ny, nz, h, hc, dx, dy, dz, Z);
+    return p;
 }
 
 template <typename T>
@@ -1202,108 +1293,91 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
             if (q >= cnt) continue;
             T x = v[0][q], y = v[1][q], z = v[2][q];
             if (x < static_cast<T>(0)) continue;
-            int i, j, k, w1;
-            T fx[2], fy[2], fz[2];
-            int from[3]; // doubled fixed-point lattice coordinates fit 32 bits for grids of up to 2^15 nodes per axis
-            axis(x, a.nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14; from[0] = 2 * (i * 16384 + w1);
-            axis(y, a.ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14; from[1] = 2 * (j * 16384 + w1);
-            axis(z, a.nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14; from[2] = 2 * (k * 16384 + w1);
-            T E[3] = { 0, 0, 0 }, B[3] = { 0, 0, 0 };
+            // cell, upper weight (14-bit fixed point) and single fixed-point coordinate cell * 2^14 + weight per axis
+            int i, j, k, wx1, wy1, wz1;
+            axis(x, a.nx, i, wx1); axis(y, a.ny, j, wy1); axis(z, a.nz, k, wz1);
             const int s0 = em_slot<T>(i, j, k, ox, oy, oz, a.nx, a.ny, a.nz);
+            if (s0 < 0) { // rare: the cell has left the window
+                P3<T> p{ x, y, z, v[3][q], v[4][q], v[5][q] };
+                p = em_particle_rare<T>(p, a.E4n, a.B4n, a.Jfix, a.nx, a.ny, a.nz, a.h, a.hc, a.dx, a.dy, a.dz, a.Z);
+                v[0][q] = p.x; v[1][q] = p.y; v[2][q] = p.z; v[3][q] = p.vx; v[4][q] = p.vy; v[5][q] = p.vz;
+                ++my_spill;
+                continue;
+            }
+            const T fx[2] = { static_cast<T>(16384 - wx1) * q14, static_cast<T>(wx1) * q14 };
+            const T fy[2] = { static_cast<T>(16384 - wy1) * q14, static_cast<T>(wy1) * q14 };
+            const T fz[2] = { static_cast<T>(16384 - wz1) * q14, static_cast<T>(wz1) * q14 };
+            T E[3], B[3];
+            if constexpr (sizeof(T) == 4) {
+                // float: each record of a ds_read_b128 is two register pairs; (E0, E1), (E2, -), (B0, B1), (B2, -) are
+                // accumulated by one v_pk_fma_f32 each (the fourth lane of a record is zero and unused)
+                f32x2 e01 = { 0.f, 0.f }, e2_ = { 0.f, 0.f }, b01 = { 0.f, 0.f }, b2_ = { 0.f, 0.f };
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int aa = 0; aa < 2; ++aa) {
-                        T e[4], bb[4];
-                        if (s0 >= 0) {
+                        for (int aa = 0; aa < 2; ++aa) {
                             const int sl = s0 + aa + W * b + W * W * c;
-#if defined(FES_ABL_EM) && (FES_ABL_EM & 2)   // development probe (timing only): no E gather
-                            e[0] = e[1] = e[2] = e[3] = static_cast<T>(sl);
-#else
-                            load4_lds3(lE + 4 * sl, e);
-#endif
-#if defined(FES_ABL_EM) && (FES_ABL_EM & 1)   // development probe (timing only): no B gather
-                            bb[0] = bb[1] = bb[2] = bb[3] = static_cast<T>(0);
-#else
-                            load4_lds3(lB + 4 * sl, bb);
-#endif
-                        } else {
-                            const int ii = (i + aa == a.nx) ? 0 : i + aa, jj = (j + b == a.ny) ? 0 : j + b, kk = (k + c == a.nz) ? 0 : k + c;
-                            const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(a.nx) * (static_cast<size_t>(jj) + static_cast<size_t>(a.ny) * kk);
-                            fpic::load4(a.E4n + 4 * node, e);
-                            fpic::load4(a.B4n + 4 * node, bb);
+                            const V ve = *reinterpret_cast<const FPIC_LDS V*>(lE + 4 * sl);
+                            const V vb = *reinterpret_cast<const FPIC_LDS V*>(lB + 4 * sl);
+                            const T wgt = (fx[aa] * fy[b]) * fz[c];
+                            e01 = fma2_(wgt, f32x2{ ve.x, ve.y }, e01);
+                            e2_ = fma2_(wgt, f32x2{ ve.z, ve.w }, e2_);
+                            b01 = fma2_(wgt, f32x2{ vb.x, vb.y }, b01);
+                            b2_ = fma2_(wgt, f32x2{ vb.z, vb.w }, b2_);
                         }
-                        const T wgt = (fx[aa] * fy[b]) * fz[c];
+                E[0] = e01.x; E[1] = e01.y; E[2] = e2_.x; B[0] = b01.x; B[1] = b01.y; B[2] = b2_.x;
+            } else {
+                E[0] = E[1] = E[2] = B[0] = B[1] = B[2] = static_cast<T>(0);
 #pragma unroll
-                        for (int m = 0; m < 3; ++m) {
-                            E[m] = E[m] + wgt * e[m];
-                            B[m] = B[m] + wgt * bb[m];
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int aa = 0; aa < 2; ++aa) {
+                            T e[4], bb[4];
+                            const int sl = s0 + aa + W * b + W * W * c;
+                            load4_lds3(lE + 4 * sl, e);
+                            load4_lds3(lB + 4 * sl, bb);
+                            const T wgt = (fx[aa] * fy[b]) * fz[c];
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) {
+                                E[m] = fma_(wgt, e[m], E[m]);
+                                B[m] = fma_(wgt, bb[m], B[m]);
+                            }
                         }
-                    }
-            const T ax = a.hc * E[0], ay = a.hc * E[1], az = a.hc * E[2];
-            const T tx = a.h * B[0], ty = a.h * B[1], tz = a.h * B[2];
-            const T f = static_cast<T>(2) / (static_cast<T>(1) + ((tx * tx + ty * ty) + tz * tz));
-            const T sx = f * tx, sy = f * ty, sz = f * tz;
-            const T ux = v[3][q] + ax, uy = v[4][q] + ay, uz = v[5][q] + az;
-            const T px = ux + (uy * tz - uz * ty);
-            const T py = uy + (uz * tx - ux * tz);
-            const T pz = uz + (ux * ty - uy * tx);
-            const T qx = ux + (py * sz - pz * sy);
-            const T qy = uy + (pz * sx - px * sz);
-            const T qz = uz + (px * sy - py * sx);
-            v[3][q] = qx + ax; v[4][q] = qy + ay; v[5][q] = qz + az;
-            x = wrap01(x + a.dx * v[3][q]);
-            y = wrap01(y + a.dy * v[4][q]);
-            z = wrap01(z + a.dz * v[5][q]);
-            v[0][q] = x; v[1][q] = y; v[2][q] = z;
-            // current: nearest periodic image, relay point, one or two segments (es3d_current), in 32-bit coordinates
-            constexpr int S = 32768;
-            const int nn[3] = { a.nx, a.ny, a.nz };
-            int to[3], ca[3], cb[3], r[3];
+            }
+            {
+                P3<T> p{ x, y, z, v[3][q], v[4][q], v[5][q] };
+                em_boris_move<T>(p, E[0], E[1], E[2], B[0], B[1], B[2], a.h, a.hc, a.dx, a.dy, a.dz);
+                x = p.x; y = p.y; z = p.z;
+                v[0][q] = x; v[1][q] = y; v[2][q] = z; v[3][q] = p.vx; v[4][q] = p.vy; v[5][q] = p.vz;
+            }
+            // current (es3d_current), in single fixed-point units: the move d = to - from (nearest periodic image)
+            int d0, d1, d2;
             {
                 int ci, cw;
-                axis(x, a.nx, ci, cw); to[0] = 2 * (ci * 16384 + cw);
-                axis(y, a.ny, ci, cw); to[1] = 2 * (ci * 16384 + cw);
-                axis(z, a.nz, ci, cw); to[2] = 2 * (ci * 16384 + cw);
+                axis(x, a.nx, ci, cw); d0 = ((ci - i) << 14) + (cw - wx1);
+                axis(y, a.ny, ci, cw); d1 = ((ci - j) << 14) + (cw - wy1);
+                axis(z, a.nz, ci, cw); d2 = ((ci - k) << 14) + (cw - wz1);
+                const int hx = a.nx << 13, hy = a.ny << 13, hz = a.nz << 13; // half a box
+                d0 += d0 > hx ? -2 * hx : (d0 < -hx ? 2 * hx : 0);
+                d1 += d1 > hy ? -2 * hy : (d1 < -hy ? 2 * hy : 0);
+                d2 += d2 > hz ? -2 * hz : (d2 < -hz ? 2 * hz : 0);
             }
-            bool same = true;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int box = nn[m] * S, half = nn[m] * (S / 2); // (2 dd > box  <=>  dd > box / 2: box is even)
-                int dd = to[m] - from[m];
-                if (dd > half) dd -= box;
-                else if (dd < -half) dd += box;
-                to[m] = from[m] + dd;
-                ca[m] = from[m] >> 15;   // floor division by S (arithmetic shift)
-                cb[m] = to[m] >> 15;
-                same &= ca[m] == cb[m];
-            }
-            // (the cell the particle was gathered in, unless a weight rounded up to a whole cell)
-            const int sa = (ca[0] == i && ca[1] == j && ca[2] == k) ? s0 : em_slot<T>(ca[0], ca[1], ca[2], ox, oy, oz, a.nx, a.ny, a.nz);
-            auto global_segment = [&](const int (&p1)[3], const int (&p2)[3], const int (&cell)[3]) {
-                const long long q1[3] = { p1[0], p1[1], p1[2] }, q2[3] = { p2[0], p2[1], p2[2] }, cc[3] = { cell[0], cell[1], cell[2] };
-                current_segment(q1, q2, cc, a.nx, a.ny, a.nz, a.Z, a.Jfix);
-                ++my_spill;
-            };
-            if (same) {
-                // both half-segments lie in one cell: their fluxes add up to the whole segment's, exactly
+            // the common case: the particle stays in the cell it was gathered in (no weight was rounded up to a whole
+            // cell), i.e. 0 <= w1 + d < 2^14 on every axis
+            const int e0 = wx1 + d0, e1 = wy1 + d1, e2 = wz1 + d2;
+            const bool common = ((e0 | e1 | e2) & ~16383) == 0 && ((wx1 | wy1 | wz1) & 16384) == 0;
 #if defined(FES_ABL_EM) && (FES_ABL_EM & 4)       // development probe (timing only): no current deposit in the common case
-                if (sa >= 0) { if (from[0] == 0x7fffffff) lJ[sa] = 1ull; }
+            if (common) { if (d0 == 0x7fffffff) lJ[s0] = 1ull; }
 #else
-                if (sa >= 0) current_cell_fast<T>(from, to, ca, sa, a.Z, lJ);
+            if (common) current_cell_fast<T>(wx1, wy1, wz1, d0, d1, d2, s0, a.Z, lJ);
 #endif
-                else global_segment(from, to, ca);
-            } else {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) r[m] = (ca[m] == cb[m]) ? (from[m] + to[m]) / 2 : (ca[m] > cb[m] ? ca[m] : cb[m]) * S;
-                const int sb = em_slot<T>(cb[0], cb[1], cb[2], ox, oy, oz, a.nx, a.ny, a.nz);
-                if (sa >= 0) current_cell<T>(from, r, ca, sa, a.Z, lJ);
-                else global_segment(from, r, ca);
-                if (sb >= 0) current_cell<T>(r, to, cb, sb, a.Z, lJ);
-                else global_segment(r, to, cb);
-            }
+            else
+                my_spill += em_current_rare<T>((i << 14) + wx1, (j << 14) + wy1, (k << 14) + wz1, (i << 14) + e0, (j << 14) + e1, (k << 14) + e2, ox, oy, oz, a.nx, a.ny,
+                                               a.nz, a.Z, lJ, a.Jfix);
         }
         if (cnt == PPT) {
 #pragma unroll
@@ -1340,7 +1414,7 @@ template <typename T>
 struct MigRecord {
     T v[6];
     uint32_t id;
-    uint32_t pad;
+    uint32_t slot;   // where the sender held it (mig_restore_kernel: a migration called off puts it back)
 };
 
 // Particles whose cell has left this rank's slab [z0, z0 + nzl) are appended to the send buffer of the
@@ -1398,7 +1472,7 @@ __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, c
 #pragma unroll
         for (int f = 0; f < 6; ++f) r.v[f] = slab[f * stride + s];
         r.id = id[s];
-        r.pad = 0;
+        r.slot = static_cast<uint32_t>(s);
         (dir == 2 ? up : down)[slot] = r;
         slab[s] = static_cast<T>(-1);
         // the census of the last push counted it in its tile: the next bin table is laid out without it
@@ -1417,6 +1491,25 @@ __global__ __launch_bounds__(256) void mig_append_kernel(const MigRecord<T>* __r
     for (int f = 0; f < 6; ++f) slab[f * stride + first + r] = m.v[f];
     id[first + r] = m.id;
     if (census) atomicAdd(census + key_of<T>(m.v[0], m.v[1], m.v[2], nx, ny, nz, ntx, nty), 1u); // ... and with the arrivals
+}
+
+// the two message counters counted every leaver; the messages hold at most `cap` records each (the others stayed)
+static __global__ void mig_clamp_kernel(unsigned* counts, unsigned cap)
+{
+    if (threadIdx.x < 2 && counts[threadIdx.x] > cap) counts[threadIdx.x] = cap;
+}
+
+// a migration that the ranks called off before any payload moved: the packed particles go back to their slots (only x
+// was overwritten) and into the census
+template <typename T>
+__global__ __launch_bounds__(256) void mig_restore_kernel(const MigRecord<T>* __restrict__ sent, unsigned count, T* slab, uint32_t* __restrict__ census, int nx, int ny,
+                                                          int nz, int ntx, int nty)
+{
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const MigRecord<T> m = sent[r];
+    slab[m.slot] = m.v[0];
+    if (census) atomicAdd(census + key_of<T>(m.v[0], m.v[1], m.v[2], nx, ny, nz, ntx, nty), 1u);
 }
 
 // ghost planes received from a neighbour, added onto this rank's own planes (exact: int64)

@@ -160,15 +160,19 @@ void es3d_set_threads(int n) { omp_set_num_threads(n); }
 #define REAL float
 #define SUF _f32
 #define FN_FLOOR floorf
+#define FN_FMA fmaf
 #include "es3d_oracle_impl.h"
 #undef REAL
 #undef SUF
 #undef FN_FLOOR
+#undef FN_FMA
 
 #define REAL double
 #define SUF _f64
 #define FN_FLOOR floor
+#define FN_FMA fma
 #include "es3d_oracle_impl.h"
 #undef REAL
 #undef SUF
 #undef FN_FLOOR
+#undef FN_FMA

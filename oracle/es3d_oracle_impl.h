@@ -18,9 +18,14 @@
  *       w1 = ((int)(f*32768) + 1) >> 1;  w0 = 16384 - w1           (14-bit fixed point, w0+w1 = 2^14 exactly)
  *   deposit: node (i+a, j+b, k+c) += Z * wx[a]*wy[b]*wz[c]  as int64 (exact, order-free);
  *            sum over all nodes = Z * 2^42 * particles, exactly
- *   gather:  E_p = sum over c,b,a (z outermost) of ((fx[a]*fy[b])*fz[c]) * E_node, fx = w * 2^-14 in T
+ *   gather:  E_p = sum over c,b,a (z outermost) of ((fx[a]*fy[b])*fz[c]) * E_node, fx = w * 2^-14 in T; every term is
+ *            added with ONE rounding: E_p = fma(w, E_node, E_p)
  *   push:    a = (h/c) E_p;  v- = v + a;  [v' = v- + v- x t;  v+ = v- + v' x s]  (t = hB, s = 2t/(1+t^2));
- *            v_new = v+ + a;  u_new = wrap(u + (dt c / L) v_new);  wrap(u) = u - floor(u), 1 -> 0
+ *            a cross product's component is fma(p, q, -(r*s));  v_new = v+ + a;
+ *            u_new = wrap(fma(dt c / L, v_new, u));  wrap(u) = u - floor(u), 1 -> 0
+ *   Fused multiply-adds are part of the DEFINITION (round 3): they are written out as fma() here and in the kernels,
+ *   nothing is left to a compiler's contraction (-ffp-contract=off on both sides); they halve the arithmetic
+ *   instructions of the gather, which is what bounds the push kernels next to their HBM streams.
  *   solve:   phi_hat = rho_hat / (eps0 K^2),  K^2 = sum_axis (2/d sin(pi l/n))^2,  mean mode = 0
  *            E_x[i] = (phi[i-1] - phi[i+1]) * (1/(2 dx))   (periodic), node record (Ex, Ey, Ez, phi)
  */
@@ -168,26 +173,26 @@ void FN(es3d_push)(REAL* x, REAL* y, REAL* z, REAL* vx, REAL* vy, REAL* vz, size
                     const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
                     const REAL* e = E4 + 4 * ((size_t)ii + (size_t)nx * ((size_t)jj + (size_t)ny * kk));
                     const REAL w = (fx[a] * fy[b]) * fz[c];
-                    Ex = Ex + w * e[0];
-                    Ey = Ey + w * e[1];
-                    Ez = Ez + w * e[2];
+                    Ex = FN_FMA(w, e[0], Ex);
+                    Ey = FN_FMA(w, e[1], Ey);
+                    Ez = FN_FMA(w, e[2], Ez);
                 }
         const REAL ax = hc * Ex, ay = hc * Ey, az = hc * Ez;
         REAL ux = vx[p] + ax, uy = vy[p] + ay, uz = vz[p] + az;
         if (has_b) {
-            const REAL px = ux + (uy * tz - uz * ty);
-            const REAL py = uy + (uz * tx - ux * tz);
-            const REAL pz = uz + (ux * ty - uy * tx);
-            const REAL qx = ux + (py * sz - pz * sy);
-            const REAL qy = uy + (pz * sx - px * sz);
-            const REAL qz = uz + (px * sy - py * sx);
+            const REAL px = ux + FN_FMA(uy, tz, -(uz * ty));
+            const REAL py = uy + FN_FMA(uz, tx, -(ux * tz));
+            const REAL pz = uz + FN_FMA(ux, ty, -(uy * tx));
+            const REAL qx = ux + FN_FMA(py, sz, -(pz * sy));
+            const REAL qy = uy + FN_FMA(pz, sx, -(px * sz));
+            const REAL qz = uz + FN_FMA(px, sy, -(py * sx));
             ux = qx; uy = qy; uz = qz;
         }
         const REAL nvx = ux + ax, nvy = uy + ay, nvz = uz + az;
         vx[p] = nvx; vy[p] = nvy; vz[p] = nvz;
-        x[p] = FN(es3d_wrap)(x[p] + dx * nvx);
-        y[p] = FN(es3d_wrap)(y[p] + dy * nvy);
-        z[p] = FN(es3d_wrap)(z[p] + dz * nvz);
+        x[p] = FN(es3d_wrap)(FN_FMA(dx, nvx, x[p]));
+        y[p] = FN(es3d_wrap)(FN_FMA(dy, nvy, y[p]));
+        z[p] = FN(es3d_wrap)(FN_FMA(dz, nvz, z[p]));
     }
 }
 
@@ -248,27 +253,27 @@ void FN(em_push)(REAL* x, REAL* y, REAL* z, REAL* vx, REAL* vy, REAL* vz, REAL* 
                     const size_t node = (size_t)ii + (size_t)nx * ((size_t)jj + (size_t)ny * kk);
                     const REAL w = (fx[a] * fy[b]) * fz[c];
                     for (int m = 0; m < 3; ++m) {
-                        E[m] = E[m] + w * E4n[4 * node + m];
-                        B[m] = B[m] + w * B4n[4 * node + m];
+                        E[m] = FN_FMA(w, E4n[4 * node + m], E[m]);
+                        B[m] = FN_FMA(w, B4n[4 * node + m], B[m]);
                     }
                 }
         const REAL ax = hc * E[0], ay = hc * E[1], az = hc * E[2];
         const REAL tx = h * B[0], ty = h * B[1], tz = h * B[2];
-        const REAL f = (REAL)2 / ((REAL)1 + ((tx * tx + ty * ty) + tz * tz));
+        const REAL f = (REAL)2 / ((REAL)1 + FN_FMA(tz, tz, FN_FMA(ty, ty, tx * tx)));
         const REAL sx = f * tx, sy = f * ty, sz = f * tz;
         const REAL ux = vx[p] + ax, uy = vy[p] + ay, uz = vz[p] + az;
-        const REAL px = ux + (uy * tz - uz * ty);
-        const REAL py = uy + (uz * tx - ux * tz);
-        const REAL pz = uz + (ux * ty - uy * tx);
-        const REAL qx = ux + (py * sz - pz * sy);
-        const REAL qy = uy + (pz * sx - px * sz);
-        const REAL qz = uz + (px * sy - py * sx);
+        const REAL px = ux + FN_FMA(uy, tz, -(uz * ty));
+        const REAL py = uy + FN_FMA(uz, tx, -(ux * tz));
+        const REAL pz = uz + FN_FMA(ux, ty, -(uy * tx));
+        const REAL qx = ux + FN_FMA(py, sz, -(pz * sy));
+        const REAL qy = uy + FN_FMA(pz, sx, -(px * sz));
+        const REAL qz = uz + FN_FMA(px, sy, -(py * sx));
         const REAL nvx = qx + ax, nvy = qy + ay, nvz = qz + az;
         vx[p] = nvx; vy[p] = nvy; vz[p] = nvz;
         ox[p] = x[p]; oy[p] = y[p]; oz[p] = z[p];
-        x[p] = FN(es3d_wrap)(x[p] + dx * nvx);
-        y[p] = FN(es3d_wrap)(y[p] + dy * nvy);
-        z[p] = FN(es3d_wrap)(z[p] + dz * nvz);
+        x[p] = FN(es3d_wrap)(FN_FMA(dx, nvx, x[p]));
+        y[p] = FN(es3d_wrap)(FN_FMA(dy, nvy, y[p]));
+        z[p] = FN(es3d_wrap)(FN_FMA(dz, nvz, z[p]));
     }
 }
 

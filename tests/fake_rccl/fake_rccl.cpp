@@ -7,6 +7,14 @@
 // receive in issue order; operations of a group take effect at ncclGroupEnd; every call is collective in the sense that
 // all ranks issue the same sequence.  Simplification: operations complete synchronously (the caller's stream is drained
 // first, the copy is a blocking device-to-device copy), which is stricter than stream-ordered execution.
+//
+// What the real library rejects or hangs on is an ERROR here (DESIGN.md section 6 lists the rule behind each): a receive
+// whose peer posted no send in the same round, a send nobody received by the end of the round, a size mismatch of a
+// matched pair, a rank that joins a communicator twice, an unbalanced ncclGroupEnd, a point-to-point call that names
+// the caller itself or a rank outside the communicator, an all-gather whose send buffer overlaps the receive buffer
+// anywhere but at its own slot, an all-reduce whose buffers overlap without being equal, a reduction the stand-in does
+// not model.  An error is sticky for the communicator's world: every later call of every rank fails too (the real
+// library would have hung them).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -28,6 +36,8 @@ struct Message {
 
 struct World {
     int nranks = 0, joined = 0, left = 0;
+    std::vector<char> present;   // ranks that have joined
+    bool broken = false;         // a usage error was seen: every later operation fails
     std::mutex m;
     std::condition_variable cv;
     int arrived = 0;
@@ -73,6 +83,13 @@ size_t type_size(ncclDataType_t t)
     }
 }
 
+ncclResult_t broke(World* w, ncclResult_t rc)
+{
+    std::lock_guard<std::mutex> lk(w->m);
+    w->broken = true;
+    return rc;
+}
+
 ncclResult_t run(std::vector<Op>& ops)
 {
     if (ops.empty()) return ncclSuccess;
@@ -80,28 +97,52 @@ ncclResult_t run(std::vector<Op>& ops)
     World* w = c->w;
     for (const Op& o : ops)
         if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+    ncclResult_t rc = ncclSuccess;
     {
         std::lock_guard<std::mutex> lk(w->m);
-        for (const Op& o : ops)
+        for (const Op& o : ops) {
+            if (o.comm != c) { rc = ncclInvalidUsage; continue; }                        // (one communicator per group is all the library uses)
+            if (o.peer < 0 || o.peer >= w->nranks || o.peer == c->rank) { rc = ncclInvalidArgument; continue; }
             if (o.send) w->mailbox[{ c->rank, o.peer }].push_back({ o.sptr, o.bytes });
+        }
     }
     w->barrier();
-    ncclResult_t rc = ncclSuccess;
     for (const Op& o : ops) {
-        if (o.send) continue;
+        if (o.send || o.peer < 0 || o.peer >= w->nranks || o.peer == c->rank) continue;
         Message msg{};
         {
             std::lock_guard<std::mutex> lk(w->m);
             auto& q = w->mailbox[{ o.peer, c->rank }];
-            if (q.empty()) { rc = ncclInvalidUsage; continue; }   // a receive nobody sent for
+            if (q.empty()) { rc = ncclInvalidUsage; continue; }   // a receive nobody sent for: the real library waits for ever
             msg = q.front();
             q.pop_front();
         }
-        if (msg.bytes != o.bytes) { rc = ncclInvalidArgument; continue; }
+        if (msg.bytes != o.bytes) { rc = ncclInvalidArgument; continue; }   // count / type mismatch of a matched pair
         if (hipMemcpy(o.rptr, msg.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
     }
     w->barrier();
+    {
+        // every send of this round must have met its receive: what is left in a mailbox addressed to me is a send
+        // whose receive I never posted (the sender of the real library would wait for ever)
+        std::lock_guard<std::mutex> lk(w->m);
+        for (int q = 0; q < w->nranks; ++q) {
+            auto it = w->mailbox.find({ q, c->rank });
+            if (it != w->mailbox.end() && !it->second.empty()) { it->second.clear(); rc = ncclInvalidUsage; }
+        }
+        if (rc != ncclSuccess) w->broken = true;
+    }
+    w->barrier();
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        if (w->broken && rc == ncclSuccess) rc = ncclRemoteError; // a peer's usage error: the real library would have hung this rank
+    }
     return rc;
+}
+
+bool overlap(const void* a, size_t na, const void* b, size_t nb)
+{
+    const char *x = static_cast<const char*>(a), *y = static_cast<const char*>(b);
+    return x < y + nb && y < x + na;
 }
 
 } // namespace
@@ -123,9 +164,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     {
         std::lock_guard<std::mutex> lk(g_m);
         World*& slot = g_worlds[std::string(id.internal, 16)];
-        if (!slot) { slot = new World(); slot->nranks = nranks; }
+        if (!slot) { slot = new World(); slot->nranks = nranks; slot->present.assign(nranks, 0); }
         w = slot;
         if (w->nranks != nranks) return ncclInvalidArgument;
+        if (w->present[rank]) return ncclInvalidArgument;   // a rank joins a communicator once
+        w->present[rank] = 1;
         ++w->joined;
     }
     Comm* c = new Comm{ w, rank };
@@ -144,7 +187,7 @@ ncclResult_t ncclGroupStart() { ++t_depth; return ncclSuccess; }
 
 ncclResult_t ncclGroupEnd()
 {
-    if (t_depth <= 0) return ncclInvalidUsage;
+    if (t_depth <= 0) { t_ops.clear(); return ncclInvalidUsage; }
     if (--t_depth) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(t_ops);
@@ -174,14 +217,24 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
     Comm* c = reinterpret_cast<Comm*>(comm);
     World* w = c->w;
     const size_t bytes = sendcount * type_size(type);
+    if (t_depth) return broke(w, ncclInvalidUsage); // (the library never groups a collective)
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    // in place means sendbuff == recvbuff + rank * sendcount exactly; any other overlap is undefined in the real library
+    const bool in_place = sendbuff == static_cast<const char*>(recvbuff) + c->rank * bytes;
+    const bool bad = !in_place && overlap(sendbuff, bytes, recvbuff, bytes * w->nranks);
     {
         std::lock_guard<std::mutex> lk(w->m);
         w->published.resize(w->nranks);
         w->published[c->rank] = sendbuff;
+        if (bad) w->broken = true;
     }
     w->barrier();
     ncclResult_t rc = ncclSuccess;
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        if (w->broken) rc = bad ? ncclInvalidArgument : ncclRemoteError;
+    }
+    if (rc != ncclSuccess) { w->barrier(); return rc; }
     for (int q = 0; q < w->nranks; ++q) {
         char* dst = static_cast<char*>(recvbuff) + q * bytes;
         if (dst == w->published[q]) continue; // in place
@@ -191,25 +244,33 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
     return rc;
 }
 
-// sum of float / double buffers, through the host (tests only: sizes of a few megabytes)
+// sum of float / double buffers and maximum of 32-bit unsigned words, through the host (tests only: a few megabytes)
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream)
 {
-    if (op != ncclSum || (type != ncclFloat32 && type != ncclFloat64)) return ncclInvalidArgument;
     Comm* c = reinterpret_cast<Comm*>(comm);
     World* w = c->w;
+    const bool sum = op == ncclSum && (type == ncclFloat32 || type == ncclFloat64), umax = op == ncclMax && type == ncclUint32;
     const size_t bytes = count * type_size(type);
+    const bool bad = (!sum && !umax) || t_depth || (sendbuff != recvbuff && overlap(sendbuff, bytes, recvbuff, bytes));
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     {
         std::lock_guard<std::mutex> lk(w->m);
         w->published.resize(w->nranks);
         w->published[c->rank] = sendbuff;
+        if (bad) w->broken = true;
     }
     w->barrier();
-    std::vector<char> acc(bytes), one(bytes);
     ncclResult_t rc = ncclSuccess;
-    for (int q = 0; q < w->nranks; ++q) { // rank order: every rank forms the same sum
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        if (w->broken) rc = bad ? ncclInvalidArgument : ncclRemoteError;
+    }
+    if (rc != ncclSuccess) { w->barrier(); w->barrier(); return rc; }
+    std::vector<char> acc(bytes), one(bytes);
+    for (int q = 0; q < w->nranks; ++q) { // rank order: every rank forms the same result
         if (hipMemcpy(one.data(), w->published[q], bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = ncclUnhandledCudaError;
         if (q == 0) acc = one;
+        else if (umax) for (size_t i = 0; i < count; ++i) { unsigned &a = reinterpret_cast<unsigned*>(acc.data())[i], b = reinterpret_cast<unsigned*>(one.data())[i]; if (b > a) a = b; }
         else if (type == ncclFloat32) for (size_t i = 0; i < count; ++i) reinterpret_cast<float*>(acc.data())[i] += reinterpret_cast<float*>(one.data())[i];
         else for (size_t i = 0; i < count; ++i) reinterpret_cast<double*>(acc.data())[i] += reinterpret_cast<double*>(one.data())[i];
     }
@@ -219,6 +280,15 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
     return rc;
 }
 
-const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake_rccl: error"; }
+const char* ncclGetErrorString(ncclResult_t r)
+{
+    switch (r) {
+    case ncclSuccess: return "no error";
+    case ncclInvalidUsage: return "fake_rccl: invalid usage (unmatched send / receive, unbalanced group)";
+    case ncclInvalidArgument: return "fake_rccl: invalid argument (size mismatch, bad peer, overlapping buffers, unsupported reduction)";
+    case ncclRemoteError: return "fake_rccl: another rank made a usage error";
+    default: return "fake_rccl: error";
+    }
+}
 
 } // extern "C"
