@@ -1920,23 +1920,23 @@ int density(fpic_handle* h)
     return rc;
 }
 
-int step(fpic_handle* h, int ncalls)
+int substeps(fpic_handle* h, int nsub)
 {
     if (!h->es->fields_ready)
         return fail(h, FPIC_ERR_STATE, "step() before precalc(): the fields of the current particle positions have not been computed");
     if (h->es->dom) {
         Ranks rk;
         if (int e = dom_ranks_of(h, rk)) return e;
-        for (int k = 0; k < 2 * ncalls; ++k)
+        for (int k = 0; k < nsub; ++k)
             if (int rc = h->prec == FPIC_F32 ? dom_substep<float>(rk) : dom_substep<double>(rk)) return rc;
         return FPIC_OK;
     }
     if (h->es->solver == FPIC_SOLVER_YEE) {
-        for (int k = 0; k < 2 * ncalls; ++k)
+        for (int k = 0; k < nsub; ++k)
             if (int rc = h->prec == FPIC_F32 ? em_substep<float>(h) : em_substep<double>(h)) return rc;
         return FPIC_OK;
     }
-    for (int k = 0; k < 2 * ncalls; ++k)
+    for (int k = 0; k < nsub; ++k)
         if (int rc = h->prec == FPIC_F32 ? substep<float>(h) : substep<double>(h)) return rc;
     return FPIC_OK;
 }
@@ -1977,7 +1977,8 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     const size_t rec = h->prec == FPIC_F32 ? sizeof(MigRecord<float>) : sizeof(MigRecord<double>);
     size_t cap = 0;
     for (const Species& s : st->sp) cap = std::max(cap, s.cap);
-    d->mig_cap = static_cast<unsigned>(std::min<size_t>(std::max<size_t>(cap / 4, 4096), 0x7FFFFFFFu));
+    // records per migration message: a quarter of the largest species (a world of one never migrates)
+    d->mig_cap = world == 1 ? 16u : static_cast<unsigned>(std::min<size_t>(std::max<size_t>(cap / 4, 4096), 0x7FFFFFFFu));
     uint64_t* acc = &h->bytes_grid;
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&d->ghost_recv[0]), ghost_planes * plane * 8, acc)) ||

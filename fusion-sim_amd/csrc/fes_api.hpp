@@ -18,7 +18,7 @@ int set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int 
 int read_field3(fpic_handle* h, int which, void* out, int dtype);
 int precalc(fpic_handle* h);
 int density(fpic_handle* h);
-int step(fpic_handle* h, int ncalls);
+int substeps(fpic_handle* h, int nsub); // (step(n) = substeps(2 n))
 int sort(fpic_handle* h);
 int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes);
 int save_checkpoint(fpic_handle* h, const char* path);

@@ -1023,19 +1023,25 @@ int fpic_precalc(fpic_handle* h)
     return h->prec == FPIC_F32 ? launch_precalc<float>(h) : launch_precalc<double>(h);
 }
 
-int fpic_step(fpic_handle* h, int ncalls)
+int fpic_substeps(fpic_handle* h, int nsub)
 {
     CHECK_HANDLE(h);
-    if (ncalls < 0) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- must be >= 0");
-    if (ncalls == 0) return FPIC_OK;
-    if (ncalls > (1 << 29)) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- too large");
-    if (h->es) return fes::step(h, ncalls);
-    const int rc = h->prec == FPIC_F32 ? launch_push<float>(h, 2 * ncalls) : launch_push<double>(h, 2 * ncalls);
+    if (nsub < 0) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- must be >= 0");
+    if (nsub == 0) return FPIC_OK;
+    if (nsub > (1 << 30)) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- too large");
+    if (h->es) return fes::substeps(h, nsub);
+    const int rc = h->prec == FPIC_F32 ? launch_push<float>(h, nsub) : launch_push<double>(h, nsub);
     if (rc == FPIC_OK) {
         h->step_launches++;
-        h->particle_updates += static_cast<uint64_t>(2) * ncalls * h->n;
+        h->particle_updates += static_cast<uint64_t>(nsub) * h->n;
     }
     return rc;
+}
+
+int fpic_step(fpic_handle* h, int ncalls)
+{
+    if (ncalls > (1 << 29)) return fail(h, FPIC_ERR_INVALID_ARG, ".ncalls <- too large");
+    return fpic_substeps(h, ncalls < 0 ? ncalls : 2 * ncalls);
 }
 
 int fpic_get_substep_counter(fpic_handle* h, uint64_t* t)

@@ -33,7 +33,7 @@ F3_E, F3_RHO, F3_PHI, F3_RHO_FIXED, F3_B_NODES, F3_EDGE_E, F3_FACE_B, F3_J_FIXED
 ABI_FUNCTIONS = [
     "fpic_last_error", "fpic_abi_version", "fpic_build_arch", "fpic_create", "fpic_destroy", "fpic_set_particles",
     "fpic_set_grid", "fpic_set_random_state", "fpic_add_current_loop", "fpic_add_current_z", "fpic_add_bz",
-    "fpic_add_btheta", "fpic_precalc", "fpic_step", "fpic_density", "fpic_deposit", "fpic_density_finish",
+    "fpic_add_btheta", "fpic_precalc", "fpic_step", "fpic_substeps", "fpic_density", "fpic_deposit", "fpic_density_finish",
     "fpic_density_finish_from",
     "fpic_read_grid", "fpic_get_particles", "fpic_get_cells", "fpic_device_buffer", "fpic_set_stream",
     "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
@@ -117,6 +117,7 @@ def load_library(path=None):
         getattr(lib, f).argtypes = [vp]
     lib.fpic_density_finish_from.argtypes = [vp, vp, vp]
     lib.fpic_step.argtypes = [vp, ci]
+    lib.fpic_substeps.argtypes = [vp, ci]
     lib.fpic_profile.argtypes = [vp, ci]
     lib.fpic_read_grid.argtypes = [vp, ci, vp, ci]
     lib.fpic_get_particles.argtypes = [vp, vp, vp, vp, vp, ci]
@@ -296,6 +297,10 @@ class CylindricalParticlePusher:
         """One call = two leap-frog sub-steps, dt fixed at construction (empic.js:1436-1469)."""
         self._check(self._lib.fpic_step(self._h, int(ncalls)))
 
+    def substeps(self, nsub):
+        """nsub single leap-frog sub-steps: step(n) == substeps(2 n) (diagnostics that need the state between the halves)"""
+        self._check(self._lib.fpic_substeps(self._h, int(nsub)))
+
     def density(self):
         self._check(self._lib.fpic_density(self._h))
 
@@ -461,6 +466,7 @@ class ElectrostaticBoxPusher:
     setStream = CylindricalParticlePusher.setStream
     precalc = CylindricalParticlePusher.precalc
     step = CylindricalParticlePusher.step
+    substeps = CylindricalParticlePusher.substeps
     density = CylindricalParticlePusher.density
     addBZ = CylindricalParticlePusher.addBZ
     deviceBuffer = CylindricalParticlePusher.deviceBuffer

@@ -175,6 +175,7 @@ function makeBox(spec, lib) {
     out.addB = function (bx, by, bz) { lib.addB(h, bx, by, bz); };
     out.precalc = function () { lib.precalc(h); };                             // empic.js:1413: fields <- particles (deposit + solve)
     out.step = function (ncalls) { lib.step(h, ncalls === undefined ? 1 : ncalls); };  // empic.js:1436: 2 sub-steps
+    out.substeps = function (n) { lib.substeps(h, n === undefined ? 1 : n); };         // extension: single sub-steps, step(k) = substeps(2 k)
     out.density = function () { lib.density(h); };                             // empic.js:1471: the charge density is always current
     out.readField = function (name, buf) {
         if (!(name in FIELD3)) throw new Error('.name <- unknown field ' + name);
@@ -281,6 +282,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
     };
     out.precalc = function () { lib.precalc(h); };                                 // empic.js:1413
     out.step = function (ncalls) { lib.step(h, ncalls === undefined ? 1 : ncalls); };  // empic.js:1436
+    out.substeps = function (n) { lib.substeps(h, n === undefined ? 1 : n); };         // extension: single sub-steps, step(k) = substeps(2 k)
     out.density = function () { lib.density(h); };                                 // empic.js:1471
 
     // ---- stand-ins for `canvas` and the reference's unseeded randomness

@@ -281,6 +281,15 @@ static napi_value n_step(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+static napi_value n_substeps(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2]; fpic_handle* h; double n;
+    if (!get_args(env, info, 2, argv, &h)) return NULL;
+    if (!get_double(env, argv[1], &n)) return NULL;
+    if (fpic_substeps(h, (int)n) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
 /* stepAsync(h, ncalls) -> Promise: fpic_step + fpic_sync on a libuv worker thread, so that Node's loop is not blocked
  * while the GPU works ("Threading").  The handle is not thread-safe: the shim refuses other calls on the
  * simulation until the promise has settled. */
@@ -683,7 +692,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "create", n_create }, { "destroy", n_destroy }, { "setParticles", n_set_particles },
         { "setGrid", n_set_grid }, { "setRandomState", n_set_random_state }, { "addCurrentLoop", n_add_current_loop },
         { "addCurrentZ", n_add_current_z }, { "addBZ", n_add_bz }, { "addBTheta", n_add_btheta },
-        { "precalc", n_precalc }, { "step", n_step }, { "stepAsync", n_step_async }, { "density", n_density }, { "deposit", n_deposit },
+        { "precalc", n_precalc }, { "step", n_step }, { "substeps", n_substeps }, { "stepAsync", n_step_async }, { "density", n_density }, { "deposit", n_deposit },
         { "densityFinish", n_density_finish }, { "readGrid", n_read_grid }, { "getParticles", n_get_particles },
         { "getCells", n_get_cells }, { "sort", n_sort }, { "sync", n_sync }, { "profile", n_profile },
         { "getStats", n_get_stats }, { "saveCheckpoint", n_save_checkpoint }, { "loadCheckpoint", n_load_checkpoint }, { "resetStats", n_reset_stats }, { "buildArch", n_build_arch },

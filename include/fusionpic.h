@@ -239,6 +239,11 @@ int fpic_precalc(fpic_handle* h);
 /* out.step() (empic.js:1436-1469) ncalls times; each call is two leap-frog
  * sub-steps (RandB,VelB,PosB,RandA,VelA,PosA). */
 int fpic_step(fpic_handle* h, int ncalls);
+/* The same advance counted in single leap-frog sub-steps: fpic_step(h, n) == fpic_substeps(h, 2 n).  The reference can
+ * only advance in pairs (empic.js:1436-1469 draws both halves of the ping-pong); an odd count exists for diagnostics that
+ * need the state between the two halves (the continuity check of the full-EM cycle, a sampled comparison with the oracle
+ * in a field read back beforehand). */
+int fpic_substeps(fpic_handle* h, int nsub);
 
 /* out.density() (empic.js:1471-1495): scatter (K4), normalise (K5), EMA (K6),
  * avgB <- avgA (K7).  fpic_density == fpic_deposit then fpic_density_finish; the

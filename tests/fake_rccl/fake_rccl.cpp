@@ -4,9 +4,12 @@
 // RCCL refuses two ranks on one device.  Bound through FPIC_RCCL_LIBRARY by tests/test_gpu_fake_rccl.py only.
 //
 // Semantics kept: ranks of a communicator meet by its unique id; between a pair of ranks the k-th send matches the k-th
-// receive in issue order; operations of a group take effect at ncclGroupEnd; every call is collective in the sense that
-// all ranks issue the same sequence.  Simplification: operations complete synchronously (the caller's stream is drained
-// first, the copy is a blocking device-to-device copy), which is stricter than stream-ordered execution.
+// receive in issue order; operations of a group take effect at ncclGroupEnd; point-to-point operations involve their
+// two ranks only (a rank with nothing to send or receive in a round takes no part in it: no barrier over the world);
+// collectives involve every rank.  Simplification: operations complete synchronously (the caller's stream is drained
+// first, the copy is a blocking device-to-device copy), which is stricter than stream-ordered execution; where the real
+// library would wait for ever — a receive whose send never comes, a send nobody receives — the stand-in gives up after
+// kPatience and reports an error.
 //
 // What the real library rejects or hangs on is an ERROR here (DESIGN.md section 6 lists the rule behind each): a receive
 // whose peer posted no send in the same round, a send nobody received by the end of the round, a size mismatch of a
@@ -18,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -29,10 +33,13 @@
 
 namespace {
 
+struct World;
 struct Message {
     const void* ptr;
     size_t bytes;
+    unsigned long id;     // per world, to tell the sender which of its messages was taken
 };
+constexpr int kPatienceMs = 4000;
 
 struct World {
     int nranks = 0, joined = 0, left = 0;
@@ -43,13 +50,19 @@ struct World {
     int arrived = 0;
     unsigned long generation = 0;
     std::map<std::pair<int, int>, std::deque<Message>> mailbox; // (from, to) -> sends in issue order
+    unsigned long next_id = 1;
+    std::map<unsigned long, int> taken;                          // message id -> 1 delivered, 2 refused (size mismatch)
+    std::condition_variable mail;
     std::vector<const void*> published;                          // collectives: every rank's send buffer
     void barrier()
     {
         std::unique_lock<std::mutex> lk(m);
         const unsigned long g = generation;
         if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g; });
+        else if (!cv.wait_for(lk, std::chrono::milliseconds(4 * kPatienceMs), [&] { return generation != g; })) {
+            broken = true;   // a collective some rank never entered: the real library waits for ever
+            --arrived;
+        }
     }
 };
 
@@ -98,43 +111,62 @@ ncclResult_t run(std::vector<Op>& ops)
     for (const Op& o : ops)
         if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
     ncclResult_t rc = ncclSuccess;
+    std::vector<unsigned long> mine;
+    const auto patience = std::chrono::milliseconds(kPatienceMs);
     {
+        // every send of the group is posted before any receive waits: two ranks that send to each other cannot block
         std::lock_guard<std::mutex> lk(w->m);
+        if (w->broken) return ncclRemoteError;
         for (const Op& o : ops) {
             if (o.comm != c) { rc = ncclInvalidUsage; continue; }                        // (one communicator per group is all the library uses)
             if (o.peer < 0 || o.peer >= w->nranks || o.peer == c->rank) { rc = ncclInvalidArgument; continue; }
-            if (o.send) w->mailbox[{ c->rank, o.peer }].push_back({ o.sptr, o.bytes });
+            if (!o.send) continue;
+            const unsigned long id = w->next_id++;
+            w->mailbox[{ c->rank, o.peer }].push_back({ o.sptr, o.bytes, id });
+            mine.push_back(id);
         }
+        w->mail.notify_all();
     }
-    w->barrier();
     for (const Op& o : ops) {
         if (o.send || o.peer < 0 || o.peer >= w->nranks || o.peer == c->rank) continue;
         Message msg{};
         {
-            std::lock_guard<std::mutex> lk(w->m);
+            std::unique_lock<std::mutex> lk(w->m);
             auto& q = w->mailbox[{ o.peer, c->rank }];
-            if (q.empty()) { rc = ncclInvalidUsage; continue; }   // a receive nobody sent for: the real library waits for ever
+            if (!w->mail.wait_for(lk, patience, [&] { return !q.empty() || w->broken; }) || q.empty()) {
+                rc = w->broken ? ncclRemoteError : ncclInvalidUsage;   // a receive nobody sent for: the real library waits for ever
+                w->broken = true;
+                w->mail.notify_all();
+                continue;
+            }
             msg = q.front();
             q.pop_front();
         }
-        if (msg.bytes != o.bytes) { rc = ncclInvalidArgument; continue; }   // count / type mismatch of a matched pair
-        if (hipMemcpy(o.rptr, msg.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
-    }
-    w->barrier();
-    {
-        // every send of this round must have met its receive: what is left in a mailbox addressed to me is a send
-        // whose receive I never posted (the sender of the real library would wait for ever)
-        std::lock_guard<std::mutex> lk(w->m);
-        for (int q = 0; q < w->nranks; ++q) {
-            auto it = w->mailbox.find({ q, c->rank });
-            if (it != w->mailbox.end() && !it->second.empty()) { it->second.clear(); rc = ncclInvalidUsage; }
+        bool ok = msg.bytes == o.bytes;                                  // count / type mismatch of a matched pair
+        if (!ok) rc = ncclInvalidArgument;
+        else if (hipMemcpy(o.rptr, msg.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->taken[msg.id] = ok ? 1 : 2;
+            if (!ok) w->broken = true;
+            w->mail.notify_all();
         }
-        if (rc != ncclSuccess) w->broken = true;
     }
-    w->barrier();
     {
-        std::lock_guard<std::mutex> lk(w->m);
-        if (w->broken && rc == ncclSuccess) rc = ncclRemoteError; // a peer's usage error: the real library would have hung this rank
+        // a send returns once its receive has taken the data (the real library's send completes on the stream; here
+        // the buffer may be reused as soon as this call returns).  A send nobody receives: the real library waits for ever
+        std::unique_lock<std::mutex> lk(w->m);
+        for (unsigned long id : mine) {
+            if (!w->mail.wait_for(lk, patience, [&] { return w->taken.count(id) || w->broken; }) || !w->taken.count(id)) {
+                if (rc == ncclSuccess) rc = w->broken ? ncclRemoteError : ncclInvalidUsage;
+                w->broken = true;
+                w->mail.notify_all();
+                continue;
+            }
+            if (w->taken[id] == 2 && rc == ncclSuccess) rc = ncclInvalidArgument;
+            w->taken.erase(id);
+        }
+        if (rc != ncclSuccess) { w->broken = true; w->mail.notify_all(); }
     }
     return rc;
 }
