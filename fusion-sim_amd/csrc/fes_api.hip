@@ -11,11 +11,13 @@
 // (fpic_dyn.hpp); without it a handle with solver = POISSON_FFT cannot be created.
 #include "fes_api.hpp"
 #include "fes_kernels.hpp"
+#include "fes_fft.hpp"
 #include "fpic_comm.hpp"
 #include "fpic_dyn.hpp"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -47,6 +49,8 @@ struct Species {
     bool binned = false;
     bool census_fresh = false;  // tile_count holds the census of the current positions (written by the last push)
     bool rebin_pending = false; // tables [wl ^ 1] are laid out from that census: the next push re-bins
+    bool rebin_now = false;     // the push in flight is that re-binning (a push in two parts decides once)
+    uint32_t* split = nullptr;  // decomposition: interior range of the work list [0..1] and of the slots [2..3] (work_split_kernel)
 };
 
 struct State {
@@ -74,6 +78,9 @@ struct State {
     unsigned long long spill_seq = 0, last_spill = 0;
     int substeps_since_bin = 0;
     bool fields_ready = false;
+    // power-of-two grids: the Poisson solve runs on the library's own FFT passes (fes_fft.hpp), which read the integer
+    // charge grid directly; rho (T) is then formed only when somebody reads it
+    bool own_fft = false, rho_fresh = true;
     std::vector<Species> sp;
     struct Domain* dom = nullptr; // z-slab decomposition over several GPUs (fpic_domain_init)
 };
@@ -98,6 +105,10 @@ struct Domain {
     bool halos_stale = false;           // lattice fields restored from a checkpoint: the halo planes are refreshed before the next sub-step
     unsigned* counts_dev = nullptr;     // down, up, lost, overflow | received from above, from below
     unsigned* counts_host = nullptr;    // pinned copy
+    // the ghost-plane exchange of a sub-step runs on a stream of its own while the interior of the slab is pushed
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_ghost = nullptr;
+    bool overlap = true;                // FPIC_DOMAIN_OVERLAP=0: everything on the handle's stream, one launch per species
     uint64_t migrated = 0, lost = 0, deferred = 0; // deferred: leavers that did not fit a message and left with a later one
     // slab-decomposed Poisson solve (distributed = true): 2-D transforms of the owned planes, transpose over the ranks,
     // transforms along z of the rank's share of the ky rows, and back; otherwise every rank transforms the whole grid
@@ -139,7 +150,8 @@ int alloc_species(fpic_handle* h, Species& s)
     uint64_t* acc = &h->bytes_grid;
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * (st->ntiles + fpic::kSortMaxBins + 1), acc))) // + chunk_first of the two-level binning
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * (st->ntiles + fpic::kSortMaxBins + 1), acc)) || // + chunk_first of the two-level binning
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.split), 4 * sizeof(uint32_t), acc)))
         return rc;
     for (int k = 0; k < 2; ++k)
         if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_start2[k]), sizeof(uint32_t) * (st->ntiles + 1), acc)) ||
@@ -155,6 +167,7 @@ void free_species(Species& s)
         if (s.slab[k]) (void)hipFree(s.slab[k]);
         if (s.id[k]) (void)hipFree(s.id[k]);
     }
+    if (s.split) (void)hipFree(s.split);
     for (void* p : { static_cast<void*>(s.tile_count), static_cast<void*>(s.tile_cursor), static_cast<void*>(s.tile_start2[0]),
                      static_cast<void*>(s.tile_start2[1]), static_cast<void*>(s.nwork2[0]), static_cast<void*>(s.nwork2[1]),
                      static_cast<void*>(s.work2[0]), static_cast<void*>(s.work2[1]) })
@@ -184,6 +197,7 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     a.Z = s.Z;
     a.ntx = st->ntx; a.nty = st->nty; a.ntz = st->ntz;
     a.work = s.work2[s.wl]; a.nwork = s.nwork2[s.wl];
+    a.split = s.split; a.part = 0;
     a.spilled = st->spilled;
     a.tile_count = s.tile_count;
     a.id = s.id[s.cur];
@@ -194,11 +208,14 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     return a;
 }
 
+// part 0: the whole species in one launch.  A rank of a decomposition may push in two parts: 1 = the tile layers along
+// the slab's faces (and the arrivals of a migration), 2 = the interior; the re-binning decision, the census reset and the
+// switch of the particle sets are taken once.
 template <typename T, bool DEPOSIT_ONLY>
-int launch_push(fpic_handle* h, Species& s)
+int launch_push(fpic_handle* h, Species& s, int part = 0)
 {
     State* st = h->es;
-    const Push3Args<T> a = push_args<T>(h, s);
+    Push3Args<T> a = push_args<T>(h, s);
     const bool has_b = st->B0[0] != 0 || st->B0[1] != 0 || st->B0[2] != 0;
     if (s.n == 0) return FPIC_OK;
     // (the full-EM mode bins by 8x8x8-cell tiles: its charge grid — a diagnostic there — takes the flat form)
@@ -208,27 +225,34 @@ int launch_push(fpic_handle* h, Species& s)
         if constexpr (DEPOSIT_ONLY) {
             push3_tiles_kernel<T, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
         } else {
-            const bool rebin = s.rebin_pending;
-            s.census_fresh = s.rebin_pending = false;
-            HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
+            if (part != 2) {
+                s.rebin_now = s.rebin_pending;
+                s.census_fresh = s.rebin_pending = false;
+                HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
+            }
+            const bool rebin = s.rebin_now;
+            a.part = part;
             if (rebin && has_b) push3_tiles_kernel<T, true, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (rebin) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else push3_tiles_kernel<T, false, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
-            if (rebin && s.tail_count) { // the arrivals of the migration that asked for this re-binning
+            if (part != 2 && rebin && s.tail_count) { // the arrivals of the migration that asked for this re-binning
                 if (has_b) push3_tail_kernel<T, true><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(a, s.tail_first, s.tail_count);
                 else push3_tail_kernel<T, false><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(a, s.tail_first, s.tail_count);
             }
             HIP_TRY(h, hipGetLastError());
-            s.census_fresh = true;
-            if (rebin) { // this launch was the binning: the other set and the other tables are live now
-                s.cur ^= 1;
-                s.wl ^= 1;
-                if (s.n_after) s.n = s.n_after;
-                s.tail_first = s.tail_count = s.n_after = 0;
+            if (part != 1) {
+                s.census_fresh = true;
+                if (rebin) { // this launch was the binning: the other set and the other tables are live now
+                    s.cur ^= 1;
+                    s.wl ^= 1;
+                    if (s.n_after) s.n = s.n_after;
+                    s.tail_first = s.tail_count = s.n_after = 0;
+                }
+                s.rebin_now = false;
             }
         }
-    } else {
+    } else if (part != 2) { // (an unbinned species is pushed whole with the first part)
         const size_t lanes = (s.n + Vec16<T>::N - 1) / Vec16<T>::N;
         if (has_b && !DEPOSIT_ONLY) push3_flat_kernel<T, true, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
         else push3_flat_kernel<T, false, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
@@ -343,17 +367,100 @@ int fft_status(fpic_handle* h, rocfft_status s, const char* what)
     return fail(h, FPIC_ERR_HIP, "%s failed (rocfft_status %d)", what, static_cast<int>(s));
 }
 
+// ---- the library's own FFT passes (fes_fft.hpp)
+template <typename T>
+int fft_x_forward(fpic_handle* h, const long long* fixed, const T* rho, double scale, size_t rows, T* hat)
+{
+    State* st = h->es;
+    const int rpw = fft_tile_columns<T>();
+    fft_x_forward_kernel<T><<<blocks_for(rows, rpw), kFftThreads, fft_lds_bytes<T>(st->nx, rpw), h->stream>>>(fixed, rho, scale, rows, st->nx, fft_log2(st->nx), rpw, hat);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+template <typename T>
+int fft_x_inverse(fpic_handle* h, const T* hat, size_t rows, T* phi)
+{
+    State* st = h->es;
+    const int rpw = fft_tile_columns<T>();
+    fft_x_inverse_kernel<T><<<blocks_for(rows, rpw), kFftThreads, fft_lds_bytes<T>(st->nx, rpw), h->stream>>>(hat, rows, st->nx, fft_log2(st->nx), rpw, phi);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+// columns of N points at `stride` complex elements, `outer` lines of them `outer_stride` apart (x fastest, nxh values)
+template <typename T, int MODE>
+int fft_columns(fpic_handle* h, T* hat, size_t outer_stride, size_t stride, int outer, int N, int y0 = 0)
+{
+    State* st = h->es;
+    const int nxh = st->nx / 2 + 1, C = fft_tile_columns<T>();
+    const ColLayout L{ outer_stride, stride, outer, nxh };
+    const unsigned tiles = static_cast<unsigned>((nxh + C - 1) / C);
+    fft_columns_kernel<T, MODE><<<static_cast<unsigned>(outer) * tiles, kFftThreads, fft_lds_bytes<T>(N, C), h->stream>>>(
+        hat, L, N, fft_log2(N), y0, st->k2[0], st->k2[1], st->k2[2], 1.0 / (kEps0 * static_cast<double>(st->nodes)));
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+// rho (T) of the whole grid / of a rank's own planes from the integer charge grid, when somebody reads it
+template <typename T>
+int refresh_rho(fpic_handle* h)
+{
+    State* st = h->es;
+    if (st->rho_fresh) return FPIC_OK;
+    const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
+    const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
+    size_t first = 0, count = st->nodes;
+    if (const Domain* d = st->dom; d && d->world > 1) { first = static_cast<size_t>(d->z0) * st->nx * st->ny; count = static_cast<size_t>(d->nzl) * st->nx * st->ny; }
+    rho_real_kernel<T><<<blocks_for(count), 256, 0, h->stream>>>(st->rho_fixed + first, count, scale, static_cast<T*>(st->rho) + first);
+    HIP_TRY(h, hipGetLastError());
+    st->rho_fresh = true;
+    return FPIC_OK;
+}
+
 // rho_fixed -> E4 (es3d_rho_real, es3d_poisson, es3d_gradient)
 template <typename T>
 int launch_solve(fpic_handle* h, bool convert = true)
 {
     State* st = h->es;
     timing_begin(h, KC_SOLVE);
+    const double dv_ = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
+    const double scale_ = h->spec.particle_charge * st->W / (4398046511104.0 * dv_); // q0 W / (2^42 dV)
+    if (st->own_fft && (st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE)) {
+        // five sweeps: x forward (straight from the integer grid), y forward, the whole z direction with the k-space
+        // factor, y inverse, x inverse
+        const int nxh = st->nx / 2 + 1;
+        const size_t rows = static_cast<size_t>(st->ny) * st->nz, line = static_cast<size_t>(st->ny) * nxh;
+        T* hat = static_cast<T*>(st->hat);
+        int rc;
+        if ((rc = fft_x_forward<T>(h, convert ? st->rho_fixed : nullptr, convert ? nullptr : static_cast<const T*>(st->rho), scale_, rows, hat)) ||
+            (rc = fft_columns<T, 0>(h, hat, line, nxh, st->nz, st->ny)) ||
+            (rc = fft_columns<T, 2>(h, hat, nxh, line, st->ny, st->nz)) ||
+            (rc = fft_columns<T, 1>(h, hat, line, nxh, st->nz, st->ny)) ||
+            (rc = fft_x_inverse<T>(h, hat, rows, static_cast<T*>(st->phi))))
+            return rc;
+        if (convert) st->rho_fresh = false;
+        if (st->solver == FPIC_SOLVER_YEE) {
+            em_edge_gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
+                                                                                   static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
+                                                                                   static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey));
+            HIP_TRY(h, hipGetLastError());
+        } else {
+            gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(
+                static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
+                static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4));
+            HIP_TRY(h, hipGetLastError());
+        }
+        timing_end(h);
+        h->solve_launches++;
+        return FPIC_OK;
+    }
     if (convert) { // (a decomposed run has converted its own planes and gathered the others)
         const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
         const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv); // q0 W / (2^42 dV)
         rho_real_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(st->rho_fixed, st->nodes, scale, static_cast<T*>(st->rho));
         HIP_TRY(h, hipGetLastError());
+        st->rho_fresh = true;
     }
     if (st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE) {
         const fdyn::RocFFT& ff = fdyn::rocfft();
@@ -385,29 +492,72 @@ int launch_solve(fpic_handle* h, bool convert = true)
     return FPIC_OK;
 }
 
-template <typename T, bool DEPOSIT_ONLY>
-int deposit_cycle(fpic_handle* h)
+// Interior tile layers of a rank's slab: at least one whole layer of tiles (2^ltz planes) away from either face, so that
+// nothing a particle of an interior tile deposits can reach a plane that is exchanged (a particle drifts at most G planes
+// between two migrations, and G + 1 (electrostatic) / G + 2 (full EM) <= 2^ltz is asked for).  Empty range: no split.
+bool interior_layers(const State* st, uint32_t& lo, uint32_t& hi)
+{
+    const Domain* d = st->dom;
+    lo = hi = 0;
+    if (!d || d->world < 2 || !d->overlap) return false;
+    const int tz = 1 << st->ltz;
+    const int reach = st->solver == FPIC_SOLVER_YEE ? d->G + 2 : d->G + 1;
+    if (reach > tz) return false;
+    const int first = (d->z0 + tz - 1) / tz + 1, last = (d->z0 + d->nzl) / tz - 1; // [first, last)
+    if (first >= last) return false;
+    lo = static_cast<uint32_t>(first); hi = static_cast<uint32_t>(last);
+    return true;
+}
+
+// every species binned (the work list is in tile order) and a non-empty interior: the push may go in two parts
+bool can_split(const State* st)
+{
+    uint32_t lo, hi;
+    if (!interior_layers(st, lo, hi)) return false;
+    for (const Species& s : st->sp)
+        if (!s.binned) return false;
+    return true;
+}
+
+int split_work(fpic_handle* h, Species& s)
 {
     State* st = h->es;
-    timing_begin(h, DEPOSIT_ONLY ? KC_DEPOSIT : KC_PUSH);
-    if (st->dom && st->dom->world > 1) {
-        // a rank of a decomposition deposits on its own planes and the ghost planes only (whatever a particle that has
-        // outrun them adds elsewhere is never read): planes [z0 - G, z0 + nzl + G], periodic
-        const Domain& d = *st->dom;
-        const size_t plane = static_cast<size_t>(st->nx) * st->ny; // nodes
-        const int span = std::min(st->nz, d.nzl + 2 * d.G + 1);
-        const int lo = ((d.z0 - d.G) % st->nz + st->nz) % st->nz;
-        const int head = std::min(span, st->nz - lo);
-        HIP_TRY(h, hipMemsetAsync(st->rho_fixed + lo * plane, 0, head * plane * sizeof(long long), h->stream));
-        if (span > head) HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, (span - head) * plane * sizeof(long long), h->stream));
-    } else {
-        HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, st->nodes * sizeof(long long), h->stream));
+    uint32_t lo, hi;
+    interior_layers(st, lo, hi);
+    work_split_kernel<<<8, 256, 0, h->stream>>>(s.work2[s.wl], s.nwork2[s.wl], static_cast<uint32_t>(st->ntx) * st->nty, lo, hi, static_cast<uint32_t>(s.n), s.split);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
+// part 0: memsets and every species in one go; part 1: memsets and the first part of every species; part 2: the rest
+template <typename T, bool DEPOSIT_ONLY>
+int deposit_cycle(fpic_handle* h, int part = 0)
+{
+    State* st = h->es;
+    if (part != 2) {
+        timing_begin(h, DEPOSIT_ONLY ? KC_DEPOSIT : KC_PUSH);
+        if (st->dom && st->dom->world > 1) {
+            // a rank of a decomposition deposits on its own planes and the ghost planes only (whatever a particle that has
+            // outrun them adds elsewhere is never read): planes [z0 - G, z0 + nzl + G], periodic
+            const Domain& d = *st->dom;
+            const size_t plane = static_cast<size_t>(st->nx) * st->ny; // nodes
+            const int span = std::min(st->nz, d.nzl + 2 * d.G + 1);
+            const int lo = ((d.z0 - d.G) % st->nz + st->nz) % st->nz;
+            const int head = std::min(span, st->nz - lo);
+            HIP_TRY(h, hipMemsetAsync(st->rho_fixed + lo * plane, 0, head * plane * sizeof(long long), h->stream));
+            if (span > head) HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, (span - head) * plane * sizeof(long long), h->stream));
+        } else {
+            HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, st->nodes * sizeof(long long), h->stream));
+        }
+        HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
     }
-    HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
     int rc = FPIC_OK;
-    for (Species& s : st->sp)
-        if ((rc = launch_push<T, DEPOSIT_ONLY>(h, s))) break;
-    timing_end(h);
+    for (Species& s : st->sp) {
+        if (part == 1 && s.binned && s.n)
+            if ((rc = split_work(h, s))) break;
+        if ((rc = launch_push<T, DEPOSIT_ONLY>(h, s, part))) break;
+    }
+    if (part != 1) timing_end(h);
     return rc;
 }
 
@@ -460,14 +610,19 @@ int em_nodes(fpic_handle* h, int k0 = 0, int nk = -1)
     return FPIC_OK;
 }
 
+int split_work(fpic_handle* h, Species& s);
+bool can_split(const State* st);
+
 // the currents of one sub-step: gather + Boris + move + integer current deposit of every species (Jfix zeroed by the caller)
 template <typename T>
-int em_push_all(fpic_handle* h)
+int em_push_all(fpic_handle* h, int part = 0)
 {
     State* st = h->es;
     const double dt = h->spec.dt;
     for (Species& s : st->sp) {
         if (!s.n) continue;
+        if (part == 1 && s.binned)
+            if (int rc = split_work(h, s)) return rc;
         EmPushArgs<T> a{};
         a.slab = static_cast<T*>(s.slab[s.cur]); a.stride = s.n_pad; a.n = s.n;
         a.E4n = static_cast<const T*>(st->E4); a.B4n = static_cast<const T*>(st->B4n);
@@ -483,9 +638,10 @@ int em_push_all(fpic_handle* h)
             t.p = a;
             t.ntx = st->ntx; t.nty = st->nty; t.ntz = st->ntz;
             t.work = s.work2[s.wl]; t.nwork = s.nwork2[s.wl];
+            t.split = s.split; t.part = part;
             t.spilled = st->spilled;
             em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmThreads, em_lds_bytes<T>(), h->stream>>>(t);
-        } else {
+        } else if (part != 2) { // (an unbinned species is pushed whole with the first part)
             em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
         }
         HIP_TRY(h, hipGetLastError());
@@ -776,7 +932,18 @@ int create_state(fpic_handle* h)
             (rc = dev_alloc(h, reinterpret_cast<void**>(&st->Jfix), st->nodes * 3 * sizeof(long long), acc)))
             return rc;
     }
-    if (st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE) { // (YEE: the initial field is the Poisson field)
+    // power-of-two grids (8 .. 1024 nodes per axis): the library's own FFT passes; FPIC_POISSON_FFT=rocfft keeps rocFFT (a
+    // development switch: the two agree within the solve's tolerance, tests/test_gpu_es3d.py)
+    {
+        const char* force = std::getenv("FPIC_POISSON_FFT");
+        st->own_fft = fft_supported(st->nx) && fft_supported(st->ny) && fft_supported(st->nz) && !(force && std::strcmp(force, "rocfft") == 0);
+        const size_t most = fft_lds_bytes<T>(1 << kFftMaxLog, fft_tile_columns<T>());
+        if ((e = set_lds(fft_x_forward_kernel<T>, most)) != hipSuccess || (e = set_lds(fft_x_inverse_kernel<T>, most)) != hipSuccess ||
+            (e = set_lds(fft_columns_kernel<T, 0>, most)) != hipSuccess || (e = set_lds(fft_columns_kernel<T, 1>, most)) != hipSuccess ||
+            (e = set_lds(fft_columns_kernel<T, 2>, most)) != hipSuccess)
+            return fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    if ((st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE) && !st->own_fft) { // (YEE: the initial field is the Poisson field)
         const fdyn::RocFFT& ff = fdyn::rocfft();
         if (!ff.ok) return fail(h, FPIC_ERR_STATE, ".solver <- rocFFT is not available (%s); there is no other Poisson solver and no CPU fallback", ff.why.c_str());
         const size_t lengths[3] = { static_cast<size_t>(st->nx), static_cast<size_t>(st->ny), static_cast<size_t>(st->nz) };
@@ -867,6 +1034,9 @@ void release(fpic_handle* h)
                          d->mig_recv[1], static_cast<void*>(d->counts_dev), static_cast<void*>(d->j_recv[0]), static_cast<void*>(d->j_recv[1]) })
             if (p) (void)hipFree(p);
         if (d->counts_host) (void)hipHostFree(d->counts_host);
+        if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
+        if (d->ev_boundary) (void)hipEventDestroy(d->ev_boundary);
+        if (d->ev_ghost) (void)hipEventDestroy(d->ev_ghost);
         for (void* p : { d->hatA, d->hatB, d->xbuf, d->hatZ, d->fft_work[0], d->fft_work[1], d->fft_work[2], d->fft_work[3] })
             if (p) (void)hipFree(p);
         const fdyn::RocFFT& ffd = fdyn::rocfft();
@@ -974,9 +1144,13 @@ int get_cells(fpic_handle* h, int species, int32_t* cells)
 // ---- checkpoint of an undecomposed box: header, per species the raw particle state in the caller's order, the fields
 namespace {
 
+// format version of both checkpoint files: 2 since the header's fpic_spec is the one of ABI 2 (a file written by an
+// older library is refused by its version, not as "truncated")
+constexpr uint32_t kCheckpointVersion = 2;
+
 struct BoxCheckpointHeader {
     char magic[8];        // "FPICBOX1"
-    uint32_t version;     // 1
+    uint32_t version;     // kCheckpointVersion
     uint32_t precision, solver, nspecies;
     int32_t nx, ny, nz;
     uint32_t fields_ready;
@@ -1127,7 +1301,7 @@ int save_rank_checkpoint(fpic_handle* h, const char* path)
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
     RankCheckpointHeader hd{};
     std::memcpy(hd.magic, "FPICRNK1", 8);
-    hd.version = 1; hd.precision = static_cast<uint32_t>(h->prec); hd.solver = static_cast<uint32_t>(st->solver);
+    hd.version = kCheckpointVersion; hd.precision = static_cast<uint32_t>(h->prec); hd.solver = static_cast<uint32_t>(st->solver);
     hd.nspecies = static_cast<uint32_t>(st->sp.size());
     hd.nx = st->nx; hd.ny = st->ny; hd.nz = st->nz; hd.rank = d.rank; hd.world = d.world; hd.ghost_planes = d.G;
     hd.fields_ready = st->fields_ready ? 1 : 0;
@@ -1157,8 +1331,12 @@ int load_rank_checkpoint(fpic_handle* h, const char* path)
     BoxFile bf{ std::fopen(path, "rb") };
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
     RankCheckpointHeader hd{};
-    if (std::fread(&hd, sizeof hd, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICRNK1", 8) != 0 || hd.version != 1)
-        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a rank of a decomposed box (version 1)", path);
+    if (std::fread(&hd, 12, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICRNK1", 8) != 0)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a rank of a decomposed box", path);
+    if (hd.version != kCheckpointVersion)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is a rank checkpoint of format version %u; this library reads version %u (the header embeds fpic_spec of ABI %d)", path, hd.version,
+                    kCheckpointVersion, FPIC_ABI_VERSION);
+    if (std::fread(reinterpret_cast<char*>(&hd) + 12, sizeof hd - 12, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
     if (static_cast<int>(hd.precision) != h->prec || static_cast<int>(hd.solver) != st->solver || hd.nspecies != st->sp.size() || hd.nx != st->nx || hd.ny != st->ny ||
         hd.nz != st->nz || hd.rank != d.rank || hd.world != d.world)
         return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint of rank %d of %d, %u species on %d x %d x %d, precision %u, solver %u; this is rank %d of %d, %zu species on %d x %d x %d, precision %d, solver %d",
@@ -1220,7 +1398,7 @@ int save_checkpoint(fpic_handle* h, const char* path)
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
     BoxCheckpointHeader hd{};
     std::memcpy(hd.magic, "FPICBOX1", 8);
-    hd.version = 1; hd.precision = static_cast<uint32_t>(h->prec); hd.solver = static_cast<uint32_t>(st->solver);
+    hd.version = kCheckpointVersion; hd.precision = static_cast<uint32_t>(h->prec); hd.solver = static_cast<uint32_t>(st->solver);
     hd.nspecies = static_cast<uint32_t>(st->sp.size());
     hd.nx = st->nx; hd.ny = st->ny; hd.nz = st->nz; hd.fields_ready = st->fields_ready ? 1 : 0;
     for (int a = 0; a < 3; ++a) hd.B0[a] = st->B0[a];
@@ -1241,8 +1419,13 @@ int load_checkpoint(fpic_handle* h, const char* path)
     BoxFile bf{ std::fopen(path, "rb") };
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
     BoxCheckpointHeader hd{};
-    if (std::fread(&hd, sizeof hd, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICBOX1", 8) != 0 || hd.version != 1)
-        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a box (version 1)", path);
+    // (magic and version are the first twelve bytes whatever the rest of the header looked like when the file was written)
+    if (std::fread(&hd, 12, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICBOX1", 8) != 0)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a box", path);
+    if (hd.version != kCheckpointVersion)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is a box checkpoint of format version %u; this library reads version %u (the header embeds fpic_spec of ABI %d)", path, hd.version,
+                    kCheckpointVersion, FPIC_ABI_VERSION);
+    if (std::fread(reinterpret_cast<char*>(&hd) + 12, sizeof hd - 12, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
     if (static_cast<int>(hd.precision) != h->prec || static_cast<int>(hd.solver) != st->solver || hd.nspecies != st->sp.size() || hd.nx != st->nx || hd.ny != st->ny ||
         hd.nz != st->nz)
         return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint holds %u species on %d x %d x %d, precision %u, solver %u; the pusher was made for %zu on %d x %d x %d, precision %d, solver %d",
@@ -1327,7 +1510,9 @@ int read_field3(fpic_handle* h, int which, void* out, int dtype)
     size_t count = st->nodes;
     switch (which) {
     case FPIC_F3_E: dev = st->E4; count *= 4; break;
-    case FPIC_F3_RHO: dev = st->rho; break;
+    case FPIC_F3_RHO:
+        if (int rc = h->prec == FPIC_F32 ? refresh_rho<float>(h) : refresh_rho<double>(h)) return rc;
+        dev = st->rho; break;
     case FPIC_F3_PHI: dev = st->phi; break;
     case FPIC_F3_B_NODES: dev = st->B4n; count *= 4; break;
     case FPIC_F3_EDGE_E: dev = st->Ey; count *= 4; break;
@@ -1412,11 +1597,12 @@ struct Ranks {
 };
 
 template <typename T>
-int exchange(Ranks& rk, int which)
+int exchange(Ranks& rk, int which, bool on_comm_stream = false)
 {
     if (rk.rccl) {
         fpic_handle* h = rk.hs[0];
         const fdyn::Rccl& rc = fdyn::rccl();
+        hipStream_t stream = on_comm_stream && h->es->dom->comm_stream ? h->es->dom->comm_stream : h->stream;
         std::vector<Xfer> x;
         dom_xfers<T>(h, which, x);
         if (int e = fcomm::check(h, rc.GroupStart(), "ncclGroupStart")) return e;
@@ -1424,8 +1610,8 @@ int exchange(Ranks& rk, int which)
         int err = FPIC_OK; // (a group once opened is always closed: an error must not leave the communicator inside it)
         for (const Xfer& m : x) {
             if (m.to == me && m.from == me) continue; // to myself: a copy, below
-            if (m.send_bytes && !err) err = fcomm::check(h, rc.Send(m.send, m.send_bytes, ncclChar, m.to, h->comm->nccl, h->stream), "ncclSend");
-            if (m.recv_bytes && !err) err = fcomm::check(h, rc.Recv(m.recv, m.recv_bytes, ncclChar, m.from, h->comm->nccl, h->stream), "ncclRecv");
+            if (m.send_bytes && !err) err = fcomm::check(h, rc.Send(m.send, m.send_bytes, ncclChar, m.to, h->comm->nccl, stream), "ncclSend");
+            if (m.recv_bytes && !err) err = fcomm::check(h, rc.Recv(m.recv, m.recv_bytes, ncclChar, m.from, h->comm->nccl, stream), "ncclRecv");
         }
         const std::string first = h->err;
         const int end = fcomm::check(h, rc.GroupEnd(), "ncclGroupEnd");
@@ -1433,7 +1619,7 @@ int exchange(Ranks& rk, int which)
         if (end) return end;
         for (const Xfer& m : x)
             if (m.to == me && m.from == me && m.send_bytes && m.recv != m.send)
-                HIP_TRY(h, hipMemcpyAsync(m.recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(m.recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, stream));
         return FPIC_OK;
     }
     std::vector<std::vector<Xfer>> all(rk.hs.size());
@@ -1449,6 +1635,30 @@ int exchange(Ranks& rk, int which)
             if (m.send_bytes && peer->recv != m.send)
                 HIP_TRY(rk.hs[r], hipMemcpyAsync(peer->recv, m.send, m.send_bytes, hipMemcpyDeviceToDevice, rk.hs[0]->stream));
         }
+    return FPIC_OK;
+}
+
+// The exchange that follows may start once everything queued so far on the handle's stream has run (fork), and what is
+// queued on the handle's stream after the join waits for it.  RCCL transport only: a group has one queue, where the
+// order of submission already is the order of execution.
+int comm_fork(Ranks& rk)
+{
+    if (!rk.rccl) return FPIC_OK;
+    fpic_handle* h = rk.hs[0];
+    Domain& d = *h->es->dom;
+    if (!d.comm_stream) return FPIC_OK;
+    HIP_TRY(h, hipEventRecord(d.ev_boundary, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(d.comm_stream, d.ev_boundary, 0));
+    return FPIC_OK;
+}
+int comm_join(Ranks& rk)
+{
+    if (!rk.rccl) return FPIC_OK;
+    fpic_handle* h = rk.hs[0];
+    Domain& d = *h->es->dom;
+    if (!d.comm_stream) return FPIC_OK;
+    HIP_TRY(h, hipEventRecord(d.ev_ghost, d.comm_stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, d.ev_ghost, 0));
     return FPIC_OK;
 }
 
@@ -1643,13 +1853,21 @@ int solve_distributed(Ranks& rk)
         void* ob[1] = { out };
         return fft_status(h, ff.execute(plan, ib, ob, info), what);
     };
+    const bool own = rk.hs[0]->es->own_fft;
     if (int e = each([&](fpic_handle* h) -> int {
             State* st = h->es;
             Domain& d = *st->dom;
             const int nxh = st->nx / 2 + 1;
             const size_t plane = static_cast<size_t>(st->nx) * st->ny;
             timing_begin(h, KC_SOLVE);
-            if (int e2 = run_fft(h, d.p2f, d.i2f, static_cast<T*>(st->rho) + d.z0 * plane, d.hatA, "rocfft_execute (2-D forward)")) return e2;
+            if (own) { // x pass straight from the integer grid of the own planes, then the y pass
+                const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
+                const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
+                if (int e2 = fft_x_forward<T>(h, st->rho_fixed + d.z0 * plane, nullptr, scale, static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(d.hatA))) return e2;
+                if (int e2 = fft_columns<T, 0>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny)) return e2;
+            } else if (int e2 = run_fft(h, d.p2f, d.i2f, static_cast<T*>(st->rho) + d.z0 * plane, d.hatA, "rocfft_execute (2-D forward)")) {
+                return e2;
+            }
             const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
             transpose_pack_kernel<T><<<blocks_for(total), 256, 0, h->stream>>>(static_cast<const T*>(d.hatA), nxh, st->ny, d.nzl, d.nyl, static_cast<T*>(d.xbuf));
             HIP_TRY(h, hipGetLastError());
@@ -1660,6 +1878,8 @@ int solve_distributed(Ranks& rk)
             State* st = h->es;
             Domain& d = *st->dom;
             const int nxh = st->nx / 2 + 1;
+            if (own) // the whole z direction in one sweep over hatB [nz][nyl][nxh]: forward, k-space factor, inverse
+                return fft_columns<T, 2>(h, static_cast<T*>(d.hatB), nxh, static_cast<size_t>(d.nyl) * nxh, d.nyl, st->nz, d.rank * d.nyl);
             // hatB [nz][nyl][nxh] -> hatZ [nyl * nxh][nz], contiguous transforms along z, the k-space factor, and back
             const int cols = d.nyl * nxh;
             const dim3 gf((cols + 31) / 32, (st->nz + 31) / 32), gb((st->nz + 31) / 32, (cols + 31) / 32);
@@ -1684,6 +1904,10 @@ int solve_distributed(Ranks& rk)
             const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
             transpose_unpack_kernel<T><<<blocks_for(total), 256, 0, h->stream>>>(static_cast<const T*>(d.xbuf), nxh, st->ny, d.nzl, d.nyl, static_cast<T*>(d.hatA));
             HIP_TRY(h, hipGetLastError());
+            if (own) {
+                if (int e2 = fft_columns<T, 1>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny)) return e2;
+                return fft_x_inverse<T>(h, static_cast<const T*>(d.hatA), static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(st->phi) + d.z0 * plane);
+            }
             return run_fft(h, d.p2i, d.i2i, d.hatA, static_cast<T*>(st->phi) + d.z0 * plane, "rocfft_execute (2-D inverse)");
         })) return e;
     if (int e = exchange<T>(rk, X_PHI)) return e;
@@ -1703,10 +1927,10 @@ int solve_distributed(Ranks& rk)
 }
 
 template <typename T>
-int dom_fields(Ranks& rk)
+int dom_fields(Ranks& rk, bool ghost_exchanged)
 {
     const bool multi = rk.hs[0]->es->dom->world > 1;
-    if (multi)
+    if (multi && !ghost_exchanged)
         if (int e = exchange<T>(rk, X_GHOST)) return e;
     for (fpic_handle* h : rk.hs) {
         State* st = h->es;
@@ -1718,10 +1942,18 @@ int dom_fields(Ranks& rk)
             ghost_add_kernel<<<blocks_for(d.G * plane), 256, 0, h->stream>>>(st->rho_fixed + (d.z0 + d.nzl - d.G) * plane, d.ghost_recv[0], d.G * plane);
             ghost_add_kernel<<<blocks_for((d.G + 1) * plane), 256, 0, h->stream>>>(st->rho_fixed + d.z0 * plane, d.ghost_recv[1], (d.G + 1) * plane);
         }
-        const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
-        const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
-        const size_t own = d.nzl * plane, off = d.z0 * plane;
-        rho_real_kernel<T><<<blocks_for(own), 256, 0, h->stream>>>(st->rho_fixed + off, own, scale, static_cast<T*>(st->rho) + off);
+        // the own planes as T: what the replicated solve gathers and what rocFFT's 2-D transforms read; the library's own
+        // x pass reads the integer grid itself
+        const bool needs_rho = multi && !(d.distributed && st->own_fft);
+        if (needs_rho) {
+            const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
+            const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
+            const size_t own = d.nzl * plane, off = d.z0 * plane;
+            rho_real_kernel<T><<<blocks_for(own), 256, 0, h->stream>>>(st->rho_fixed + off, own, scale, static_cast<T*>(st->rho) + off);
+            st->rho_fresh = true;
+        } else if (multi) {
+            st->rho_fresh = false;
+        }
         HIP_TRY(h, hipGetLastError());
         timing_end(h);
     }
@@ -1729,12 +1961,15 @@ int dom_fields(Ranks& rk)
     if (multi)
         if (int e = allgather_rho<T>(rk)) return e;
     for (fpic_handle* h : rk.hs)
-        if (int e = launch_solve<T>(h, /*convert=*/false)) return e;
+        if (int e = launch_solve<T>(h, /*convert=*/!multi)) return e; // (a world of one is one handle's solve)
     return FPIC_OK;
 }
 
 template <typename T>
 int dom_em_after_precalc(Ranks& rk);
+
+template <typename T>
+int dom_fields(Ranks& rk, bool ghost_exchanged);
 
 template <typename T>
 int dom_precalc(Ranks& rk)
@@ -1743,7 +1978,7 @@ int dom_precalc(Ranks& rk)
         if (int e = deposit_cycle<T, true>(h)) return e;
         h->deposit_launches++;
     }
-    if (int e = dom_fields<T>(rk)) return e;
+    if (int e = dom_fields<T>(rk, false)) return e;
     if (rk.hs[0]->es->solver == FPIC_SOLVER_YEE)
         if (int e = dom_em_after_precalc<T>(rk)) return e;
     for (fpic_handle* h : rk.hs) h->es->fields_ready = true;
@@ -1783,6 +2018,8 @@ int dom_em_substep(Ranks& rk)
         for (fpic_handle* h : rk.hs)
             if (int e = bin_all<T>(h, true)) return e;
     }
+    bool split = multi;
+    for (fpic_handle* h : rk.hs) split &= can_split(h->es);
     if (multi && s0->dom->halos_stale) { // fields restored from the ranks' checkpoints: own planes only
         if (int e = exchange<T>(rk, X_EM_E)) return e;
         if (int e = exchange<T>(rk, X_EM_B)) return e;
@@ -1803,11 +2040,20 @@ int dom_em_substep(Ranks& rk)
         } else {
             HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, st->nodes * 3 * sizeof(long long), h->stream));
         }
-        if (int e = em_push_all<T>(h)) return e;
-        timing_end(h);
+        if (int e = em_push_all<T>(h, split ? 1 : 0)) return e;
+        if (!split) timing_end(h);
     }
-    if (multi)
+    if (split) { // the current's ghost planes travel while the interior of the slab is pushed (see dom_substep)
+        if (int e = comm_fork(rk)) return e;
+        if (int e = exchange<T>(rk, X_EM_J, /*on_comm_stream=*/true)) return e;
+        for (fpic_handle* h : rk.hs) {
+            if (int e = em_push_all<T>(h, 2)) return e;
+            timing_end(h);
+        }
+        if (int e = comm_join(rk)) return e;
+    } else if (multi) {
         if (int e = exchange<T>(rk, X_EM_J)) return e;
+    }
     for (fpic_handle* h : rk.hs) {
         State* st = h->es;
         const Domain& d = *st->dom;
@@ -1863,15 +2109,36 @@ int dom_substep(Ranks& rk)
         for (fpic_handle* h : rk.hs)
             if (int e = bin_all<T>(h, false)) return e;
     }
-    for (fpic_handle* h : rk.hs) {
-        if (int e = deposit_cycle<T, false>(h)) return e;
+    // The tile layers along the slab's faces are pushed first; their deposits complete the ghost planes, which then
+    // travel (RCCL: on the communicator's stream) while the interior of the slab is pushed.  Every rank takes the same
+    // branch: the condition depends on the decomposition and on "every species is binned", which holds on every rank
+    // once the first migration has run.
+    bool split = true;
+    for (fpic_handle* h : rk.hs) split &= can_split(h->es);
+    auto count = [](fpic_handle* h) {
         State* st = h->es;
         st->substeps_since_bin++;
         st->dom->substeps_since_migration++;
         h->step_launches++;
         h->particle_updates += total_particles(st);
+    };
+    if (!split) {
+        for (fpic_handle* h : rk.hs) {
+            if (int e = deposit_cycle<T, false>(h)) return e;
+            count(h);
+        }
+        return dom_fields<T>(rk, false);
     }
-    return dom_fields<T>(rk);
+    for (fpic_handle* h : rk.hs)
+        if (int e = deposit_cycle<T, false>(h, 1)) return e;
+    if (int e = comm_fork(rk)) return e;
+    if (int e = exchange<T>(rk, X_GHOST, /*on_comm_stream=*/true)) return e;
+    for (fpic_handle* h : rk.hs) {
+        if (int e = deposit_cycle<T, false>(h, 2)) return e;
+        count(h);
+    }
+    if (int e = comm_join(rk)) return e;
+    return dom_fields<T>(rk, true);
 }
 
 int dom_ranks_of(fpic_handle* h, Ranks& rk)
@@ -1993,20 +2260,31 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
             if ((rc = dev_alloc(h, reinterpret_cast<void**>(&d->j_recv[k]), static_cast<size_t>(d->H) * plane * 3 * sizeof(long long), acc))) return rc;
     }
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&d->counts_host), 8 * sizeof(unsigned)));
+    if (const char* v = std::getenv("FPIC_DOMAIN_OVERLAP")) d->overlap = std::strcmp(v, "0") != 0;
+    if (world > 1 && d->overlap) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_TRY(h, hipStreamCreateWithPriority(&d->comm_stream, hipStreamNonBlocking, hi)); // (its few workgroups must be placed while the push fills the chip)
+        HIP_TRY(h, hipEventCreateWithFlags(&d->ev_boundary, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&d->ev_ghost, hipEventDisableTiming));
+    }
     std::memset(d->counts_host, 0, 8 * sizeof(unsigned));
     for (Species& s : st->sp) s.n = 0; // the rank's particles arrive through domain_set_particles
     if (distributed_solve && world > 1 && st->solver == FPIC_SOLVER_POISSON_FFT) {
         if (st->ny % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d rows along y do not divide into %d shares for the decomposed solve", st->ny, world);
         if (ghost_planes + 2 > nzl) return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- the decomposed solve needs ghost_planes + 2 <= %d planes per slab", nzl);
-        const fdyn::RocFFT& ff = fdyn::rocfft();
-        if (!ff.ok) return fail(h, FPIC_ERR_STATE, "rocFFT is not available (%s)", ff.why.c_str());
         d->distributed = true;
         d->nyl = st->ny / world;
         const size_t nxh = st->nx / 2 + 1, esz = h->esize;
         const size_t cbytes = nxh * st->ny * nzl * 2 * esz;
-        if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc)) ||
-            (rc = dev_alloc(h, &d->hatZ, cbytes, acc)))
-            return rc;
+        if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc))) return rc;
+        if (st->own_fft) { // the library's own passes work in place on hatA / hatB: no plans, no z-major copy
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            return FPIC_OK;
+        }
+        const fdyn::RocFFT& ff = fdyn::rocfft();
+        if (!ff.ok) return fail(h, FPIC_ERR_STATE, "rocFFT is not available (%s)", ff.why.c_str());
+        if ((rc = dev_alloc(h, &d->hatZ, cbytes, acc))) return rc;
         const rocfft_precision prec = h->prec == FPIC_F32 ? rocfft_precision_single : rocfft_precision_double;
         const size_t len2[2] = { static_cast<size_t>(st->nx), static_cast<size_t>(st->ny) };
         const size_t lenz[1] = { static_cast<size_t>(st->nz) };

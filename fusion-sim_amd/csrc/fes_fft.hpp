@@ -1,0 +1,296 @@
+// fes_fft.hpp — the hand-written FFT of the CART3D Poisson solve (power-of-two grids): Stockham radix-8/4/2 passes on
+// tiles held in LDS, one HBM sweep per pass of the 3-D transform and ONE sweep for the whole z direction (forward
+// transform, k-space factor, inverse transform fused).  No reference counterpart (the reference has no field solve in its
+// step loop, empic.js:1436-1505): PARITY UNPINNED, the definition is oracle/es3d_oracle_impl.h
+// (es3d_poisson: phi_hat = rho_hat / (eps0 K^2), K^2 the eigenvalues of the 3-point Laplacian, mean mode 0), which these
+// kernels meet within the solve's tolerance (2e-5 fp32 / 1e-10 fp64), not bit for bit — exactly as rocFFT did.
+//
+// Why not rocFFT here: its strided-column kernels run a 512-point pass at 1.7 TB/s on this part
+// (profiles/r02_c4_kernel_stats.csv: fft_rtc_*_len512_*_sbcc, 610 us for 1.07 GB), and the conversion, k-space and
+// gradient sweeps around it cannot be fused into its kernels.  Grids that are not powers of two keep the rocFFT path.
+//
+// The arithmetic core (radix butterflies, the Stockham index maps) is plain C++ that also compiles for the host:
+// tests/test_fft_core.py builds it with g++ and checks every supported length against a direct DFT.
+#pragma once
+
+#if defined(__HIPCC__)
+#define FESFFT_HD __host__ __device__ __forceinline__
+#else
+#define FESFFT_HD inline
+#endif
+
+namespace fesfft {
+
+template <typename T>
+struct C2 {
+    T x, y;
+};
+
+// load / store through a pointer in any address space (a struct cannot be assigned across address spaces as a whole)
+template <typename T, typename P> FESFFT_HD C2<T> ldc(P p, int i) { return C2<T>{ p[i].x, p[i].y }; }
+template <typename T, typename P> FESFFT_HD void stc(P p, int i, C2<T> v) { p[i].x = v.x; p[i].y = v.y; }
+
+template <typename T> FESFFT_HD C2<T> operator+(C2<T> a, C2<T> b) { return { a.x + b.x, a.y + b.y }; }
+template <typename T> FESFFT_HD C2<T> operator-(C2<T> a, C2<T> b) { return { a.x - b.x, a.y - b.y }; }
+template <typename T> FESFFT_HD C2<T> cmul(C2<T> a, C2<T> b) { return { a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
+template <typename T> FESFFT_HD C2<T> cconj(C2<T> a) { return { a.x, -a.y }; }
+// times -i (forward) / +i (inverse): the quarter turn of the transform's direction
+template <typename T, bool INV> FESFFT_HD C2<T> quarter(C2<T> a) { return INV ? C2<T>{ -a.y, a.x } : C2<T>{ a.y, -a.x }; }
+
+template <typename T, bool INV>
+FESFFT_HD void dft2(C2<T>& a, C2<T>& b)
+{
+    const C2<T> t = a;
+    a = t + b;
+    b = t - b;
+}
+
+// natural order in, natural order out
+template <typename T, bool INV>
+FESFFT_HD void dft4(C2<T>& v0, C2<T>& v1, C2<T>& v2, C2<T>& v3)
+{
+    const C2<T> a = v0 + v2, b = v0 - v2, c = v1 + v3, d = quarter<T, INV>(v1 - v3);
+    v0 = a + c; v1 = b + d; v2 = a - c; v3 = b - d;
+}
+
+template <typename T, bool INV>
+FESFFT_HD void dft8(C2<T> (&v)[8])
+{
+    // even and odd halves (decimation in time), then X[k] = E[k] + W8^k O[k], X[k+4] = E[k] - W8^k O[k]
+    dft4<T, INV>(v[0], v[2], v[4], v[6]);
+    dft4<T, INV>(v[1], v[3], v[5], v[7]);
+    const T h = static_cast<T>(0.70710678118654752440);
+    const C2<T> o0 = v[1];
+    const C2<T> o1 = INV ? C2<T>{ (v[3].x - v[3].y) * h, (v[3].x + v[3].y) * h } : C2<T>{ (v[3].x + v[3].y) * h, (v[3].y - v[3].x) * h };   // W8^1 = (1 -+ i) / sqrt 2
+    const C2<T> o2 = quarter<T, INV>(v[5]);                                                                                                  // W8^2 = -+ i
+    const C2<T> o3 = INV ? C2<T>{ (-v[7].x - v[7].y) * h, (v[7].x - v[7].y) * h } : C2<T>{ (v[7].y - v[7].x) * h, (-v[7].x - v[7].y) * h };  // W8^3 = (-1 -+ i) / sqrt 2
+    const C2<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+
+template <typename T, int R, bool INV>
+FESFFT_HD void dft(C2<T> (&v)[R])
+{
+    if constexpr (R == 2) dft2<T, INV>(v[0], v[1]);
+    else if constexpr (R == 4) dft4<T, INV>(v[0], v[1], v[2], v[3]);
+    else dft8<T, INV>(v);
+}
+
+// One butterfly of a Stockham pass of radix R on one column (N points at col[0 .. N), unit stride), Ns = the product
+// of the radices of the passes before it: butterfly j of N / R reads col[j + r N / R], turns input r by
+// W_N^(r k N / (Ns R)) with k = j mod Ns (tw[t] = exp(-2 pi i t / N), conjugated for the inverse), transforms, and — after
+// every butterfly of the column has read — writes col[(j div Ns) Ns R + k + r Ns].  The passes in any order of radices
+// whose product is N leave the transform in natural order (autosort; unnormalised in both directions).
+// (Col / Tw: pointers to C2<T> in whatever address space the caller keeps the column and the table: LDS on the device)
+template <typename T, int R, bool INV, typename Col, typename Tw>
+FESFFT_HD void pass_load(Col col, Tw tw, int N, int Ns, int j, C2<T> (&v)[R])
+{
+    const int per = N / R, k = j & (Ns - 1);
+    const int tstep = k * (N / (Ns * R));
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        v[r] = ldc<T>(col, j + r * per);
+        if (r && Ns > 1) {
+            const C2<T> w = ldc<T>(tw, r * tstep);
+            v[r] = cmul(v[r], INV ? cconj(w) : w);
+        }
+    }
+    dft<T, R, INV>(v);
+}
+
+template <typename T, int R, typename Col>
+FESFFT_HD void pass_store(Col col, int Ns, int j, const C2<T> (&v)[R])
+{
+    const int k = j & (Ns - 1);
+    const int j0 = (j - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) stc<T>(col, j0 + r * Ns, v[r]);
+}
+
+// the radix of the next pass when 2^rem points are still to be factored: 8 while it divides, then 4 or 2
+FESFFT_HD int next_radix_log(int rem) { return rem >= 3 ? 3 : rem; }
+
+} // namespace fesfft
+
+#if defined(__HIPCC__)
+
+#include "fpic_kernels.hpp"
+
+namespace fes {
+
+using fesfft::C2;
+
+constexpr int kFftThreads = 512;
+constexpr int kFftMaxLog = 10, kFftMinLog = 3;          // 8 .. 1024 points per axis
+// columns of a tile: 128 contiguous bytes of a row (16 complex floats, 8 complex doubles)
+template <typename T> constexpr int fft_tile_columns() { return static_cast<int>(128 / sizeof(C2<T>)); }
+// LDS of a tile of `cols` transforms of N points (one complex of padding per column: consecutive columns then start
+// two banks apart, and the transposing loads / stores of a tile are free of bank conflicts) + the twiddle table
+template <typename T> constexpr size_t fft_lds_bytes(int N, int cols) { return (static_cast<size_t>(cols) * (N + 1) + N) * sizeof(C2<T>); }
+
+inline bool fft_supported(int n) { return n >= (1 << kFftMinLog) && n <= (1 << kFftMaxLog) && (n & (n - 1)) == 0; }
+inline int fft_log2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+
+template <typename T> __device__ __forceinline__ void sincospi_(T a, T* s, T* c);
+template <> __device__ __forceinline__ void sincospi_<float>(float a, float* s, float* c) { sincospif(a, s, c); }
+template <> __device__ __forceinline__ void sincospi_<double>(double a, double* s, double* c) { sincospi(a, s, c); }
+
+// tw[t] = exp(-2 pi i t / N), formed in double and rounded once
+template <typename T>
+__device__ __forceinline__ void fft_twiddles(FPIC_LDS C2<T>* tw, int N)
+{
+    for (int t = threadIdx.x; t < N; t += kFftThreads) {
+        double s, c;
+        sincospi(-2.0 * static_cast<double>(t) / static_cast<double>(N), &s, &c);
+        fesfft::stc<T>(tw, t, C2<T>{ static_cast<T>(c), static_cast<T>(s) });
+    }
+}
+
+// one pass of radix R over `cols` columns of N points in LDS (column c at buf + c * ld), in place: a round of the loop
+// takes whole columns (N / R butterflies each, a power of two that divides the workgroup), so "every butterfly of the
+// column has read" is one barrier
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void fft_pass(FPIC_LDS C2<T>* buf, int ld, int cols, const FPIC_LDS C2<T>* tw, int N, int Ns)
+{
+    const int per = N / R;                       // <= 512 = kFftThreads for N <= 1024, R >= 2
+    const int total = per * cols;
+    for (int b0 = 0; b0 < total; b0 += kFftThreads) {
+        const int b = b0 + static_cast<int>(threadIdx.x);
+        const bool active = b < total;
+        const int c = b / per, j = b - c * per;
+        C2<T> v[R];
+        FPIC_LDS C2<T>* col = buf + c * ld;
+        if (active) fesfft::pass_load<T, R, INV>(col, tw, N, Ns, j, v);
+        __syncthreads();
+        if (active) fesfft::pass_store<T, R>(col, Ns, j, v);
+        __syncthreads();
+    }
+}
+
+// all passes of a transform of N = 2^logn points on the tile
+template <typename T, bool INV>
+__device__ __forceinline__ void fft_tile(FPIC_LDS C2<T>* buf, int ld, int cols, const FPIC_LDS C2<T>* tw, int N, int logn)
+{
+    int Ns = 1;
+    for (int rem = logn; rem > 0;) {
+        const int rl = fesfft::next_radix_log(rem);
+        if (rl == 3) fft_pass<T, 8, INV>(buf, ld, cols, tw, N, Ns);
+        else if (rl == 2) fft_pass<T, 4, INV>(buf, ld, cols, tw, N, Ns);
+        else fft_pass<T, 2, INV>(buf, ld, cols, tw, N, Ns);
+        Ns <<= rl;
+        rem -= rl;
+    }
+}
+
+// ---- x pass, forward: rows of nx real values -> rows of nx / 2 + 1 complex values.  The real values are the charge
+// grid itself, rho = T((double)fixed * scale) (es3d_rho_real) formed while the row is loaded: no separate conversion
+// sweep.  A workgroup takes `rows_per_wg` rows at a time.
+template <typename T>
+__global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long long* __restrict__ fixed, const T* __restrict__ rho, double scale, size_t rows, int nx, int logn,
+                                                                    int rows_per_wg, T* __restrict__ hat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
+    FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
+    const int ld = nx + 1, nxh = nx / 2 + 1;
+    FPIC_LDS C2<T>* tw = buf + rows_per_wg * ld;
+    fft_twiddles<T>(tw, nx);
+    const size_t row0 = static_cast<size_t>(blockIdx.x) * rows_per_wg;
+    const int nrows = static_cast<int>(rows - row0 < static_cast<size_t>(rows_per_wg) ? rows - row0 : rows_per_wg);
+    for (int e = threadIdx.x; e < nrows * nx; e += kFftThreads) {
+        const int r = e / nx, i = e - r * nx;
+        // (rho given: the charge density already converted — a rank of a replicated solve has gathered the others' planes)
+        const T v = fixed ? static_cast<T>(static_cast<double>(fixed[(row0 + r) * nx + i]) * scale) : rho[(row0 + r) * nx + i];
+        fesfft::stc<T>(buf, r * ld + i, C2<T>{ v, static_cast<T>(0) });
+    }
+    __syncthreads();
+    fft_tile<T, false>(buf, ld, nrows, tw, nx, logn);
+    C2<T>* out = reinterpret_cast<C2<T>*>(hat);
+    for (int e = threadIdx.x; e < nrows * nxh; e += kFftThreads) {
+        const int r = e / nxh, i = e - r * nxh;
+        out[(row0 + r) * nxh + i] = fesfft::ldc<T>(buf, r * ld + i);
+    }
+}
+
+// ---- x pass, inverse: rows of nx / 2 + 1 complex values (the half spectrum of a real row) -> rows of nx real values
+template <typename T>
+__global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __restrict__ hat, size_t rows, int nx, int logn, int rows_per_wg, T* __restrict__ phi)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
+    FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
+    const int ld = nx + 1, nxh = nx / 2 + 1;
+    FPIC_LDS C2<T>* tw = buf + rows_per_wg * ld;
+    fft_twiddles<T>(tw, nx);
+    const size_t row0 = static_cast<size_t>(blockIdx.x) * rows_per_wg;
+    const int nrows = static_cast<int>(rows - row0 < static_cast<size_t>(rows_per_wg) ? rows - row0 : rows_per_wg);
+    const C2<T>* in = reinterpret_cast<const C2<T>*>(hat);
+    for (int e = threadIdx.x; e < nrows * nxh; e += kFftThreads) {
+        const int r = e / nxh, i = e - r * nxh;
+        const C2<T> v = in[(row0 + r) * nxh + i];
+        fesfft::stc<T>(buf, r * ld + i, v);
+        if (i && i < nx - i) fesfft::stc<T>(buf, r * ld + nx - i, fesfft::cconj(v));   // the mirror half of a real row's spectrum
+    }
+    __syncthreads();
+    fft_tile<T, true>(buf, ld, nrows, tw, nx, logn);
+    for (int e = threadIdx.x; e < nrows * nx; e += kFftThreads) {
+        const int r = e / nx, i = e - r * nx;
+        phi[(row0 + r) * nx + i] = buf[r * ld + i].x;
+    }
+}
+
+// ---- column passes.  The half spectrum is [outer2][N or outer1][...][nxh] with the x index fastest; a tile is C
+// consecutive x of every point of ONE column line: element (idx, c) of tile (o, t) sits at
+//     base + o * outer_stride + idx * stride + t * C + c.
+// MODE 0: forward transform; 1: inverse; 2: forward, k-space factor, inverse — the whole z direction of the solve in one
+// sweep (the factor needs the mode indices: kx = t C + c, ky = y0 + o, kz = idx).
+struct ColLayout {
+    size_t outer_stride, stride;   // complex elements
+    int outer, nxh;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict__ hat, ColLayout L, int N, int logn, int y0, const double* __restrict__ k2x,
+                                                                  const double* __restrict__ k2y, const double* __restrict__ k2z, double inv_eps0_n)
+{
+    constexpr int C = fft_tile_columns<T>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
+    FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
+    const int ld = N + 1;
+    FPIC_LDS C2<T>* tw = buf + C * ld;
+    fft_twiddles<T>(tw, N);
+    const int tiles = (L.nxh + C - 1) / C;
+    const int o = static_cast<int>(blockIdx.x / tiles), t = static_cast<int>(blockIdx.x % tiles);
+    const int i0 = t * C, cols = L.nxh - i0 < C ? L.nxh - i0 : C;
+    C2<T>* base = reinterpret_cast<C2<T>*>(hat) + static_cast<size_t>(o) * L.outer_stride + i0;
+    for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
+        const int idx = e / C, c = e - idx * C;
+        if (c < cols) fesfft::stc<T>(buf, c * ld + idx, base[static_cast<size_t>(idx) * L.stride + c]);
+    }
+    __syncthreads();
+    if constexpr (MODE == 1) fft_tile<T, true>(buf, ld, cols, tw, N, logn);
+    else fft_tile<T, false>(buf, ld, cols, tw, N, logn);
+    if constexpr (MODE == 2) {
+        // phi_hat = rho_hat / (eps0 K^2 N), K^2 = (k2x + k2y) + k2z in double, the mean mode 0 (es3d_poisson, kspace_kernel)
+        const int j = y0 + o;
+        for (int e = threadIdx.x; e < N * cols; e += kFftThreads) {
+            const int c = e / N, k = e - c * N;
+            const int i = i0 + c;
+            const double K2 = (k2x[i] + k2y[j]) + k2z[k];
+            const T g = (i | j | k) ? static_cast<T>(inv_eps0_n / K2) : static_cast<T>(0);
+            const C2<T> v = fesfft::ldc<T>(buf, c * ld + k);
+            fesfft::stc<T>(buf, c * ld + k, C2<T>{ v.x * g, v.y * g });
+        }
+        __syncthreads();
+        fft_tile<T, true>(buf, ld, cols, tw, N, logn);
+    }
+    for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
+        const int idx = e / C, c = e - idx * C;
+        if (c < cols) base[static_cast<size_t>(idx) * L.stride + c] = fesfft::ldc<T>(buf, c * ld + idx);
+    }
+}
+
+} // namespace fes
+
+#endif // __HIPCC__

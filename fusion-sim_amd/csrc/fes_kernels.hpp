@@ -100,6 +100,11 @@ struct Push3Args {
     int ntx, nty, ntz;
     const BlockWork* work;
     const uint32_t* nwork;
+    // a rank of a decomposition pushes the tiles along its slab's faces first (part 1), so that the ghost planes can travel
+    // while the interior is pushed (part 2); split[0..1] = the interior's range of the work list (work_split_kernel);
+    // part 0: the whole list
+    const uint32_t* split;
+    int part;
     unsigned long long* spilled;
     uint32_t* tile_count;            // census of the NEW positions per tile, zeroed by the host
     // REBIN launch: the other particle set and its bin table
@@ -431,6 +436,38 @@ struct Neighbourhood3 {
     }
 };
 
+// The work list is in tile order, i.e. by tile layer along z: the interior layers of a slab are one contiguous range
+// [split[0], split[1]) of it.  Item of workgroup b: part 0 -> b; part 2 (interior) -> split[0] + b; part 1 (the layers along
+// the faces and the ghost layers beyond them) -> b below the range, b + its length above.  ~0u: nothing to do.
+__device__ __forceinline__ uint32_t work_item(uint32_t b, int part, const uint32_t* __restrict__ split, uint32_t nwork)
+{
+    if (part == 0) return b < nwork ? b : ~0u;
+    const uint32_t lo = split[0], hi = split[1];
+    if (part == 2) return lo + b < hi ? lo + b : ~0u;
+    const uint32_t i = b < lo ? b : b + (hi - lo);
+    return i < nwork ? i : ~0u;
+}
+
+// split[0..1] = the range of work items whose tile layer (tile / tiles_per_layer) lies in [layer_lo, layer_hi); split[2..3] =
+// the range of particle slots those items cover (the migration's pack pass skips it: nobody leaves from the interior)
+static __global__ __launch_bounds__(256) void work_split_kernel(const BlockWork* __restrict__ work, const uint32_t* __restrict__ nwork, uint32_t tiles_per_layer,
+                                                                uint32_t layer_lo, uint32_t layer_hi, uint32_t n_slots, uint32_t* __restrict__ split)
+{
+    const uint32_t n = *nwork;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n == 0 || layer_lo >= layer_hi)) { split[0] = split[1] = 0; split[2] = split[3] = 0; }
+    if (n == 0 || layer_lo >= layer_hi) return;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+        // boundaries between item i - 1 and item i (layer of "item -1" = none below, of "item n" = none above)
+        const uint32_t here = i < n ? work[i].tile / tiles_per_layer : ~0u;
+        const bool has_prev = i > 0;
+        const uint32_t prev = has_prev ? work[i - 1].tile / tiles_per_layer : 0u;
+        const bool first_ge_lo = here >= layer_lo && (!has_prev || prev < layer_lo);
+        const bool first_ge_hi = here >= layer_hi && (!has_prev || prev < layer_hi);
+        if (first_ge_lo) { split[0] = i; split[2] = i < n ? work[i].begin : n_slots; }
+        if (first_ge_hi) { split[1] = i; split[3] = i < n ? work[i].begin : n_slots; }
+    }
+}
+
 template <typename T>
 constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 * sizeof(T) + 8) + 3 * kNbr3 * sizeof(uint32_t) + 16; }
 
@@ -457,8 +494,9 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lrho + kWN);
     FPIC_LDS uint32_t* lrank = lcensus + kNbr3;
     FPIC_LDS uint32_t* lrange = lrank + kNbr3;
-    if (blockIdx.x >= *a.nwork) return;
-    const BlockWork w = a.work[blockIdx.x];
+    const uint32_t item = work_item(blockIdx.x, a.part, a.split, *a.nwork);
+    if (item == ~0u) return;
+    const BlockWork w = a.work[item];
     const int ti = static_cast<int>(w.tile % a.ntx), tj = static_cast<int>((w.tile / a.ntx) % a.nty), tk = static_cast<int>(w.tile / (a.ntx * a.nty));
     const int ox = ti * kTX - kHalo, oy = tj * kTY - kHalo, oz = tk * kTZ - kHalo;
     const Neighbourhood3 nb{ ti, tj, tk, a.ntx, a.nty, a.ntz };
@@ -1109,6 +1147,8 @@ struct EmTileArgs {
     int ntx, nty, ntz;
     const BlockWork* work;
     const uint32_t* nwork;
+    const uint32_t* split;   // see Push3Args
+    int part;
     unsigned long long* spilled;
 };
 
@@ -1256,8 +1296,9 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     FPIC_LDS T* lE = (FPIC_LDS T*)ldsem;
     FPIC_LDS T* lB = lE + 4 * WN;
     FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(lB + 4 * WN);
-    if (blockIdx.x >= *t.nwork) return;
-    const BlockWork w = t.work[blockIdx.x];
+    const uint32_t item = work_item(blockIdx.x, t.part, t.split, *t.nwork);
+    if (item == ~0u) return;
+    const BlockWork w = t.work[item];
     const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
     const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
     using V = typename NatVec16<T>::type;

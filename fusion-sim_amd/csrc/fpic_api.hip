@@ -588,9 +588,11 @@ void release(fpic_handle* h)
 // inverse CDF, entropy, running average).  The reference keeps its state only in GPU textures
 // and never reads it back (utilities.js:701-711 exists but is unused): this is the read-back /
 // resume path a host needs.
+// 2 since the header's fpic_spec is the one of ABI 2: a file of an older library is refused by its version
+constexpr uint32_t kRzCheckpointVersion = 2;
 struct CheckpointHeader {
     char magic[8];          // "FPICCKP1"
-    uint32_t version;       // 1
+    uint32_t version;       // kRzCheckpointVersion
     uint32_t precision;     // fpic_dtype of every T below
     uint64_t n;
     int32_t nr, nz;
@@ -1244,7 +1246,7 @@ int fpic_save_checkpoint(fpic_handle* h, const char* path)
     if (!fc.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
     CheckpointHeader hd{};
     std::memcpy(hd.magic, "FPICCKP1", 8);
-    hd.version = 1; hd.precision = static_cast<uint32_t>(h->prec); hd.n = h->n; hd.nr = h->nr; hd.nz = h->nz;
+    hd.version = kRzCheckpointVersion; hd.precision = static_cast<uint32_t>(h->prec); hd.n = h->n; hd.nr = h->nr; hd.nz = h->nz;
     hd.t_substep = h->t_substep; hd.rng_mode = h->spec.rng_mode; hd.spec = h->spec;
     if (std::fwrite(&hd, sizeof hd, 1, fc.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint write failed");
     return h->prec == FPIC_F32 ? save_state<float>(h, fc.f) : save_state<double>(h, fc.f);
@@ -1259,8 +1261,13 @@ int fpic_load_checkpoint(fpic_handle* h, const char* path)
     FileCloser fc{ std::fopen(path, "rb") };
     if (!fc.f) return fail(h, FPIC_ERR_STATE, "cannot open %s", path);
     CheckpointHeader hd{};
-    if (std::fread(&hd, sizeof hd, 1, fc.f) != 1 || std::memcmp(hd.magic, "FPICCKP1", 8) != 0 || hd.version != 1)
-        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a fusionpic checkpoint (version 1)", path);
+    // (magic and version are the first twelve bytes whatever the rest of the header looked like when the file was written)
+    if (std::fread(&hd, 12, 1, fc.f) != 1 || std::memcmp(hd.magic, "FPICCKP1", 8) != 0)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a fusionpic checkpoint", path);
+    if (hd.version != kRzCheckpointVersion)
+        return fail(h, FPIC_ERR_INVALID_ARG, "%s is a checkpoint of format version %u; this library reads version %u (the header embeds fpic_spec of ABI %d)", path, hd.version,
+                    kRzCheckpointVersion, FPIC_ABI_VERSION);
+    if (std::fread(reinterpret_cast<char*>(&hd) + 12, sizeof hd - 12, 1, fc.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
     if (hd.n != h->n || hd.nr != h->nr || hd.nz != h->nz || static_cast<int>(hd.precision) != h->prec || hd.rng_mode != h->spec.rng_mode)
         return fail(h, FPIC_ERR_INVALID_ARG, ".spec <- checkpoint holds %llu particles on %d x %d, precision %u, rng %d; the pusher was made for %zu on %d x %d, precision %d, rng %d",
                     static_cast<unsigned long long>(hd.n), hd.nr, hd.nz, hd.precision, hd.rng_mode, h->n, h->nr, h->nz, h->prec, h->spec.rng_mode);

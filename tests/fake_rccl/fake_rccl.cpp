@@ -144,7 +144,9 @@ ncclResult_t run(std::vector<Op>& ops)
         }
         bool ok = msg.bytes == o.bytes;                                  // count / type mismatch of a matched pair
         if (!ok) rc = ncclInvalidArgument;
-        else if (hipMemcpy(o.rptr, msg.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+        // (a device-to-device hipMemcpy may return before the copy has run: the sender must not be told "taken" — and reuse
+        // its buffer on a stream of its own — before the data has really left it)
+        else if (hipMemcpy(o.rptr, msg.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = ncclUnhandledCudaError;
         {
             std::lock_guard<std::mutex> lk(w->m);
             w->taken[msg.id] = ok ? 1 : 2;
@@ -272,6 +274,7 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
         if (dst == w->published[q]) continue; // in place
         if (hipMemcpy(dst, w->published[q], bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
     }
+    if (hipDeviceSynchronize() != hipSuccess) rc = ncclUnhandledCudaError; // (device-to-device copies may still be in flight)
     w->barrier();
     return rc;
 }

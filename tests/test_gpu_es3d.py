@@ -409,7 +409,7 @@ def test_slab_decomposition_reproduces_one_gpu_bit_for_bit(fp, eo, precision, wo
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
-@pytest.mark.parametrize("world,shape", [(2, (16, 16, 16)), (4, (24, 16, 32)), (8, (20, 32, 64))])
+@pytest.mark.parametrize("world,shape", [(2, (16, 16, 16)), (4, (24, 16, 32)), (8, (20, 32, 64)), (4, (32, 16, 64)), (8, (64, 32, 128))])
 def test_slab_decomposed_poisson_solve(fp, eo, precision, world, shape):
     """distributed_solve: no rank transforms the whole grid — 2-D transforms of the owned planes, all-to-all transposition,
     transforms along z on ny/N rows of ky, back, potential ghost planes, gradient on the slab and its ghost planes.  The
@@ -663,6 +663,9 @@ def test_box_checkpoint_resume_is_bit_identical(fp, eo, tmp_path, precision, sol
     before = b.getParticles()
     with pytest.raises(fp.FusionPicError, match="truncated"):
         b.loadCheckpoint(tmp_path / "short.ckpt")
+    (tmp_path / "old.ckpt").write_bytes(data[:8] + (1).to_bytes(4, "little") + data[12:])
+    with pytest.raises(fp.FusionPicError, match="format version 1"):
+        b.loadCheckpoint(tmp_path / "old.ckpt")          # a file of an older library: refused by its version, not as "truncated"
     other = fp.makeCylindricalParticlePusher(dict(spec, nz=shape[2] + 8), precision=precision)
     with pytest.raises(fp.FusionPicError):
         other.loadCheckpoint(path)                       # one species, another grid
