@@ -50,7 +50,6 @@ struct Species {
     bool census_fresh = false;  // tile_count holds the census of the current positions (written by the last push)
     bool rebin_pending = false; // tables [wl ^ 1] are laid out from that census: the next push re-bins
     bool rebin_now = false;     // the push in flight is that re-binning (a push in two parts decides once)
-    uint32_t* split = nullptr;  // decomposition: interior range of the work list [0..1] and of the slots [2..3] (work_split_kernel)
 };
 
 struct State {
@@ -150,8 +149,7 @@ int alloc_species(fpic_handle* h, Species& s)
     uint64_t* acc = &h->bytes_grid;
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * (st->ntiles + fpic::kSortMaxBins + 1), acc)) || // + chunk_first of the two-level binning
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.split), 4 * sizeof(uint32_t), acc)))
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * (st->ntiles + fpic::kSortMaxBins + 1), acc))) // + chunk_first of the two-level binning
         return rc;
     for (int k = 0; k < 2; ++k)
         if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_start2[k]), sizeof(uint32_t) * (st->ntiles + 1), acc)) ||
@@ -167,12 +165,13 @@ void free_species(Species& s)
         if (s.slab[k]) (void)hipFree(s.slab[k]);
         if (s.id[k]) (void)hipFree(s.id[k]);
     }
-    if (s.split) (void)hipFree(s.split);
     for (void* p : { static_cast<void*>(s.tile_count), static_cast<void*>(s.tile_cursor), static_cast<void*>(s.tile_start2[0]),
                      static_cast<void*>(s.tile_start2[1]), static_cast<void*>(s.nwork2[0]), static_cast<void*>(s.nwork2[1]),
                      static_cast<void*>(s.work2[0]), static_cast<void*>(s.work2[1]) })
         if (p) (void)hipFree(p);
 }
+
+bool interior_layers(const State* st, uint32_t& lo, uint32_t& hi);
 
 template <typename T>
 Push3Args<T> push_args(fpic_handle* h, const Species& s)
@@ -197,7 +196,7 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     a.Z = s.Z;
     a.ntx = st->ntx; a.nty = st->nty; a.ntz = st->ntz;
     a.work = s.work2[s.wl]; a.nwork = s.nwork2[s.wl];
-    a.split = s.split; a.part = 0;
+    a.part = 0; a.tiles_per_layer = static_cast<uint32_t>(st->ntx) * st->nty; a.layer_lo = a.layer_hi = 0;
     a.spilled = st->spilled;
     a.tile_count = s.tile_count;
     a.id = s.id[s.cur];
@@ -232,6 +231,7 @@ int launch_push(fpic_handle* h, Species& s, int part = 0)
             }
             const bool rebin = s.rebin_now;
             a.part = part;
+            interior_layers(st, a.layer_lo, a.layer_hi);
             if (rebin && has_b) push3_tiles_kernel<T, true, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (rebin) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
@@ -372,8 +372,8 @@ template <typename T>
 int fft_x_forward(fpic_handle* h, const long long* fixed, const T* rho, double scale, size_t rows, T* hat)
 {
     State* st = h->es;
-    const int rpw = fft_tile_columns<T>();
-    fft_x_forward_kernel<T><<<blocks_for(rows, rpw), kFftThreads, fft_lds_bytes<T>(st->nx, rpw), h->stream>>>(fixed, rho, scale, rows, st->nx, fft_log2(st->nx), rpw, hat);
+    const int ppw = fft_tile_columns<T>(); // pairs of rows per workgroup (two real rows ride on one complex transform)
+    fft_x_forward_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(fixed, rho, scale, rows, st->nx, fft_log2(st->nx), ppw, hat);
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -382,8 +382,8 @@ template <typename T>
 int fft_x_inverse(fpic_handle* h, const T* hat, size_t rows, T* phi)
 {
     State* st = h->es;
-    const int rpw = fft_tile_columns<T>();
-    fft_x_inverse_kernel<T><<<blocks_for(rows, rpw), kFftThreads, fft_lds_bytes<T>(st->nx, rpw), h->stream>>>(hat, rows, st->nx, fft_log2(st->nx), rpw, phi);
+    const int ppw = fft_tile_columns<T>();
+    fft_x_inverse_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(hat, rows, st->nx, fft_log2(st->nx), ppw, phi);
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -519,16 +519,6 @@ bool can_split(const State* st)
     return true;
 }
 
-int split_work(fpic_handle* h, Species& s)
-{
-    State* st = h->es;
-    uint32_t lo, hi;
-    interior_layers(st, lo, hi);
-    work_split_kernel<<<8, 256, 0, h->stream>>>(s.work2[s.wl], s.nwork2[s.wl], static_cast<uint32_t>(st->ntx) * st->nty, lo, hi, static_cast<uint32_t>(s.n), s.split);
-    HIP_TRY(h, hipGetLastError());
-    return FPIC_OK;
-}
-
 // part 0: memsets and every species in one go; part 1: memsets and the first part of every species; part 2: the rest
 template <typename T, bool DEPOSIT_ONLY>
 int deposit_cycle(fpic_handle* h, int part = 0)
@@ -552,11 +542,8 @@ int deposit_cycle(fpic_handle* h, int part = 0)
         HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
     }
     int rc = FPIC_OK;
-    for (Species& s : st->sp) {
-        if (part == 1 && s.binned && s.n)
-            if ((rc = split_work(h, s))) break;
+    for (Species& s : st->sp)
         if ((rc = launch_push<T, DEPOSIT_ONLY>(h, s, part))) break;
-    }
     if (part != 1) timing_end(h);
     return rc;
 }
@@ -610,8 +597,8 @@ int em_nodes(fpic_handle* h, int k0 = 0, int nk = -1)
     return FPIC_OK;
 }
 
-int split_work(fpic_handle* h, Species& s);
 bool can_split(const State* st);
+bool interior_layers(const State* st, uint32_t& lo, uint32_t& hi);
 
 // the currents of one sub-step: gather + Boris + move + integer current deposit of every species (Jfix zeroed by the caller)
 template <typename T>
@@ -621,8 +608,6 @@ int em_push_all(fpic_handle* h, int part = 0)
     const double dt = h->spec.dt;
     for (Species& s : st->sp) {
         if (!s.n) continue;
-        if (part == 1 && s.binned)
-            if (int rc = split_work(h, s)) return rc;
         EmPushArgs<T> a{};
         a.slab = static_cast<T*>(s.slab[s.cur]); a.stride = s.n_pad; a.n = s.n;
         a.E4n = static_cast<const T*>(st->E4); a.B4n = static_cast<const T*>(st->B4n);
@@ -638,7 +623,8 @@ int em_push_all(fpic_handle* h, int part = 0)
             t.p = a;
             t.ntx = st->ntx; t.nty = st->nty; t.ntz = st->ntz;
             t.work = s.work2[s.wl]; t.nwork = s.nwork2[s.wl];
-            t.split = s.split; t.part = part;
+            t.part = part; t.tiles_per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
+            interior_layers(st, t.layer_lo, t.layer_hi);
             t.spilled = st->spilled;
             em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmThreads, em_lds_bytes<T>(), h->stream>>>(t);
         } else if (part != 2) { // (an unbinned species is pushed whole with the first part)

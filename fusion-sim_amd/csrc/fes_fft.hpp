@@ -85,14 +85,15 @@ FESFFT_HD void dft(C2<T> (&v)[R])
 // every butterfly of the column has read — writes col[(j div Ns) Ns R + k + r Ns].  The passes in any order of radices
 // whose product is N leave the transform in natural order (autosort; unnormalised in both directions).
 // (Col / Tw: pointers to C2<T> in whatever address space the caller keeps the column and the table: LDS on the device)
+// (point idx of the column sits at col[idx * stride])
 template <typename T, int R, bool INV, typename Col, typename Tw>
-FESFFT_HD void pass_load(Col col, Tw tw, int N, int Ns, int j, C2<T> (&v)[R])
+FESFFT_HD void pass_load(Col col, Tw tw, int N, int Ns, int j, C2<T> (&v)[R], int stride = 1)
 {
     const int per = N / R, k = j & (Ns - 1);
     const int tstep = k * (N / (Ns * R));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        v[r] = ldc<T>(col, j + r * per);
+        v[r] = ldc<T>(col, (j + r * per) * stride);
         if (r && Ns > 1) {
             const C2<T> w = ldc<T>(tw, r * tstep);
             v[r] = cmul(v[r], INV ? cconj(w) : w);
@@ -102,12 +103,12 @@ FESFFT_HD void pass_load(Col col, Tw tw, int N, int Ns, int j, C2<T> (&v)[R])
 }
 
 template <typename T, int R, typename Col>
-FESFFT_HD void pass_store(Col col, int Ns, int j, const C2<T> (&v)[R])
+FESFFT_HD void pass_store(Col col, int Ns, int j, const C2<T> (&v)[R], int stride = 1)
 {
     const int k = j & (Ns - 1);
     const int j0 = (j - k) * R + k;
 #pragma unroll
-    for (int r = 0; r < R; ++r) stc<T>(col, j0 + r * Ns, v[r]);
+    for (int r = 0; r < R; ++r) stc<T>(col, (j0 + r * Ns) * stride, v[r]);
 }
 
 // the radix of the next pass when 2^rem points are still to be factored: 8 while it divides, then 4 or 2
@@ -187,56 +188,66 @@ __device__ __forceinline__ void fft_tile(FPIC_LDS C2<T>* buf, int ld, int cols, 
 
 // ---- x pass, forward: rows of nx real values -> rows of nx / 2 + 1 complex values.  The real values are the charge
 // grid itself, rho = T((double)fixed * scale) (es3d_rho_real) formed while the row is loaded: no separate conversion
-// sweep.  A workgroup takes `rows_per_wg` rows at a time.
+// sweep.  TWO real rows a, b ride on one complex transform z = a + i b; their spectra come apart as
+// A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i (exact halvings).  A workgroup takes 2 * pairs_per_wg rows.
 template <typename T>
 __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long long* __restrict__ fixed, const T* __restrict__ rho, double scale, size_t rows, int nx, int logn,
-                                                                    int rows_per_wg, T* __restrict__ hat)
+                                                                    int pairs_per_wg, T* __restrict__ hat)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
     const int ld = nx + 1, nxh = nx / 2 + 1;
-    FPIC_LDS C2<T>* tw = buf + rows_per_wg * ld;
+    FPIC_LDS C2<T>* tw = buf + pairs_per_wg * ld;
     fft_twiddles<T>(tw, nx);
-    const size_t row0 = static_cast<size_t>(blockIdx.x) * rows_per_wg;
-    const int nrows = static_cast<int>(rows - row0 < static_cast<size_t>(rows_per_wg) ? rows - row0 : rows_per_wg);
-    for (int e = threadIdx.x; e < nrows * nx; e += kFftThreads) {
-        const int r = e / nx, i = e - r * nx;
+    const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
+    const int pairs = static_cast<int>((rows - row0 < static_cast<size_t>(2 * pairs_per_wg) ? rows - row0 : 2 * pairs_per_wg) / 2); // (rows is even: ny is a power of two)
+    for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
+        const int p = e / nx, i = e - p * nx;
+        const size_t g = (row0 + 2 * p) * nx + i;
         // (rho given: the charge density already converted — a rank of a replicated solve has gathered the others' planes)
-        const T v = fixed ? static_cast<T>(static_cast<double>(fixed[(row0 + r) * nx + i]) * scale) : rho[(row0 + r) * nx + i];
-        fesfft::stc<T>(buf, r * ld + i, C2<T>{ v, static_cast<T>(0) });
+        const T a = fixed ? static_cast<T>(static_cast<double>(fixed[g]) * scale) : rho[g];
+        const T b = fixed ? static_cast<T>(static_cast<double>(fixed[g + nx]) * scale) : rho[g + nx];
+        fesfft::stc<T>(buf, p * ld + i, C2<T>{ a, b });
     }
     __syncthreads();
-    fft_tile<T, false>(buf, ld, nrows, tw, nx, logn);
+    fft_tile<T, false>(buf, ld, pairs, tw, nx, logn);
     C2<T>* out = reinterpret_cast<C2<T>*>(hat);
-    for (int e = threadIdx.x; e < nrows * nxh; e += kFftThreads) {
-        const int r = e / nxh, i = e - r * nxh;
-        out[(row0 + r) * nxh + i] = fesfft::ldc<T>(buf, r * ld + i);
+    const T half = static_cast<T>(0.5);
+    for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
+        const int p = e / nxh, k = e - p * nxh;
+        const C2<T> z = fesfft::ldc<T>(buf, p * ld + k), w = fesfft::ldc<T>(buf, p * ld + ((nx - k) & (nx - 1)));
+        out[(row0 + 2 * p) * nxh + k] = C2<T>{ (z.x + w.x) * half, (z.y - w.y) * half };
+        out[(row0 + 2 * p + 1) * nxh + k] = C2<T>{ (z.y + w.y) * half, (w.x - z.x) * half };
     }
 }
 
-// ---- x pass, inverse: rows of nx / 2 + 1 complex values (the half spectrum of a real row) -> rows of nx real values
+// ---- x pass, inverse: rows of nx / 2 + 1 complex values (the half spectra of real rows) -> rows of nx real values; two
+// rows per complex transform again: Z[k] = A[k] + i B[k], Z[N-k] = conj A[k] + i conj B[k]; a = Re z, b = Im z
 template <typename T>
-__global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __restrict__ hat, size_t rows, int nx, int logn, int rows_per_wg, T* __restrict__ phi)
+__global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __restrict__ hat, size_t rows, int nx, int logn, int pairs_per_wg, T* __restrict__ phi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
     const int ld = nx + 1, nxh = nx / 2 + 1;
-    FPIC_LDS C2<T>* tw = buf + rows_per_wg * ld;
+    FPIC_LDS C2<T>* tw = buf + pairs_per_wg * ld;
     fft_twiddles<T>(tw, nx);
-    const size_t row0 = static_cast<size_t>(blockIdx.x) * rows_per_wg;
-    const int nrows = static_cast<int>(rows - row0 < static_cast<size_t>(rows_per_wg) ? rows - row0 : rows_per_wg);
+    const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
+    const int pairs = static_cast<int>((rows - row0 < static_cast<size_t>(2 * pairs_per_wg) ? rows - row0 : 2 * pairs_per_wg) / 2);
     const C2<T>* in = reinterpret_cast<const C2<T>*>(hat);
-    for (int e = threadIdx.x; e < nrows * nxh; e += kFftThreads) {
-        const int r = e / nxh, i = e - r * nxh;
-        const C2<T> v = in[(row0 + r) * nxh + i];
-        fesfft::stc<T>(buf, r * ld + i, v);
-        if (i && i < nx - i) fesfft::stc<T>(buf, r * ld + nx - i, fesfft::cconj(v));   // the mirror half of a real row's spectrum
+    for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
+        const int p = e / nxh, k = e - p * nxh;
+        const C2<T> A = in[(row0 + 2 * p) * nxh + k], B = in[(row0 + 2 * p + 1) * nxh + k];
+        fesfft::stc<T>(buf, p * ld + k, C2<T>{ A.x - B.y, A.y + B.x });
+        if (k && k < nx - k) fesfft::stc<T>(buf, p * ld + nx - k, C2<T>{ A.x + B.y, B.x - A.y });
     }
     __syncthreads();
-    fft_tile<T, true>(buf, ld, nrows, tw, nx, logn);
-    for (int e = threadIdx.x; e < nrows * nx; e += kFftThreads) {
-        const int r = e / nx, i = e - r * nx;
-        phi[(row0 + r) * nx + i] = buf[r * ld + i].x;
+    fft_tile<T, true>(buf, ld, pairs, tw, nx, logn);
+    for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
+        const int p = e / nx, i = e - p * nx;
+        const C2<T> z = fesfft::ldc<T>(buf, p * ld + i);
+        const size_t g = (row0 + 2 * p) * nx + i;
+        phi[g] = z.x;
+        phi[g + nx] = z.y;
     }
 }
 

@@ -101,10 +101,10 @@ struct Push3Args {
     const BlockWork* work;
     const uint32_t* nwork;
     // a rank of a decomposition pushes the tiles along its slab's faces first (part 1), so that the ghost planes can travel
-    // while the interior is pushed (part 2); split[0..1] = the interior's range of the work list (work_split_kernel);
-    // part 0: the whole list
-    const uint32_t* split;
+    // while the interior is pushed (part 2): a work item belongs to the interior when its tile's layer along z
+    // (tile / tiles_per_layer) lies in [layer_lo, layer_hi); part 0: the whole list
     int part;
+    uint32_t tiles_per_layer, layer_lo, layer_hi;
     unsigned long long* spilled;
     uint32_t* tile_count;            // census of the NEW positions per tile, zeroed by the host
     // REBIN launch: the other particle set and its bin table
@@ -436,36 +436,29 @@ struct Neighbourhood3 {
     }
 };
 
-// The work list is in tile order, i.e. by tile layer along z: the interior layers of a slab are one contiguous range
-// [split[0], split[1]) of it.  Item of workgroup b: part 0 -> b; part 2 (interior) -> split[0] + b; part 1 (the layers along
-// the faces and the ghost layers beyond them) -> b below the range, b + its length above.  ~0u: nothing to do.
-__device__ __forceinline__ uint32_t work_item(uint32_t b, int part, const uint32_t* __restrict__ split, uint32_t nwork)
+// does the work item of this tile belong to the part being launched?  (0: every item; 2: the slab's interior tile layers;
+// 1: the layers along the faces and the ghost layers beyond them.)  Decided from the item itself and launch constants:
+// every workgroup of either launch sees the same partition whatever else is in flight.
+__device__ __forceinline__ bool in_part(uint32_t tile, int part, uint32_t tiles_per_layer, uint32_t layer_lo, uint32_t layer_hi)
 {
-    if (part == 0) return b < nwork ? b : ~0u;
-    const uint32_t lo = split[0], hi = split[1];
-    if (part == 2) return lo + b < hi ? lo + b : ~0u;
-    const uint32_t i = b < lo ? b : b + (hi - lo);
-    return i < nwork ? i : ~0u;
+    if (part == 0) return true;
+    const uint32_t layer = tile / tiles_per_layer;
+    const bool interior = layer >= layer_lo && layer < layer_hi;
+    return (part == 2) == interior;
 }
 
-// split[0..1] = the range of work items whose tile layer (tile / tiles_per_layer) lies in [layer_lo, layer_hi); split[2..3] =
-// the range of particle slots those items cover (the migration's pack pass skips it: nobody leaves from the interior)
-static __global__ __launch_bounds__(256) void work_split_kernel(const BlockWork* __restrict__ work, const uint32_t* __restrict__ nwork, uint32_t tiles_per_layer,
-                                                                uint32_t layer_lo, uint32_t layer_hi, uint32_t n_slots, uint32_t* __restrict__ split)
+// The particles of a work item are taken in groups of PPT slots; a group that straddles two items belongs to the earlier
+// one (begin rounds up, end rounds up).  In a two-part launch the group between the LAST interior item and the first item
+// of the layer along the upper face holds particles of that face layer — they may deposit on planes that are exchanged
+// before the interior is pushed — so there, and only there, it goes with the later item: the interior item gives it up,
+// the face item takes it.
+__device__ __forceinline__ void item_groups(const BlockWork* __restrict__ work, uint32_t b, uint32_t nwork, const BlockWork& w, int ppt, int part, uint32_t tiles_per_layer,
+                                            uint32_t layer_lo, uint32_t layer_hi, size_t& g_begin, size_t& g_end)
 {
-    const uint32_t n = *nwork;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (n == 0 || layer_lo >= layer_hi)) { split[0] = split[1] = 0; split[2] = split[3] = 0; }
-    if (n == 0 || layer_lo >= layer_hi) return;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
-        // boundaries between item i - 1 and item i (layer of "item -1" = none below, of "item n" = none above)
-        const uint32_t here = i < n ? work[i].tile / tiles_per_layer : ~0u;
-        const bool has_prev = i > 0;
-        const uint32_t prev = has_prev ? work[i - 1].tile / tiles_per_layer : 0u;
-        const bool first_ge_lo = here >= layer_lo && (!has_prev || prev < layer_lo);
-        const bool first_ge_hi = here >= layer_hi && (!has_prev || prev < layer_hi);
-        if (first_ge_lo) { split[0] = i; split[2] = i < n ? work[i].begin : n_slots; }
-        if (first_ge_hi) { split[1] = i; split[3] = i < n ? work[i].begin : n_slots; }
-    }
+    g_begin = (static_cast<size_t>(w.begin) + ppt - 1) / ppt;
+    g_end = (static_cast<size_t>(w.end) + ppt - 1) / ppt;
+    if (part == 2 && b + 1 < nwork && !in_part(work[b + 1].tile, 2, tiles_per_layer, layer_lo, layer_hi)) g_end = w.end / ppt;
+    if (part == 1 && b > 0 && in_part(work[b - 1].tile, 2, tiles_per_layer, layer_lo, layer_hi)) g_begin = w.begin / ppt;
 }
 
 template <typename T>
@@ -494,9 +487,9 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lrho + kWN);
     FPIC_LDS uint32_t* lrank = lcensus + kNbr3;
     FPIC_LDS uint32_t* lrange = lrank + kNbr3;
-    const uint32_t item = work_item(blockIdx.x, a.part, a.split, *a.nwork);
-    if (item == ~0u) return;
-    const BlockWork w = a.work[item];
+    if (blockIdx.x >= *a.nwork) return;
+    const BlockWork w = a.work[blockIdx.x];
+    if (!in_part(w.tile, a.part, a.tiles_per_layer, a.layer_lo, a.layer_hi)) return;
     const int ti = static_cast<int>(w.tile % a.ntx), tj = static_cast<int>((w.tile / a.ntx) % a.nty), tk = static_cast<int>(w.tile / (a.ntx * a.nty));
     const int ox = ti * kTX - kHalo, oy = tj * kTY - kHalo, oz = tk * kTZ - kHalo;
     const Neighbourhood3 nb{ ti, tj, tk, a.ntx, a.nty, a.ntz };
@@ -523,8 +516,8 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     unsigned my_spill = 0;
     uint32_t census_own = 0;
     const WindowGrid<T, ABL> grid{ GlobalGrid<T>{ a.E4, a.rho, a.nx, a.ny, a.nz }, lE, lrho, ox, oy, oz, &my_spill };
-    const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
-    const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
+    size_t g_begin, g_end;
+    item_groups(a.work, blockIdx.x, *a.nwork, w, PPT, a.part, a.tiles_per_layer, a.layer_lo, a.layer_hi, g_begin, g_end);
 
     if constexpr (REBIN) {
         // Pass A: count the chunk's LOADED positions per destination bin, then reserve one range per bin
@@ -1147,8 +1140,8 @@ struct EmTileArgs {
     int ntx, nty, ntz;
     const BlockWork* work;
     const uint32_t* nwork;
-    const uint32_t* split;   // see Push3Args
-    int part;
+    int part;                // see Push3Args
+    uint32_t tiles_per_layer, layer_lo, layer_hi;
     unsigned long long* spilled;
 };
 
@@ -1296,9 +1289,9 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     FPIC_LDS T* lE = (FPIC_LDS T*)ldsem;
     FPIC_LDS T* lB = lE + 4 * WN;
     FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(lB + 4 * WN);
-    const uint32_t item = work_item(blockIdx.x, t.part, t.split, *t.nwork);
-    if (item == ~0u) return;
-    const BlockWork w = t.work[item];
+    if (blockIdx.x >= *t.nwork) return;
+    const BlockWork w = t.work[blockIdx.x];
+    if (!in_part(w.tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) return;
     const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
     const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
     using V = typename NatVec16<T>::type;
@@ -1321,8 +1314,8 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     __syncthreads();
     unsigned my_spill = 0;
     const T q14 = static_cast<T>(1.0 / 16384.0);
-    const size_t g_begin = (static_cast<size_t>(w.begin) + PPT - 1) / PPT;
-    const size_t g_end = (static_cast<size_t>(w.end) + PPT - 1) / PPT;
+    size_t g_begin, g_end;
+    item_groups(t.work, blockIdx.x, *t.nwork, w, PPT, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi, g_begin, g_end);
     for (size_t g = g_begin + threadIdx.x; g < g_end; g += kEmThreads) {
         const size_t base = g * PPT;
         const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);

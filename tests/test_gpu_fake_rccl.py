@@ -123,14 +123,14 @@ def run_case(tmp_path, **case):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
-@pytest.mark.parametrize("world,shape,ghost,every", [(2, (16, 12, 16), 2, 2), (3, (12, 16, 18), 1, 1), (4, (20, 12, 32), 3, 3)])
+@pytest.mark.parametrize("world,shape,ghost,every", [(2, (16, 12, 16), 2, 2), (3, (12, 16, 18), 1, 1), (4, (20, 12, 32), 3, 3), (2, (20, 24, 64), 3, 4)])
 def test_rccl_transport_electrostatic_replicated_solve(tmp_path, precision, world, shape, ghost, every):
     res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=every, em=False, distributed_solve=False, precision=precision, n=20000, seed=world)
     assert res["ids_ok"] and res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
     assert res["migrated"] > 0 and res["lost"] == 0
 
 
-@pytest.mark.parametrize("world,shape,ghost", [(2, (16, 12, 16), 2), (4, (18, 16, 24), 2)])
+@pytest.mark.parametrize("world,shape,ghost", [(2, (16, 12, 16), 2), (4, (18, 16, 24), 2), (2, (32, 16, 64), 3)])
 def test_rccl_transport_slab_decomposed_solve(tmp_path, world, shape, ghost):
     res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=2, em=False, distributed_solve=True, precision="fp32", n=20000, seed=7)
     # another summation order in the solve: particles agree to rounding, so a few 14-bit weights of the integer charge grid
@@ -140,7 +140,7 @@ def test_rccl_transport_slab_decomposed_solve(tmp_path, world, shape, ghost):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
-@pytest.mark.parametrize("world,shape,ghost,every", [(2, (12, 10, 16), 2, 2), (3, (10, 12, 30), 3, 4)])
+@pytest.mark.parametrize("world,shape,ghost,every", [(2, (12, 10, 16), 2, 2), (3, (10, 12, 30), 3, 4), (2, (12, 16, 64), 3, 4)])
 def test_rccl_transport_full_em(tmp_path, precision, world, shape, ghost, every):
     res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=every, em=True, distributed_solve=False, precision=precision, n=15000, seed=11)
     assert res["ids_ok"] and res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
