@@ -26,6 +26,13 @@ struct C2 {
     T x, y;
 };
 
+// Where point idx of a transform sits in its column: one complex of padding after every eight.  A radix-8 pass stores
+// with a stride of 8 (first pass) or in runs of 8 at a stride of 64 (second pass); on 32 four-byte LDS banks those strides
+// land every lane of a wavefront on two or four banks, with the padding they spread over all of them (the stride of 8
+// becomes 9 complex = 18 words, which visits every even bank once in 16 lanes).  Loads are unit stride either way.
+FESFFT_HD int swz(int idx) { return idx + (idx >> 3); }
+FESFFT_HD int swz_len(int n) { return n + (n >> 3); }   // slots of a column of n points
+
 // load / store through a pointer in any address space (a struct cannot be assigned across address spaces as a whole)
 template <typename T, typename P> FESFFT_HD C2<T> ldc(P p, int i) { return C2<T>{ p[i].x, p[i].y }; }
 template <typename T, typename P> FESFFT_HD void stc(P p, int i, C2<T> v) { p[i].x = v.x; p[i].y = v.y; }
@@ -93,7 +100,7 @@ FESFFT_HD void pass_load(Col col, Tw tw, int N, int Ns, int j, C2<T> (&v)[R], in
     const int tstep = k * (N / (Ns * R));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        v[r] = ldc<T>(col, (j + r * per) * stride);
+        v[r] = ldc<T>(col, swz(j + r * per) * stride);
         if (r && Ns > 1) {
             const C2<T> w = ldc<T>(tw, r * tstep);
             v[r] = cmul(v[r], INV ? cconj(w) : w);
@@ -108,7 +115,7 @@ FESFFT_HD void pass_store(Col col, int Ns, int j, const C2<T> (&v)[R], int strid
     const int k = j & (Ns - 1);
     const int j0 = (j - k) * R + k;
 #pragma unroll
-    for (int r = 0; r < R; ++r) stc<T>(col, (j0 + r * Ns) * stride, v[r]);
+    for (int r = 0; r < R; ++r) stc<T>(col, swz(j0 + r * Ns) * stride, v[r]);
 }
 
 // the radix of the next pass when 2^rem points are still to be factored: 8 while it divides, then 4 or 2
@@ -125,12 +132,13 @@ namespace fes {
 using fesfft::C2;
 
 constexpr int kFftThreads = 512;
-constexpr int kFftMaxLog = 10, kFftMinLog = 3;          // 8 .. 1024 points per axis
+constexpr int kFftMaxLog = 9, kFftMinLog = 3;           // 8 .. 512 points per axis (a padded tile of 1024-point double columns would not fit the LDS; such grids keep rocFFT)
 // columns of a tile: 128 contiguous bytes of a row (16 complex floats, 8 complex doubles)
 template <typename T> constexpr int fft_tile_columns() { return static_cast<int>(128 / sizeof(C2<T>)); }
-// LDS of a tile of `cols` transforms of N points (one complex of padding per column: consecutive columns then start
-// two banks apart, and the transposing loads / stores of a tile are free of bank conflicts) + the twiddle table
-template <typename T> constexpr size_t fft_lds_bytes(int N, int cols) { return (static_cast<size_t>(cols) * (N + 1) + N) * sizeof(C2<T>); }
+// LDS of a tile of `cols` transforms of N points — each column N + N / 8 slots (fesfft::swz) and one more complex of
+// padding, so that consecutive columns start two banks apart and the transposing loads / stores of a tile are free of
+// bank conflicts too — + the twiddle table
+template <typename T> constexpr size_t fft_lds_bytes(int N, int cols) { return (static_cast<size_t>(cols) * (N + (N >> 3) + 1) + N) * sizeof(C2<T>); }
 
 inline bool fft_supported(int n) { return n >= (1 << kFftMinLog) && n <= (1 << kFftMaxLog) && (n & (n - 1)) == 0; }
 inline int fft_log2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
-    const int ld = nx + 1, nxh = nx / 2 + 1;
+    const int ld = fesfft::swz_len(nx) + 1, nxh = nx / 2 + 1;
     FPIC_LDS C2<T>* tw = buf + pairs_per_wg * ld;
     fft_twiddles<T>(tw, nx);
     const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
         // (rho given: the charge density already converted — a rank of a replicated solve has gathered the others' planes)
         const T a = fixed ? static_cast<T>(static_cast<double>(fixed[g]) * scale) : rho[g];
         const T b = fixed ? static_cast<T>(static_cast<double>(fixed[g + nx]) * scale) : rho[g + nx];
-        fesfft::stc<T>(buf, p * ld + i, C2<T>{ a, b });
+        fesfft::stc<T>(buf, p * ld + fesfft::swz(i), C2<T>{ a, b });
     }
     __syncthreads();
     fft_tile<T, false>(buf, ld, pairs, tw, nx, logn);
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
     const T half = static_cast<T>(0.5);
     for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
         const int p = e / nxh, k = e - p * nxh;
-        const C2<T> z = fesfft::ldc<T>(buf, p * ld + k), w = fesfft::ldc<T>(buf, p * ld + ((nx - k) & (nx - 1)));
+        const C2<T> z = fesfft::ldc<T>(buf, p * ld + fesfft::swz(k)), w = fesfft::ldc<T>(buf, p * ld + fesfft::swz((nx - k) & (nx - 1)));
         out[(row0 + 2 * p) * nxh + k] = C2<T>{ (z.x + w.x) * half, (z.y - w.y) * half };
         out[(row0 + 2 * p + 1) * nxh + k] = C2<T>{ (z.y + w.y) * half, (w.x - z.x) * half };
     }
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
-    const int ld = nx + 1, nxh = nx / 2 + 1;
+    const int ld = fesfft::swz_len(nx) + 1, nxh = nx / 2 + 1;
     FPIC_LDS C2<T>* tw = buf + pairs_per_wg * ld;
     fft_twiddles<T>(tw, nx);
     const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
@@ -237,14 +245,14 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
     for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
         const int p = e / nxh, k = e - p * nxh;
         const C2<T> A = in[(row0 + 2 * p) * nxh + k], B = in[(row0 + 2 * p + 1) * nxh + k];
-        fesfft::stc<T>(buf, p * ld + k, C2<T>{ A.x - B.y, A.y + B.x });
-        if (k && k < nx - k) fesfft::stc<T>(buf, p * ld + nx - k, C2<T>{ A.x + B.y, B.x - A.y });
+        fesfft::stc<T>(buf, p * ld + fesfft::swz(k), C2<T>{ A.x - B.y, A.y + B.x });
+        if (k && k < nx - k) fesfft::stc<T>(buf, p * ld + fesfft::swz(nx - k), C2<T>{ A.x + B.y, B.x - A.y });
     }
     __syncthreads();
     fft_tile<T, true>(buf, ld, pairs, tw, nx, logn);
     for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
         const int p = e / nx, i = e - p * nx;
-        const C2<T> z = fesfft::ldc<T>(buf, p * ld + i);
+        const C2<T> z = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i));
         const size_t g = (row0 + 2 * p) * nx + i;
         phi[g] = z.x;
         phi[g + nx] = z.y;
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict_
     constexpr int C = fft_tile_columns<T>();
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
-    const int ld = N + 1;
+    const int ld = fesfft::swz_len(N) + 1;
     FPIC_LDS C2<T>* tw = buf + C * ld;
     fft_twiddles<T>(tw, N);
     const int tiles = (L.nxh + C - 1) / C;
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict_
     C2<T>* base = reinterpret_cast<C2<T>*>(hat) + static_cast<size_t>(o) * L.outer_stride + i0;
     for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
         const int idx = e / C, c = e - idx * C;
-        if (c < cols) fesfft::stc<T>(buf, c * ld + idx, base[static_cast<size_t>(idx) * L.stride + c]);
+        if (c < cols) fesfft::stc<T>(buf, c * ld + fesfft::swz(idx), base[static_cast<size_t>(idx) * L.stride + c]);
     }
     __syncthreads();
     if constexpr (MODE == 1) fft_tile<T, true>(buf, ld, cols, tw, N, logn);
@@ -290,15 +298,15 @@ __global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict_
             const int i = i0 + c;
             const double K2 = (k2x[i] + k2y[j]) + k2z[k];
             const T g = (i | j | k) ? static_cast<T>(inv_eps0_n / K2) : static_cast<T>(0);
-            const C2<T> v = fesfft::ldc<T>(buf, c * ld + k);
-            fesfft::stc<T>(buf, c * ld + k, C2<T>{ v.x * g, v.y * g });
+            const C2<T> v = fesfft::ldc<T>(buf, c * ld + fesfft::swz(k));
+            fesfft::stc<T>(buf, c * ld + fesfft::swz(k), C2<T>{ v.x * g, v.y * g });
         }
         __syncthreads();
         fft_tile<T, true>(buf, ld, cols, tw, N, logn);
     }
     for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
         const int idx = e / C, c = e - idx * C;
-        if (c < cols) base[static_cast<size_t>(idx) * L.stride + c] = fesfft::ldc<T>(buf, c * ld + idx);
+        if (c < cols) base[static_cast<size_t>(idx) * L.stride + c] = fesfft::ldc<T>(buf, c * ld + fesfft::swz(idx));
     }
 }
 

@@ -33,9 +33,9 @@ double check(int logn, unsigned seed)
     const int N = 1 << logn;
     std::mt19937 gen(seed);
     std::uniform_real_distribution<double> u(-1, 1);
-    std::vector<C2<T>> col(N), tw(N);
+    std::vector<C2<T>> col(fesfft::swz_len(N) + 1), tw(N);
     std::vector<long double> xr(N), xi(N);
-    for (int n = 0; n < N; ++n) { col[n] = { static_cast<T>(u(gen)), static_cast<T>(u(gen)) }; xr[n] = col[n].x; xi[n] = col[n].y; }
+    for (int n = 0; n < N; ++n) { const C2<T> v{ static_cast<T>(u(gen)), static_cast<T>(u(gen)) }; col[fesfft::swz(n)] = v; xr[n] = v.x; xi[n] = v.y; }
     const long double pi = 3.14159265358979323846264338327950288L;
     for (int t = 0; t < N; ++t) tw[t] = { static_cast<T>(std::cos(-2 * pi * t / N)), static_cast<T>(std::sin(-2 * pi * t / N)) };
     int Ns = 1;
@@ -56,7 +56,7 @@ double check(int logn, unsigned seed)
             sr += xr[n] * c - xi[n] * s;
             si += xr[n] * s + xi[n] * c;
         }
-        worst = std::fmax(worst, std::fmax(std::fabs(static_cast<double>(sr - col[k].x)), std::fabs(static_cast<double>(si - col[k].y))));
+        worst = std::fmax(worst, std::fmax(std::fabs(static_cast<double>(sr - col[fesfft::swz(k)].x)), std::fabs(static_cast<double>(si - col[fesfft::swz(k)].y))));
         scale = std::fmax(scale, std::fmax(std::fabs(static_cast<double>(sr)), std::fabs(static_cast<double>(si))));
     }
     return worst / scale;
