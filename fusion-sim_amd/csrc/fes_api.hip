@@ -50,6 +50,8 @@ struct Species {
     bool census_fresh = false;  // tile_count holds the census of the current positions (written by the last push)
     bool rebin_pending = false; // tables [wl ^ 1] are laid out from that census: the next push re-bins
     bool rebin_now = false;     // the push in flight is that re-binning (a push in two parts decides once)
+    uint32_t* chunk_census = nullptr;  // 27 words per work item: the new positions of the last in-place launch by neighbour slot
+    bool chunk_census_fresh = false;   // ... of the live work list and slots: the next re-binning launch need not count
 };
 
 struct State {
@@ -148,7 +150,8 @@ int alloc_species(fpic_handle* h, Species& s)
     s.work_cap = (s.cap + kChunk3 - 1) / kChunk3 + st->ntiles;
     uint64_t* acc = &h->bytes_grid;
     int rc;
-    if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
+    if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.chunk_census), sizeof(uint32_t) * kNbr3 * s.work_cap, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * (st->ntiles + fpic::kSortMaxBins + 1), acc))) // + chunk_first of the two-level binning
         return rc;
     for (int k = 0; k < 2; ++k)
@@ -165,6 +168,7 @@ void free_species(Species& s)
         if (s.slab[k]) (void)hipFree(s.slab[k]);
         if (s.id[k]) (void)hipFree(s.id[k]);
     }
+    if (s.chunk_census) (void)hipFree(s.chunk_census);
     for (void* p : { static_cast<void*>(s.tile_count), static_cast<void*>(s.tile_cursor), static_cast<void*>(s.tile_start2[0]),
                      static_cast<void*>(s.tile_start2[1]), static_cast<void*>(s.nwork2[0]), static_cast<void*>(s.nwork2[1]),
                      static_cast<void*>(s.work2[0]), static_cast<void*>(s.work2[1]) })
@@ -196,6 +200,7 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     a.Z = s.Z;
     a.ntx = st->ntx; a.nty = st->nty; a.ntz = st->ntz;
     a.work = s.work2[s.wl]; a.nwork = s.nwork2[s.wl];
+    a.chunk_census = nullptr;
     a.part = 0; a.tiles_per_layer = static_cast<uint32_t>(st->ntx) * st->nty; a.layer_lo = a.layer_hi = 0;
     a.spilled = st->spilled;
     a.tile_count = s.tile_count;
@@ -232,6 +237,11 @@ int launch_push(fpic_handle* h, Species& s, int part = 0)
             const bool rebin = s.rebin_now;
             a.part = part;
             interior_layers(st, a.layer_lo, a.layer_hi);
+            // an undecomposed handle's in-place launch leaves the per-item census the next re-binning launch starts from
+            // (a decomposition's migration changes the slots in between: it counts)
+            const bool chunkwise = !st->dom && part == 0;
+            a.chunk_census = chunkwise && (!rebin || s.chunk_census_fresh) ? s.chunk_census : nullptr;
+            s.chunk_census_fresh = chunkwise && !rebin;
             if (rebin && has_b) push3_tiles_kernel<T, true, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (rebin) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
@@ -256,7 +266,7 @@ int launch_push(fpic_handle* h, Species& s, int part = 0)
         const size_t lanes = (s.n + Vec16<T>::N - 1) / Vec16<T>::N;
         if (has_b && !DEPOSIT_ONLY) push3_flat_kernel<T, true, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
         else push3_flat_kernel<T, false, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
-        if (!DEPOSIT_ONLY) s.census_fresh = false;
+        if (!DEPOSIT_ONLY) s.census_fresh = s.chunk_census_fresh = false;
     }
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
@@ -329,7 +339,7 @@ int launch_bin(fpic_handle* h, Species& s)
     s.wl = nw;
     s.binned = true;
     s.ids_identity = false;
-    s.census_fresh = s.rebin_pending = false; // tile_count now describes this binning, not a push
+    s.census_fresh = s.rebin_pending = s.chunk_census_fresh = false; // tile_count now describes this binning, not a push
     return FPIC_OK;
 }
 
@@ -1086,7 +1096,7 @@ int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* 
         else
             rc = dtype == FPIC_F32 ? upload_pos<double, float>(h, s, static_cast<const float*>(pos_aos), first, n) : upload_pos<double, double>(h, s, static_cast<const double*>(pos_aos), first, n);
         s.binned = false;
-        s.census_fresh = s.rebin_pending = false;
+        s.census_fresh = s.rebin_pending = s.chunk_census_fresh = false;
         if (h->es->solver != FPIC_SOLVER_NONE) h->es->fields_ready = false; // the fields of these positions are not known yet
     }
     if (rc == FPIC_OK && vel_aos && n) {
@@ -1438,7 +1448,7 @@ int load_checkpoint(fpic_handle* h, const char* path)
     if (std::fseek(bf.f, at, SEEK_SET) != 0) return fail(h, FPIC_ERR_STATE, "cannot seek in %s", path);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (Species& s : st->sp) { // the arrays are about to hold the caller's order: bins and census are void
-        s.binned = s.census_fresh = s.rebin_pending = false;
+        s.binned = s.census_fresh = s.rebin_pending = s.chunk_census_fresh = false;
         s.tail_first = s.tail_count = s.n_after = 0;
         s.ids_identity = true; // (ckpt_scatter_kernel writes slot = index)
     }

@@ -106,6 +106,10 @@ struct Push3Args {
     int part;
     uint32_t tiles_per_layer, layer_lo, layer_hi;
     unsigned long long* spilled;
+    // census of the NEW positions per work item and neighbour slot (27 words per item), written by every in-place launch:
+    // the re-binning launch that follows (same work list, same slots) takes its per-bin counts from it instead of
+    // counting the chunk again — one read of x, y, z less (nullptr: count, e.g. after a migration changed the slots)
+    uint32_t* chunk_census;
     uint32_t* tile_count;            // census of the NEW positions per tile, zeroed by the host
     // REBIN launch: the other particle set and its bin table
     const uint32_t* id;
@@ -520,8 +524,12 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     item_groups(a.work, blockIdx.x, *a.nwork, w, PPT, a.part, a.tiles_per_layer, a.layer_lo, a.layer_hi, g_begin, g_end);
 
     if constexpr (REBIN) {
-        // Pass A: count the chunk's LOADED positions per destination bin, then reserve one range per bin
+        // Pass A: the chunk's LOADED positions per destination bin — what the launch before counted as its new positions
+        // (chunk_census), or counted now — then one range per bin is reserved
         uint32_t own_count = 0;
+        if (a.chunk_census) {
+            if (threadIdx.x < kNbr3) lrank[threadIdx.x] = a.chunk_census[static_cast<size_t>(blockIdx.x) * kNbr3 + threadIdx.x];
+        } else
         for (size_t g = g_begin + threadIdx.x; g < g_end; g += THREADS) {
             const size_t base = g * PPT;
             const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
@@ -647,6 +655,9 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
             const uint32_t c = lcensus[threadIdx.x];
             const uint32_t bin = nb.bin_of_slot(threadIdx.x);
             if (c && bin != ~0u) atomicAdd(a.tile_count + bin, c);
+            if constexpr (!REBIN) {
+                if (a.chunk_census) a.chunk_census[static_cast<size_t>(blockIdx.x) * kNbr3 + threadIdx.x] = c;
+            }
         }
     }
     if (my_spill) atomicAdd(a.spilled, static_cast<unsigned long long>(my_spill));
