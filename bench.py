@@ -325,13 +325,16 @@ def em_line(device, n, grid, steps, warmup, precision="fp64"):
     esize = 8 if precision == "fp64" else 4
     push_ms = st["ms_push"] / max(1, st["step_launches"])
     algo = 12.0 * esize * n
+    tr = measured_traffic({"workload": "em", "particles": n, "grid": grid, "dtype": "f64" if esize == 8 else "f32"})
     return {"what": "spec.solver='yee' (EXTENSION, parity unpinned): %d^3 periodic Yee lattice, %.1e electrons, %s"
                     % (grid, n, precision),
             "value": n * sub / el, "unit": "particle-updates/s", "ms_per_substep": 1e3 * el / sub,
             "kernel_ms_per_substep": {"push_gather_current": push_ms, "fdtd_b_e_b": st["ms_solve"] / max(1, st["solve_launches"]),
                                       "rebinning": st["ms_sort"] / sub},
             "roofline": {"bound": "hbm", "kernel": "em_push_tiles_kernel<%s>" % ("double" if esize == 8 else "float"), "achieved": algo / (push_ms * 1e-3) / 1e9 if push_ms else 0.0,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if push_ms else 0.0, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if push_ms else 0.0,
+                         "traffic": tr.get("bytes_per_launch") if tr else None,
+                         "traffic_source": ("%s: %s" % (tr.get("file"), tr.get("source"))) if tr else "no committed PMC pass for this configuration (profiles/r*_traffic.json)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": push_ms},
             "fdtd_algorithmic_bytes": 21 * esize * grid ** 3, "device_bytes": device_bytes}
 
@@ -970,7 +973,7 @@ def main():
         cic.destroy()
         out["extensions"]["dense_sor"] = dense_sor_line(local_rank)
         out["extensions"]["em"] = em_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, "fp64")
-        out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, stream=stream,
+        out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(8, args.steps // 4), 1, stream=stream,
                                             cpu=not args.no_cpu_baseline)
     if not args.no_strong_c4:
         # north_star's scaling target lives on another workload than the parity-pinned headline: BASELINE configs[3]

@@ -1719,10 +1719,17 @@ int migrate(Ranks& rk)
             // a species whose last push left a census of the current positions is not re-binned by separate passes:
             // the census is corrected for leavers and arrivals and the next push re-bins (and compacts) itself
             const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
-            if (s.n)
+            if (s.n) {
+                // a species binned since its last upload is scanned along the slab's faces only: the interior tile layers
+                // (interior_layers: the same rule as the two-part push) cannot hold a leaver
+                uint32_t lo = 0, hi = 0;
+                const bool faces_only = s.binned && interior_layers(st, lo, hi);
+                const uint32_t per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
                 mig_pack_kernel<T><<<blocks_for(s.n, 256 * kMigPer), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
                                                                           static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]),
-                                                                          d.mig_cap, d.counts_dev, riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty);
+                                                                          d.mig_cap, d.counts_dev, riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty,
+                                                                          faces_only ? s.tile_start2[s.wl] : nullptr, lo * per_layer, hi * per_layer);
+            }
             // the message counters counted every leaver; what the messages hold is at most mig_cap records each
             mig_clamp_kernel<<<1, 64, 0, h->stream>>>(d.counts_dev, d.mig_cap);
             HIP_TRY(h, hipGetLastError());
@@ -1981,6 +1988,31 @@ int dom_precalc(Ranks& rk)
     return FPIC_OK;
 }
 
+// density() on the ranks of a decomposed full-EM run (the cycle deposits currents; the reference's frame loop still calls
+// density() every frame, fusionsim.js:174): every rank deposits the charge of the particles it holds on its own planes
+// and its ghost planes, the ghost planes travel to the slabs that own them and are added there (exact: int64).  After it
+// FPIC_F3_RHO_FIXED is complete on every rank's own planes.  Collective: every rank calls it.
+template <typename T>
+int dom_density(Ranks& rk)
+{
+    for (fpic_handle* h : rk.hs) {
+        if (int e = deposit_cycle<T, true>(h)) return e;
+        h->deposit_launches++;
+    }
+    if (rk.hs[0]->es->dom->world < 2) return FPIC_OK;
+    if (int e = exchange<T>(rk, X_GHOST)) return e;
+    for (fpic_handle* h : rk.hs) {
+        State* st = h->es;
+        Domain& d = *st->dom;
+        const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+        ghost_add_kernel<<<blocks_for(d.G * plane), 256, 0, h->stream>>>(st->rho_fixed + (d.z0 + d.nzl - d.G) * plane, d.ghost_recv[0], d.G * plane);
+        ghost_add_kernel<<<blocks_for((d.G + 1) * plane), 256, 0, h->stream>>>(st->rho_fixed + d.z0 * plane, d.ghost_recv[1], (d.G + 1) * plane);
+        HIP_TRY(h, hipGetLastError());
+        st->rho_fresh = false;
+    }
+    return FPIC_OK;
+}
+
 // ---- the full-EM cycle of a decomposition.  Every rank keeps the lattice fields of its slab and of H = G + 2 halo
 // planes on each side current: after the E update and after the second B half step the boundary planes are copied to
 // the neighbours (X_EM_E, X_EM_B); the current of a sub-step is completed on the owned planes by adding what the
@@ -2177,9 +2209,13 @@ int precalc(fpic_handle* h)
 int density(fpic_handle* h)
 {
     if (h->es->solver != FPIC_SOLVER_YEE) return FPIC_OK; // the electrostatic cycle deposits the charge every sub-step
-    if (h->es->dom) return fail(h, FPIC_ERR_STATE, "density() is not available on a rank of a decomposed full-EM run (the cycle deposits currents: read FPIC_F3_J_FIXED)");
+    if (h->es->dom) { // every rank of the decomposition calls it: the ghost planes of the charge grid are exchanged
+        Ranks rk;
+        if (int e = dom_ranks_of(h, rk)) return e;
+        return h->prec == FPIC_F32 ? dom_density<float>(rk) : dom_density<double>(rk);
+    }
     const int rc = h->prec == FPIC_F32 ? deposit_cycle<float, true>(h) : deposit_cycle<double, true>(h);
-    if (rc == FPIC_OK) h->deposit_launches++;
+    if (rc == FPIC_OK) { h->deposit_launches++; h->es->rho_fresh = false; }
     return rc;
 }
 
@@ -2433,7 +2469,7 @@ int group_run(fpic_handle** hs, int n, int what, int ncalls)
         if (h->prec != h0->prec || h->es->nodes != h0->es->nodes || h->device != h0->device || h->es->sp.size() != h0->es->sp.size())
             return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d differs in precision, grid, device or species", r);
         if (h->comm) return fail(h0, FPIC_ERR_INVALID_ARG, ".handles <- member %d has a communicator; a group is the in-process exchange", r);
-        if (what != 0 && !h->es->fields_ready) return fail(h0, FPIC_ERR_STATE, "step() before precalc()");
+        if (what == 1 && !h->es->fields_ready) return fail(h0, FPIC_ERR_STATE, "step() before precalc()");
     }
     GroupStreams streams;
     if (int e = streams.enter(hs, n)) return e;
@@ -2446,6 +2482,7 @@ int group_run(fpic_handle** hs, int n, int what, int ncalls)
     };
     for (int r = 0; r < n; ++r) hs[r]->err.clear();
     if (what == 0) return report(h0->prec == FPIC_F32 ? dom_precalc<float>(rk) : dom_precalc<double>(rk));
+    if (what == 2) return report(h0->es->solver != FPIC_SOLVER_YEE ? FPIC_OK : (h0->prec == FPIC_F32 ? dom_density<float>(rk) : dom_density<double>(rk)));
     for (int k = 0; k < 2 * ncalls; ++k)
         if (int rc = h0->prec == FPIC_F32 ? dom_substep<float>(rk) : dom_substep<double>(rk)) return report(rc);
     return FPIC_OK;

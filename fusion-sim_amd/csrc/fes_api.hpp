@@ -29,7 +29,7 @@ int domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* po
 int domain_get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, uint32_t* ids, uint64_t capacity, uint64_t* n_out, int dtype);
 int domain_stats(fpic_handle* h, uint64_t* migrated, uint64_t* lost);
 bool is_decomposed(const fpic_handle* h);
-int group_run(fpic_handle** hs, int n, int what /* 0 precalc, 1 step */, int ncalls);
+int group_run(fpic_handle** hs, int n, int what /* 0 precalc, 1 step, 2 density */, int ncalls);
 uint64_t particle_count(const fpic_handle* h);
 uint64_t last_spill(const fpic_handle* h); // out-of-window deposits of the sub-step before last (lagged read-back)
 

@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 // arguments BY VALUE, so that the common path keeps no state in memory.
 constexpr int kEL = 3;                 // log2 of the EM tile edge
 constexpr int kET = 1 << kEL;
-constexpr int kEmThreads = 512;
+constexpr int kEmThreads = 768;
 template <typename T>
 struct EmWin {
     // one halo cell: an EM step moves a particle by a small fraction of a cell (c dt < dx / sqrt 3), and at 74.5 KB the
@@ -1471,8 +1471,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, const uint32_t* __restrict__ id, size_t n, int nz, int z0, int nzl,
                                                        int reach, int world, MigRecord<T>* down, MigRecord<T>* up, unsigned cap,
                                                        unsigned* __restrict__ counts /* down, up, lost, overflow */,
-                                                       uint32_t* __restrict__ census = nullptr, int nx = 0, int ny = 0, int ntx = 0, int nty = 0)
+                                                       uint32_t* __restrict__ census = nullptr, int nx = 0, int ny = 0, int ntx = 0, int nty = 0,
+                                                       const uint32_t* __restrict__ tile_start = nullptr, uint32_t t_lo = 0, uint32_t t_hi = 0)
 {
+    // (tile_start given: the slots of the tiles [t_lo, t_hi) — the interior layers of the slab, at least one tile layer
+    // from either face — are skipped: nobody can have left the slab from there since the last binning)
+    const size_t skip_from = tile_start ? tile_start[t_lo] : 0, skip = tile_start ? tile_start[t_hi] - tile_start[t_lo] : 0;
     // (the leavers of a sorted array sit in the tiles along the two faces: counted in LDS first, so that the two
     // message counters see one atomic per workgroup and direction instead of one per particle)
     __shared__ unsigned l_cnt[2], l_base[2], l_lost;
@@ -1483,7 +1487,8 @@ __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, c
     uint32_t flags = 0; // two bits per particle of this lane: 1 = down, 2 = up
 #pragma unroll
     for (int k = 0; k < kMigPer; ++k) {
-        const size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+        size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+        if (s >= skip_from) s += skip;
         if (s >= n) continue;
         if (slab[s] < static_cast<T>(0)) continue;
         int kz, w;
@@ -1510,7 +1515,8 @@ __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, c
     for (int k = 0; k < kMigPer; ++k) {
         const unsigned dir = (flags >> (2 * k)) & 3u;
         if (!dir) continue;
-        const size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+        size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+        if (s >= skip_from) s += skip;
         const unsigned slot = l_base[dir - 1] + atomicAdd(&l_cnt[dir - 1], 1u);
         if (slot >= cap) { atomicAdd(counts + 3, 1u); continue; } // stays (and is reported): no room in the message
         MigRecord<T> r;

@@ -1355,6 +1355,12 @@ int fpic_group_precalc(fpic_handle** handles, int n)
     CHECK_HANDLE(handles[0]);
     return fes::group_run(handles, n, 0, 0);
 }
+int fpic_group_density(fpic_handle** handles, int n)
+{
+    if (!handles || n < 1 || !handles[0]) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".handles <- Non-optional property is undefined!");
+    CHECK_HANDLE(handles[0]);
+    return fes::group_run(handles, n, 2, 0);
+}
 int fpic_group_step(fpic_handle** handles, int n, int ncalls)
 {
     if (!handles || n < 1 || !handles[0]) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".handles <- Non-optional property is undefined!");

@@ -42,7 +42,7 @@ ABI_FUNCTIONS = [
     "fpic_set_field3", "fpic_read_field3", "fpic_set_particles_range",
     "fpic_comm_unique_id", "fpic_comm_init", "fpic_comm_destroy", "fpic_comm_info", "fpic_comm_set_overlap",
     "fpic_domain_init", "fpic_domain_set_particles", "fpic_domain_get_particles", "fpic_domain_stats",
-    "fpic_group_precalc", "fpic_group_step",
+    "fpic_group_precalc", "fpic_group_step", "fpic_group_density",
 ]
 
 
@@ -141,6 +141,7 @@ def load_library(path=None):
     lib.fpic_domain_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.fpic_group_precalc.argtypes = [ctypes.POINTER(vp), ci]
     lib.fpic_group_step.argtypes = [ctypes.POINTER(vp), ci, ci]
+    lib.fpic_group_density.argtypes = [ctypes.POINTER(vp), ci]
     lib.fpic_add_species.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.POINTER(ci)]
     lib.fpic_set_particles_of.argtypes = [vp, ci, vp, vp, ctypes.c_uint64, ci]
     lib.fpic_get_particles_of.argtypes = [vp, ci, vp, vp, ci]
@@ -594,6 +595,10 @@ class BoxGroup:
 
     def step(self, ncalls=1):
         self._check(self._lib.fpic_group_step(self._arr, len(self.sims), int(ncalls)))
+
+    def density(self):
+        """density() of every member of a full-EM group: the charge grid of the current positions, complete on own planes"""
+        self._check(self._lib.fpic_group_density(self._arr, len(self.sims)))
 
 
 def commUniqueId(library=None):

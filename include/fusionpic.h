@@ -339,6 +339,9 @@ int fpic_domain_get_particles(fpic_handle* h, int species, void* pos_aos, void* 
 int fpic_domain_stats(fpic_handle* h, uint64_t* migrated, uint64_t* lost);
 int fpic_group_precalc(fpic_handle** handles, int n);
 int fpic_group_step(fpic_handle** handles, int n, int ncalls);
+/* out.density() (empic.js:1471) of every member of a full-EM group: the charge grid of the current positions, complete on
+ * every member's own planes (ghost planes exchanged and added).  Over a communicator every rank calls fpic_density. */
+int fpic_group_density(fpic_handle** handles, int n);
 
 /* Counter-based RNG mode only: the global sub-step index (starts at 0, +2 per step() call);
  * settable so that a run can be resumed. */

@@ -260,6 +260,13 @@ def test_slab_decomposed_em_reproduces_one_gpu_bit_for_bit(fp, eo, precision, wo
             got = s.readField(fp.F3_J_FIXED).reshape(shape[2], -1)
             assert np.array_equal(got[r * nzl:(r + 1) * nzl], jref[r * nzl:(r + 1) * nzl]), (frame, r)
         compare("frame %d" % frame)
+        # density() of the frame loop (fusionsim.js:174) on a decomposed full-EM run: the charge grid of the current
+        # positions, ghost planes exchanged and added — complete and exact on every rank's own planes
+        one.density(); group.density()
+        rref = one.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+        for r, s in enumerate(ranks):
+            got = s.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)
+            assert np.array_equal(got[r * nzl:(r + 1) * nzl], rref[r * nzl:(r + 1) * nzl]), ("density", frame, r)
     stats = [s.domainStats() for s in ranks]
     assert sum(s["migrated"] for s in stats) > 0 and all(s["lost"] == 0 for s in stats)
     for s in ranks + [one]:
