@@ -82,6 +82,7 @@ struct State {
     // power-of-two grids: the Poisson solve runs on the library's own FFT passes (fes_fft.hpp), which read the integer
     // charge grid directly; rho (T) is then formed only when somebody reads it
     bool own_fft = false, rho_fresh = true;
+    void* fft_tw[3] = {};   // twiddle tables exp(-2 pi i t / n) of the three axes (T pairs)
     std::vector<Species> sp;
     struct Domain* dom = nullptr; // z-slab decomposition over several GPUs (fpic_domain_init)
 };
@@ -383,7 +384,8 @@ int fft_x_forward(fpic_handle* h, const long long* fixed, const T* rho, double s
 {
     State* st = h->es;
     const int ppw = fft_tile_columns<T>(); // pairs of rows per workgroup (two real rows ride on one complex transform)
-    fft_x_forward_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(fixed, rho, scale, rows, st->nx, fft_log2(st->nx), ppw, hat);
+    fft_x_forward_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(fixed, rho, scale, rows, st->nx, fft_log2(st->nx), ppw, hat,
+                                                                                                                 static_cast<const T*>(st->fft_tw[0]));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -393,21 +395,26 @@ int fft_x_inverse(fpic_handle* h, const T* hat, size_t rows, T* phi)
 {
     State* st = h->es;
     const int ppw = fft_tile_columns<T>();
-    fft_x_inverse_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(hat, rows, st->nx, fft_log2(st->nx), ppw, phi);
+    fft_x_inverse_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(hat, rows, st->nx, fft_log2(st->nx), ppw, phi,
+                                                                                                                 static_cast<const T*>(st->fft_tw[0]));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
 
-// columns of N points at `stride` complex elements, `outer` lines of them `outer_stride` apart (x fastest, nxh values)
+// columns of N points at `stride` complex elements, `outer` lines of them `outer_stride` apart (x fastest, nxh values);
+// xbuf + nyl + nzl: the y passes of a slab-decomposed solve store into / load from the all-to-all's buffer (ColLayout)
 template <typename T, int MODE>
-int fft_columns(fpic_handle* h, T* hat, size_t outer_stride, size_t stride, int outer, int N, int y0 = 0)
+int fft_columns(fpic_handle* h, T* hat, size_t outer_stride, size_t stride, int outer, int N, int y0 = 0, T* xbuf = nullptr, int nyl = 0, int nzl = 0)
 {
     State* st = h->es;
-    const int nxh = st->nx / 2 + 1, C = fft_tile_columns<T>();
-    const ColLayout L{ outer_stride, stride, outer, nxh };
+    const T* twt = static_cast<const T*>(st->fft_tw[MODE == 2 ? 2 : 1]); // (the y passes and the z sweep: N is ny resp. nz)
+    const int nxh = st->nx / 2 + 1;
+    const ColLayout L{ outer_stride, stride, outer, nxh, xbuf ? nyl : 0, nzl };
+    // (tiles of 16 complex floats / 8 doubles: 4, 8 and 32 columns were measured and lose, profiles/r03_fft_ablation.txt)
+    constexpr int C = fft_tile_columns<T>();
     const unsigned tiles = static_cast<unsigned>((nxh + C - 1) / C);
     fft_columns_kernel<T, MODE><<<static_cast<unsigned>(outer) * tiles, kFftThreads, fft_lds_bytes<T>(N, C), h->stream>>>(
-        hat, L, N, fft_log2(N), y0, st->k2[0], st->k2[1], st->k2[2], 1.0 / (kEps0 * static_cast<double>(st->nodes)));
+        hat, xbuf, L, N, fft_log2(N), y0, st->k2[0], st->k2[1], st->k2[2], 1.0 / (kEps0 * static_cast<double>(st->nodes)), twt);
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -933,6 +940,14 @@ int create_state(fpic_handle* h)
     {
         const char* force = std::getenv("FPIC_POISSON_FFT");
         st->own_fft = fft_supported(st->nx) && fft_supported(st->ny) && fft_supported(st->nz) && !(force && std::strcmp(force, "rocfft") == 0);
+        if (st->own_fft) {
+            const int dims3[3] = { st->nx, st->ny, st->nz };
+            for (int a = 0; a < 3; ++a) {
+                if ((rc = dev_alloc(h, &st->fft_tw[a], static_cast<size_t>(dims3[a]) * 2 * sizeof(T), acc))) return rc;
+                fft_twiddle_table_kernel<T><<<blocks_for(dims3[a]), 256, 0, h->stream>>>(static_cast<T*>(st->fft_tw[a]), dims3[a]);
+            }
+            HIP_TRY(h, hipGetLastError());
+        }
         const size_t most = fft_lds_bytes<T>(1 << kFftMaxLog, fft_tile_columns<T>());
         if ((e = set_lds(fft_x_forward_kernel<T>, most)) != hipSuccess || (e = set_lds(fft_x_inverse_kernel<T>, most)) != hipSuccess ||
             (e = set_lds(fft_columns_kernel<T, 0>, most)) != hipSuccess || (e = set_lds(fft_columns_kernel<T, 1>, most)) != hipSuccess ||
@@ -1042,7 +1057,7 @@ void release(fpic_handle* h)
         }
         delete d;
     }
-    for (void* p : { st->Ey, st->By, st->B4n, static_cast<void*>(st->Jfix) })
+    for (void* p : { st->Ey, st->By, st->B4n, static_cast<void*>(st->Jfix), st->fft_tw[0], st->fft_tw[1], st->fft_tw[2] })
         if (p) (void)hipFree(p);
     for (void* p : { static_cast<void*>(st->rho_fixed), st->rho, st->hat, st->phi, st->E4, static_cast<void*>(st->k2[0]), static_cast<void*>(st->k2[1]),
                      static_cast<void*>(st->k2[2]), st->work_f, st->work_i, static_cast<void*>(st->spilled) })
@@ -1867,7 +1882,8 @@ int solve_distributed(Ranks& rk)
                 const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
                 const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
                 if (int e2 = fft_x_forward<T>(h, st->rho_fixed + d.z0 * plane, nullptr, scale, static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(d.hatA))) return e2;
-                if (int e2 = fft_columns<T, 0>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny)) return e2;
+                // (the y pass stores straight into the all-to-all's send buffer: no pack sweep)
+                return fft_columns<T, 0>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny, 0, static_cast<T*>(d.xbuf), d.nyl, d.nzl);
             } else if (int e2 = run_fft(h, d.p2f, d.i2f, static_cast<T*>(st->rho) + d.z0 * plane, d.hatA, "rocfft_execute (2-D forward)")) {
                 return e2;
             }
@@ -1905,12 +1921,12 @@ int solve_distributed(Ranks& rk)
             const int nxh = st->nx / 2 + 1;
             const size_t plane = static_cast<size_t>(st->nx) * st->ny;
             const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
-            transpose_unpack_kernel<T><<<blocks_for(total), 256, 0, h->stream>>>(static_cast<const T*>(d.xbuf), nxh, st->ny, d.nzl, d.nyl, static_cast<T*>(d.hatA));
-            HIP_TRY(h, hipGetLastError());
-            if (own) {
-                if (int e2 = fft_columns<T, 1>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny)) return e2;
+            if (own) { // (the y pass loads straight from the all-to-all's receive buffer: no unpack sweep)
+                if (int e2 = fft_columns<T, 1>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny, 0, static_cast<T*>(d.xbuf), d.nyl, d.nzl)) return e2;
                 return fft_x_inverse<T>(h, static_cast<const T*>(d.hatA), static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(st->phi) + d.z0 * plane);
             }
+            transpose_unpack_kernel<T><<<blocks_for(total), 256, 0, h->stream>>>(static_cast<const T*>(d.xbuf), nxh, st->ny, d.nzl, d.nyl, static_cast<T*>(d.hatA));
+            HIP_TRY(h, hipGetLastError());
             return run_fft(h, d.p2i, d.i2i, d.hatA, static_cast<T*>(st->phi) + d.z0 * plane, "rocfft_execute (2-D inverse)");
         })) return e;
     if (int e = exchange<T>(rk, X_PHI)) return e;

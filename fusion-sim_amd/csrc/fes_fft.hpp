@@ -147,15 +147,24 @@ template <typename T> __device__ __forceinline__ void sincospi_(T a, T* s, T* c)
 template <> __device__ __forceinline__ void sincospi_<float>(float a, float* s, float* c) { sincospif(a, s, c); }
 template <> __device__ __forceinline__ void sincospi_<double>(double a, double* s, double* c) { sincospi(a, s, c); }
 
-// tw[t] = exp(-2 pi i t / N), formed in double and rounded once
+// tw[t] = exp(-2 pi i t / N), formed in double and rounded once: a table per axis in global memory, made once per handle
+// (forming it per workgroup cost a quarter of a column pass at 256 points) ...
 template <typename T>
-__device__ __forceinline__ void fft_twiddles(FPIC_LDS C2<T>* tw, int N)
+__global__ __launch_bounds__(256) void fft_twiddle_table_kernel(T* __restrict__ table, int N)
 {
-    for (int t = threadIdx.x; t < N; t += kFftThreads) {
-        double s, c;
-        sincospi(-2.0 * static_cast<double>(t) / static_cast<double>(N), &s, &c);
-        fesfft::stc<T>(tw, t, C2<T>{ static_cast<T>(c), static_cast<T>(s) });
-    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    double s, c;
+    sincospi(-2.0 * static_cast<double>(t) / static_cast<double>(N), &s, &c);
+    table[2 * t] = static_cast<T>(c);
+    table[2 * t + 1] = static_cast<T>(s);
+}
+// ... and copied into LDS by every workgroup
+template <typename T>
+__device__ __forceinline__ void fft_twiddles(FPIC_LDS C2<T>* tw, const T* __restrict__ table, int N)
+{
+    const C2<T>* g = reinterpret_cast<const C2<T>*>(table);
+    for (int t = threadIdx.x; t < N; t += kFftThreads) fesfft::stc<T>(tw, t, g[t]);
 }
 
 // one pass of radix R over `cols` columns of N points in LDS (column c at buf + c * ld), in place: a round of the loop
@@ -200,13 +209,13 @@ __device__ __forceinline__ void fft_tile(FPIC_LDS C2<T>* buf, int ld, int cols, 
 // A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i (exact halvings).  A workgroup takes 2 * pairs_per_wg rows.
 template <typename T>
 __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long long* __restrict__ fixed, const T* __restrict__ rho, double scale, size_t rows, int nx, int logn,
-                                                                    int pairs_per_wg, T* __restrict__ hat)
+                                                                    int pairs_per_wg, T* __restrict__ hat, const T* __restrict__ twt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
     const int ld = fesfft::swz_len(nx) + 1, nxh = nx / 2 + 1;
     FPIC_LDS C2<T>* tw = buf + pairs_per_wg * ld;
-    fft_twiddles<T>(tw, nx);
+    fft_twiddles<T>(tw, twt, nx);
     const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
     const int pairs = static_cast<int>((rows - row0 < static_cast<size_t>(2 * pairs_per_wg) ? rows - row0 : 2 * pairs_per_wg) / 2); // (rows is even: ny is a power of two)
     for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
@@ -232,13 +241,14 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
 // ---- x pass, inverse: rows of nx / 2 + 1 complex values (the half spectra of real rows) -> rows of nx real values; two
 // rows per complex transform again: Z[k] = A[k] + i B[k], Z[N-k] = conj A[k] + i conj B[k]; a = Re z, b = Im z
 template <typename T>
-__global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __restrict__ hat, size_t rows, int nx, int logn, int pairs_per_wg, T* __restrict__ phi)
+__global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __restrict__ hat, size_t rows, int nx, int logn, int pairs_per_wg, T* __restrict__ phi,
+                                                                    const T* __restrict__ twt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
     const int ld = fesfft::swz_len(nx) + 1, nxh = nx / 2 + 1;
     FPIC_LDS C2<T>* tw = buf + pairs_per_wg * ld;
-    fft_twiddles<T>(tw, nx);
+    fft_twiddles<T>(tw, twt, nx);
     const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
     const int pairs = static_cast<int>((rows - row0 < static_cast<size_t>(2 * pairs_per_wg) ? rows - row0 : 2 * pairs_per_wg) / 2);
     const C2<T>* in = reinterpret_cast<const C2<T>*>(hat);
@@ -267,25 +277,40 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
 struct ColLayout {
     size_t outer_stride, stride;   // complex elements
     int outer, nxh;
+    // The y passes of a slab-decomposed solve exchange their lines with the other ranks (an all-to-all transposition): the
+    // forward pass STORES straight into the send buffer [q][nzl][nyl][nxh] — row ky = q nyl + yl of plane o goes to rank q
+    // — and the inverse pass LOADS from the receive buffer of the same shape (nyl = 0: plain layout on both sides).  That
+    // is the pack / unpack sweep of round 2 (26 + 39 us per rank at 512^3 / 8) done by address arithmetic.
+    int nyl, nzl;
 };
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict__ hat, ColLayout L, int N, int logn, int y0, const double* __restrict__ k2x,
-                                                                  const double* __restrict__ k2y, const double* __restrict__ k2z, double inv_eps0_n)
+// element (idx, c) of the tile of line o in the exchange buffer: [q][nzl][nyl][nxh]
+__device__ __forceinline__ size_t exchange_index(const ColLayout& L, int o, int idx, int i)
 {
-    constexpr int C = fft_tile_columns<T>();
+    const int q = idx / L.nyl, yl = idx - q * L.nyl;
+    return ((static_cast<size_t>(q) * L.nzl + o) * L.nyl + yl) * L.nxh + i;
+}
+
+template <typename T, int MODE, int C = fft_tile_columns<T>()>
+__global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict__ hat, T* __restrict__ xbuf, ColLayout L, int N, int logn, int y0,
+                                                                  const double* __restrict__ k2x, const double* __restrict__ k2y, const double* __restrict__ k2z,
+                                                                  double inv_eps0_n, const T* __restrict__ twt)
+{
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
     const int ld = fesfft::swz_len(N) + 1;
     FPIC_LDS C2<T>* tw = buf + C * ld;
-    fft_twiddles<T>(tw, N);
+    fft_twiddles<T>(tw, twt, N);
     const int tiles = (L.nxh + C - 1) / C;
     const int o = static_cast<int>(blockIdx.x / tiles), t = static_cast<int>(blockIdx.x % tiles);
     const int i0 = t * C, cols = L.nxh - i0 < C ? L.nxh - i0 : C;
     C2<T>* base = reinterpret_cast<C2<T>*>(hat) + static_cast<size_t>(o) * L.outer_stride + i0;
+    C2<T>* xb = reinterpret_cast<C2<T>*>(xbuf);
+    const bool load_exchanged = MODE == 1 && L.nyl > 0, store_exchanged = MODE == 0 && L.nyl > 0;
     for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
         const int idx = e / C, c = e - idx * C;
-        if (c < cols) fesfft::stc<T>(buf, c * ld + fesfft::swz(idx), base[static_cast<size_t>(idx) * L.stride + c]);
+        if (c < cols)
+            fesfft::stc<T>(buf, c * ld + fesfft::swz(idx), load_exchanged ? xb[exchange_index(L, o, idx, i0 + c)] : base[static_cast<size_t>(idx) * L.stride + c]);
     }
     __syncthreads();
     if constexpr (MODE == 1) fft_tile<T, true>(buf, ld, cols, tw, N, logn);
@@ -306,7 +331,10 @@ __global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict_
     }
     for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
         const int idx = e / C, c = e - idx * C;
-        if (c < cols) base[static_cast<size_t>(idx) * L.stride + c] = fesfft::ldc<T>(buf, c * ld + fesfft::swz(idx));
+        if (c >= cols) continue;
+        const C2<T> v = fesfft::ldc<T>(buf, c * ld + fesfft::swz(idx));
+        if (store_exchanged) xb[exchange_index(L, o, idx, i0 + c)] = v;
+        else base[static_cast<size_t>(idx) * L.stride + c] = v;
     }
 }
 
