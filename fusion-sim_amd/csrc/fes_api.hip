@@ -52,12 +52,16 @@ struct Species {
     bool rebin_now = false;     // the push in flight is that re-binning (a push in two parts decides once)
     uint32_t* chunk_census = nullptr;  // 27 words per work item: the new positions of the last in-place launch by neighbour slot
     bool chunk_census_fresh = false;   // ... of the live work list and slots: the next re-binning launch need not count
+    void* em_args = nullptr;           // EmPushArgs of the last full-EM launch, resident for the kernel's out-of-line paths
 };
 
 struct State {
     int nx = 0, ny = 0, nz = 0;
     double lx = 0, ly = 0, lz = 0, W = 1;
     size_t nodes = 0;
+    // the planes the node arrays hold (fes_kernels.hpp, Held): all nz of them, or — a rank of a compact decomposition —
+    // the slab with its halo: zs0 = z0 - H, nzs = nzl + 2 H + 1 planes
+    int zs0 = 0, nzs = 0;
     int solver = FPIC_SOLVER_NONE;
     int ltx = 4, lty = 4, ltz = 3; // log2 of the tile edges: 16x16x8 cells (electrostatic), 8x8x8 (full EM)
     int ntx = 0, nty = 0, ntz = 0;
@@ -136,6 +140,28 @@ size_t total_particles(const State* st)
     return n;
 }
 
+Held held_of(const State* st) { return Held{ st->zs0, st->nzs }; }
+bool compact(const State* st) { return st->nzs != st->nz; }
+// place of global plane k (any integer: periodic) in the node arrays; the caller names held planes only
+size_t lp(const State* st, int k)
+{
+    const int l = (((k - st->zs0) % st->nz) + st->nz) % st->nz;
+    return static_cast<size_t>(l);
+}
+size_t held_nodes(const State* st) { return static_cast<size_t>(st->nx) * st->ny * st->nzs; }
+// zero `count` planes from global plane `first` on (periodic) of a node array with `per_plane` bytes per plane: one run
+// of the array, or two where the planes wrap past its end
+int zero_planes(fpic_handle* h, void* base, size_t per_plane, int first, int count)
+{
+    const State* st = h->es;
+    count = std::min(count, st->nzs);
+    const size_t l0 = lp(st, first);
+    const size_t head = std::min<size_t>(count, static_cast<size_t>(st->nzs) - l0);
+    HIP_TRY(h, hipMemsetAsync(static_cast<char*>(base) + l0 * per_plane, 0, head * per_plane, h->stream));
+    if (static_cast<size_t>(count) > head) HIP_TRY(h, hipMemsetAsync(base, 0, (count - head) * per_plane, h->stream));
+    return FPIC_OK;
+}
+
 template <typename T>
 int alloc_species(fpic_handle* h, Species& s)
 {
@@ -170,6 +196,7 @@ void free_species(Species& s)
         if (s.id[k]) (void)hipFree(s.id[k]);
     }
     if (s.chunk_census) (void)hipFree(s.chunk_census);
+    if (s.em_args) (void)hipFree(s.em_args);
     for (void* p : { static_cast<void*>(s.tile_count), static_cast<void*>(s.tile_cursor), static_cast<void*>(s.tile_start2[0]),
                      static_cast<void*>(s.tile_start2[1]), static_cast<void*>(s.nwork2[0]), static_cast<void*>(s.nwork2[1]),
                      static_cast<void*>(s.work2[0]), static_cast<void*>(s.work2[1]) })
@@ -189,6 +216,7 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     a.E4 = static_cast<const T*>(st->E4);
     a.rho = reinterpret_cast<unsigned long long*>(st->rho_fixed);
     a.nx = st->nx; a.ny = st->ny; a.nz = st->nz;
+    a.held = held_of(st);
     // derived in double, rounded once into T (es3d_oracle.py push_params)
     const double hh = s.charge * h->spec.dt / (2 * s.mass); // empic.js:44
     const double t[3] = { hh * st->B0[0], hh * st->B0[1], hh * st->B0[2] };
@@ -428,7 +456,7 @@ int refresh_rho(fpic_handle* h)
     const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
     const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
     size_t first = 0, count = st->nodes;
-    if (const Domain* d = st->dom; d && d->world > 1) { first = static_cast<size_t>(d->z0) * st->nx * st->ny; count = static_cast<size_t>(d->nzl) * st->nx * st->ny; }
+    if (const Domain* d = st->dom; d && d->world > 1) { first = lp(st, d->z0) * st->nx * st->ny; count = static_cast<size_t>(d->nzl) * st->nx * st->ny; }
     rho_real_kernel<T><<<blocks_for(count), 256, 0, h->stream>>>(st->rho_fixed + first, count, scale, static_cast<T*>(st->rho) + first);
     HIP_TRY(h, hipGetLastError());
     st->rho_fresh = true;
@@ -440,6 +468,7 @@ template <typename T>
 int launch_solve(fpic_handle* h, bool convert = true)
 {
     State* st = h->es;
+    if (compact(st)) return fail(h, FPIC_ERR_STATE, "a rank with slab-only arrays solves with its group (the decomposed solve), not alone");
     timing_begin(h, KC_SOLVE);
     const double dv_ = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
     const double scale_ = h->spec.particle_charge * st->W / (4398046511104.0 * dv_); // q0 W / (2^42 dV)
@@ -460,7 +489,7 @@ int launch_solve(fpic_handle* h, bool convert = true)
         if (st->solver == FPIC_SOLVER_YEE) {
             em_edge_gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
                                                                                    static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
-                                                                                   static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey));
+                                                                                   static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey), 0, st->nz, held_of(st));
             HIP_TRY(h, hipGetLastError());
         } else {
             gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(
@@ -497,7 +526,7 @@ int launch_solve(fpic_handle* h, bool convert = true)
         if (st->solver == FPIC_SOLVER_YEE) // the field on the lattice's edges: Gauss's law holds exactly there
             em_edge_gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
                                                                                    static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
-                                                                                   static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey));
+                                                                                   static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey), 0, st->nz, held_of(st));
         else
             gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(
                 static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
@@ -548,11 +577,7 @@ int deposit_cycle(fpic_handle* h, int part = 0)
             // outrun them adds elsewhere is never read): planes [z0 - G, z0 + nzl + G], periodic
             const Domain& d = *st->dom;
             const size_t plane = static_cast<size_t>(st->nx) * st->ny; // nodes
-            const int span = std::min(st->nz, d.nzl + 2 * d.G + 1);
-            const int lo = ((d.z0 - d.G) % st->nz + st->nz) % st->nz;
-            const int head = std::min(span, st->nz - lo);
-            HIP_TRY(h, hipMemsetAsync(st->rho_fixed + lo * plane, 0, head * plane * sizeof(long long), h->stream));
-            if (span > head) HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, (span - head) * plane * sizeof(long long), h->stream));
+            if (int rc = zero_planes(h, st->rho_fixed, plane * sizeof(long long), d.z0 - d.G, d.nzl + 2 * d.G + 1)) return rc;
         } else {
             HIP_TRY(h, hipMemsetAsync(st->rho_fixed, 0, st->nodes * sizeof(long long), h->stream));
         }
@@ -609,7 +634,8 @@ int em_nodes(fpic_handle* h, int k0 = 0, int nk = -1)
     if (nk < 0 || nk > st->nz) nk = st->nz;
     k0 = (k0 % st->nz + st->nz) % st->nz;
     em_nodes_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<const T*>(st->Ey), static_cast<const T*>(st->By), st->nx,
-                                                                                                  st->ny, st->nz, static_cast<T*>(st->E4), static_cast<T*>(st->B4n), k0, nk);
+                                                                                                  st->ny, st->nz, static_cast<T*>(st->E4), static_cast<T*>(st->B4n), k0, nk,
+                                                                                                  held_of(st));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -630,6 +656,7 @@ int em_push_all(fpic_handle* h, int part = 0)
         a.E4n = static_cast<const T*>(st->E4); a.B4n = static_cast<const T*>(st->B4n);
         a.Jfix = reinterpret_cast<unsigned long long*>(st->Jfix);
         a.nx = st->nx; a.ny = st->ny; a.nz = st->nz;
+        a.held = held_of(st);
         const double hh = s.charge * dt / (2 * s.mass), step = dt * kSpeedOfLight;
         a.h = static_cast<T>(hh);
         a.hc = static_cast<T>(hh) / static_cast<T>(kSpeedOfLight); // in T, as the oracle forms it
@@ -643,6 +670,12 @@ int em_push_all(fpic_handle* h, int part = 0)
             t.part = part; t.tiles_per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
             interior_layers(st, t.layer_lo, t.layer_hi);
             t.spilled = st->spilled;
+            if (part != 2) { // (the second part of a split push follows the first on this stream with the same grid)
+                if (!s.em_args)
+                    if (int rc = dev_alloc(h, &s.em_args, sizeof(EmPushArgs<double>), &h->bytes_grid)) return rc;
+                store_args_kernel<EmPushArgs<T>><<<1, 1, 0, h->stream>>>(a, static_cast<EmPushArgs<T>*>(s.em_args));
+            }
+            t.resident = static_cast<const EmPushArgs<T>*>(s.em_args);
             em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmThreads, em_lds_bytes<T>(), h->stream>>>(t);
         } else if (part != 2) { // (an unbinned species is pushed whole with the first part)
             em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
@@ -676,7 +709,7 @@ int em_half_b(fpic_handle* h, const EmCoef<T>& c, int k0, int nk)
     State* st = h->es;
     k0 = (k0 % st->nz + st->nz) % st->nz;
     em_update_b_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->By), static_cast<const T*>(st->Ey), st->nx, st->ny,
-                                                                                                     st->nz, c.cb[0], c.cb[1], c.cb[2], k0, nk);
+                                                                                                     st->nz, c.cb[0], c.cb[1], c.cb[2], k0, nk, held_of(st));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -688,7 +721,7 @@ int em_full_e(fpic_handle* h, const EmCoef<T>& c, int k0, int nk)
     k0 = (k0 % st->nz + st->nz) % st->nz;
     em_update_e_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(st->By), st->Jfix, st->nx,
                                                                                                      st->ny, st->nz, c.ce[0], c.ce[1], c.ce[2], c.je, c.js[0], c.js[1],
-                                                                                                     c.js[2], k0, nk);
+                                                                                                     c.js[2], k0, nk, held_of(st));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -700,8 +733,8 @@ int em_precalc(fpic_handle* h)
     if (int rc = deposit_cycle<T, true>(h)) return rc;
     h->deposit_launches++;
     if (int rc = launch_solve<T>(h)) return rc; // rho -> phi -> E on the edges
-    fill4_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), st->nodes, static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
-                                                                static_cast<T>(st->B0[2]));
+    fill4_kernel<T><<<blocks_for(held_nodes(st)), 256, 0, h->stream>>>(static_cast<T*>(st->By), held_nodes(st), static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
+                                                                     static_cast<T>(st->B0[2]));
     HIP_TRY(h, hipGetLastError());
     return em_nodes<T>(h);
 }
@@ -855,7 +888,7 @@ int upload_field(fpic_handle* h, const In* host, void* target)
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), bytes));
     hipError_t e = hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
-        pack_field3_kernel<T, In><<<blocks_for(st->nodes), 256, 0, h->stream>>>(stage, st->nx, st->ny, st->nz, static_cast<T*>(target));
+        pack_field3_kernel<T, In><<<blocks_for(st->nodes), 256, 0, h->stream>>>(stage, st->nx, st->ny, st->nz, static_cast<T*>(target), held_of(st));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1018,6 +1051,7 @@ int create(fpic_handle* h)
     st->solver = sp.solver;
     st->fields_ready = sp.solver == FPIC_SOLVER_NONE; // static fields (zero until fpic_set_field3) need no precalc()
     st->nodes = static_cast<size_t>(st->nx) * st->ny * st->nz;
+    st->zs0 = 0; st->nzs = st->nz; // (a rank of a decomposition may keep its slab and halo only: domain_init)
     if (st->nodes >= (1ull << 31)) return fail(h, FPIC_ERR_INVALID_ARG, ".nr <- at most 2^31 nodes per device");
     if (sp.solver == FPIC_SOLVER_YEE) st->ltx = st->lty = st->ltz = kEL;
     st->ntx = (st->nx + (1 << st->ltx) - 1) >> st->ltx;
@@ -1295,8 +1329,8 @@ std::vector<std::pair<char*, size_t>> rank_fields(const fpic_handle* h)
     const size_t t = h->prec == FPIC_F32 ? 4 : 8, plane = static_cast<size_t>(st->nx) * st->ny;
     std::vector<std::pair<char*, size_t>> out;
     if (st->solver == FPIC_SOLVER_YEE) {
-        out.push_back({ static_cast<char*>(st->Ey) + 4 * t * plane * d.z0, 4 * t * plane * d.nzl });
-        out.push_back({ static_cast<char*>(st->By) + 4 * t * plane * d.z0, 4 * t * plane * d.nzl });
+        out.push_back({ static_cast<char*>(st->Ey) + 4 * t * plane * lp(st, d.z0), 4 * t * plane * d.nzl });
+        out.push_back({ static_cast<char*>(st->By) + 4 * t * plane * lp(st, d.z0), 4 * t * plane * d.nzl });
     } else if (st->solver == FPIC_SOLVER_NONE) {
         out.push_back({ static_cast<char*>(st->E4), 4 * t * st->nodes });
     }
@@ -1505,6 +1539,17 @@ int set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int 
     return rc;
 }
 
+// host side of a read-back from a rank with slab-only arrays: plane l of the held array is plane zs0 + l of the grid
+template <typename V>
+void spread_held(const State* st, const V* held, size_t per, V* out)
+{
+    std::memset(out, 0, per * st->nz * sizeof(V));
+    for (int l = 0; l < st->nzs; ++l) {
+        const int g = ((st->zs0 + l) % st->nz + st->nz) % st->nz;
+        std::memcpy(out + g * per, held + static_cast<size_t>(l) * per, per * sizeof(V));
+    }
+}
+
 int read_field3(fpic_handle* h, int which, void* out, int dtype)
 {
     State* st = h->es;
@@ -1512,7 +1557,15 @@ int read_field3(fpic_handle* h, int which, void* out, int dtype)
     if (which == FPIC_F3_RHO_FIXED || which == FPIC_F3_J_FIXED) {
         if (which == FPIC_F3_J_FIXED && !st->Jfix) return fail(h, FPIC_ERR_STATE, ".which <- the current grid exists in the full-EM mode only (spec.solver = 2)");
         const void* src = which == FPIC_F3_RHO_FIXED ? static_cast<const void*>(st->rho_fixed) : static_cast<const void*>(st->Jfix);
-        HIP_TRY(h, hipMemcpyAsync(out, src, st->nodes * (which == FPIC_F3_RHO_FIXED ? 1 : 3) * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+        const size_t per = static_cast<size_t>(st->nx) * st->ny * (which == FPIC_F3_RHO_FIXED ? 1 : 3);
+        if (compact(st)) {
+            std::vector<long long> held(per * st->nzs);
+            HIP_TRY(h, hipMemcpyAsync(held.data(), src, held.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            spread_held(st, held.data(), per, static_cast<long long*>(out));
+            return FPIC_OK;
+        }
+        HIP_TRY(h, hipMemcpyAsync(out, src, per * st->nz * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return FPIC_OK;
     }
@@ -1531,6 +1584,20 @@ int read_field3(fpic_handle* h, int which, void* out, int dtype)
     default: return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown grid %d", which);
     }
     if (!dev) return fail(h, FPIC_ERR_STATE, ".which <- this grid exists in the full-EM mode only (spec.solver = 2)");
+    if (compact(st)) { // the planes this rank holds, in their places of a whole grid whose other planes read zero
+        const size_t per = count / st->nz, held = per * st->nzs;
+        int rc;
+        if (dtype == FPIC_F32) {
+            std::vector<float> tmp(held);
+            rc = h->prec == FPIC_F32 ? download_grid<float, float>(h, dev, held, tmp.data()) : download_grid<double, float>(h, dev, held, tmp.data());
+            if (rc == FPIC_OK) spread_held(st, tmp.data(), per, static_cast<float*>(out));
+        } else {
+            std::vector<double> tmp(held);
+            rc = h->prec == FPIC_F32 ? download_grid<float, double>(h, dev, held, tmp.data()) : download_grid<double, double>(h, dev, held, tmp.data());
+            if (rc == FPIC_OK) spread_held(st, tmp.data(), per, static_cast<double*>(out));
+        }
+        return rc;
+    }
     if (h->prec == FPIC_F32)
         return dtype == FPIC_F32 ? download_grid<float, float>(h, dev, count, static_cast<float*>(out)) : download_grid<float, double>(h, dev, count, static_cast<double*>(out));
     return dtype == FPIC_F32 ? download_grid<double, float>(h, dev, count, static_cast<float*>(out)) : download_grid<double, double>(h, dev, count, static_cast<double*>(out));
@@ -1563,8 +1630,8 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
     out.clear();
     if (which == X_GHOST) {
         const int lo = (d.z0 - d.G + st->nz) % st->nz, hi = (d.z0 + d.nzl) % st->nz;
-        out.push_back({ down, up, st->rho_fixed + lo * plane, d.G * plane * 8, d.ghost_recv[0], d.G * plane * 8, 0 });
-        out.push_back({ up, down, st->rho_fixed + hi * plane, (d.G + 1) * plane * 8, d.ghost_recv[1], (d.G + 1) * plane * 8, 1 });
+        out.push_back({ down, up, st->rho_fixed + lp(st, lo) * plane, d.G * plane * 8, d.ghost_recv[0], d.G * plane * 8, 0 });
+        out.push_back({ up, down, st->rho_fixed + lp(st, hi) * plane, (d.G + 1) * plane * 8, d.ghost_recv[1], (d.G + 1) * plane * 8, 1 });
     } else if (which == X_MIG_COUNTS) {
         out.push_back({ down, up, d.counts_dev + 0, 4, d.counts_dev + 4, 4, 0 });
         out.push_back({ up, down, d.counts_dev + 1, 4, d.counts_dev + 5, 4, 1 });
@@ -1582,21 +1649,21 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
         // the current a rank's particles left on its H ghost planes below / above goes to the slab that owns them
         const int lo = (d.z0 - d.H + st->nz) % st->nz, hi = (d.z0 + d.nzl) % st->nz;
         const size_t bytes = static_cast<size_t>(d.H) * plane * 3 * sizeof(long long);
-        out.push_back({ down, up, st->Jfix + 3 * lo * plane, bytes, d.j_recv[0], bytes, 0 });
-        out.push_back({ up, down, st->Jfix + 3 * hi * plane, bytes, d.j_recv[1], bytes, 1 });
+        out.push_back({ down, up, st->Jfix + 3 * lp(st, lo) * plane, bytes, d.j_recv[0], bytes, 0 });
+        out.push_back({ up, down, st->Jfix + 3 * lp(st, hi) * plane, bytes, d.j_recv[1], bytes, 1 });
     } else if (which == X_EM_E || which == X_EM_B) {
         // halo copy of a lattice field: my first H planes are the lower neighbour's upper halo, my last H planes the
         // upper neighbour's lower halo; what arrives lands in my halo planes in place
         T* f = static_cast<T*>(which == X_EM_E ? st->Ey : st->By);
         const size_t bytes = static_cast<size_t>(d.H) * plane * 4 * sizeof(T);
         const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.H + st->nz) % st->nz;
-        out.push_back({ down, up, f + 4 * d.z0 * plane, bytes, f + 4 * above * plane, bytes, 0 });
-        out.push_back({ up, down, f + 4 * (d.z0 + d.nzl - d.H) * plane, bytes, f + 4 * below * plane, bytes, 1 });
+        out.push_back({ down, up, f + 4 * lp(st, d.z0) * plane, bytes, f + 4 * lp(st, above) * plane, bytes, 0 });
+        out.push_back({ up, down, f + 4 * lp(st, d.z0 + d.nzl - d.H) * plane, bytes, f + 4 * lp(st, below) * plane, bytes, 1 });
     } else { // X_PHI: the potential on the planes the gradient of my slab and its ghost planes needs
         T* phi = static_cast<T*>(st->phi);
         const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.G - 1 + st->nz) % st->nz;
-        out.push_back({ down, up, phi + d.z0 * plane, (d.G + 2) * plane * sizeof(T), phi + above * plane, (d.G + 2) * plane * sizeof(T), 0 });
-        out.push_back({ up, down, phi + (d.z0 + d.nzl - d.G - 1) * plane, (d.G + 1) * plane * sizeof(T), phi + below * plane, (d.G + 1) * plane * sizeof(T), 1 });
+        out.push_back({ down, up, phi + lp(st, d.z0) * plane, (d.G + 2) * plane * sizeof(T), phi + lp(st, above) * plane, (d.G + 2) * plane * sizeof(T), 0 });
+        out.push_back({ up, down, phi + lp(st, d.z0 + d.nzl - d.G - 1) * plane, (d.G + 1) * plane * sizeof(T), phi + lp(st, below) * plane, (d.G + 1) * plane * sizeof(T), 1 });
     }
 }
 
@@ -1881,10 +1948,10 @@ int solve_distributed(Ranks& rk)
             if (own) { // x pass straight from the integer grid of the own planes, then the y pass
                 const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
                 const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
-                if (int e2 = fft_x_forward<T>(h, st->rho_fixed + d.z0 * plane, nullptr, scale, static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(d.hatA))) return e2;
+                if (int e2 = fft_x_forward<T>(h, st->rho_fixed + lp(st, d.z0) * plane, nullptr, scale, static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(d.hatA))) return e2;
                 // (the y pass stores straight into the all-to-all's send buffer: no pack sweep)
                 return fft_columns<T, 0>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny, 0, static_cast<T*>(d.xbuf), d.nyl, d.nzl);
-            } else if (int e2 = run_fft(h, d.p2f, d.i2f, static_cast<T*>(st->rho) + d.z0 * plane, d.hatA, "rocfft_execute (2-D forward)")) {
+            } else if (int e2 = run_fft(h, d.p2f, d.i2f, static_cast<T*>(st->rho) + lp(st, d.z0) * plane, d.hatA, "rocfft_execute (2-D forward)")) {
                 return e2;
             }
             const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
@@ -1923,11 +1990,11 @@ int solve_distributed(Ranks& rk)
             const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
             if (own) { // (the y pass loads straight from the all-to-all's receive buffer: no unpack sweep)
                 if (int e2 = fft_columns<T, 1>(h, static_cast<T*>(d.hatA), static_cast<size_t>(st->ny) * nxh, nxh, d.nzl, st->ny, 0, static_cast<T*>(d.xbuf), d.nyl, d.nzl)) return e2;
-                return fft_x_inverse<T>(h, static_cast<const T*>(d.hatA), static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(st->phi) + d.z0 * plane);
+                return fft_x_inverse<T>(h, static_cast<const T*>(d.hatA), static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(st->phi) + lp(st, d.z0) * plane);
             }
             transpose_unpack_kernel<T><<<blocks_for(total), 256, 0, h->stream>>>(static_cast<const T*>(d.xbuf), nxh, st->ny, d.nzl, d.nyl, static_cast<T*>(d.hatA));
             HIP_TRY(h, hipGetLastError());
-            return run_fft(h, d.p2i, d.i2i, d.hatA, static_cast<T*>(st->phi) + d.z0 * plane, "rocfft_execute (2-D inverse)");
+            return run_fft(h, d.p2i, d.i2i, d.hatA, static_cast<T*>(st->phi) + lp(st, d.z0) * plane, "rocfft_execute (2-D inverse)");
         })) return e;
     if (int e = exchange<T>(rk, X_PHI)) return e;
     return each([&](fpic_handle* h) -> int {
@@ -1937,7 +2004,7 @@ int solve_distributed(Ranks& rk)
         const int count = d.nzl + 2 * d.G + 1;
         gradient_planes_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
             static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, d.z0 - d.G, count, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
-            static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4));
+            static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4), held_of(st));
         HIP_TRY(h, hipGetLastError());
         timing_end(h);
         h->solve_launches++;
@@ -1958,8 +2025,8 @@ int dom_fields(Ranks& rk, bool ghost_exchanged)
         timing_begin(h, KC_SOLVE);
         if (multi) {
             // from above: the upper neighbour's lower ghost planes = my top G planes; from below: its G + 1 upper ghost planes = my first ones
-            ghost_add_kernel<<<blocks_for(d.G * plane), 256, 0, h->stream>>>(st->rho_fixed + (d.z0 + d.nzl - d.G) * plane, d.ghost_recv[0], d.G * plane);
-            ghost_add_kernel<<<blocks_for((d.G + 1) * plane), 256, 0, h->stream>>>(st->rho_fixed + d.z0 * plane, d.ghost_recv[1], (d.G + 1) * plane);
+            ghost_add_kernel<<<blocks_for(d.G * plane), 256, 0, h->stream>>>(st->rho_fixed + lp(st, d.z0 + d.nzl - d.G) * plane, d.ghost_recv[0], d.G * plane);
+            ghost_add_kernel<<<blocks_for((d.G + 1) * plane), 256, 0, h->stream>>>(st->rho_fixed + lp(st, d.z0) * plane, d.ghost_recv[1], (d.G + 1) * plane);
         }
         // the own planes as T: what the replicated solve gathers and what rocFFT's 2-D transforms read; the library's own
         // x pass reads the integer grid itself
@@ -1967,7 +2034,7 @@ int dom_fields(Ranks& rk, bool ghost_exchanged)
         if (needs_rho) {
             const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz);
             const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
-            const size_t own = d.nzl * plane, off = d.z0 * plane;
+            const size_t own = d.nzl * plane, off = lp(st, d.z0) * plane;
             rho_real_kernel<T><<<blocks_for(own), 256, 0, h->stream>>>(st->rho_fixed + off, own, scale, static_cast<T*>(st->rho) + off);
             st->rho_fresh = true;
         } else if (multi) {
@@ -2021,8 +2088,8 @@ int dom_density(Ranks& rk)
         State* st = h->es;
         Domain& d = *st->dom;
         const size_t plane = static_cast<size_t>(st->nx) * st->ny;
-        ghost_add_kernel<<<blocks_for(d.G * plane), 256, 0, h->stream>>>(st->rho_fixed + (d.z0 + d.nzl - d.G) * plane, d.ghost_recv[0], d.G * plane);
-        ghost_add_kernel<<<blocks_for((d.G + 1) * plane), 256, 0, h->stream>>>(st->rho_fixed + d.z0 * plane, d.ghost_recv[1], (d.G + 1) * plane);
+        ghost_add_kernel<<<blocks_for(d.G * plane), 256, 0, h->stream>>>(st->rho_fixed + lp(st, d.z0 + d.nzl - d.G) * plane, d.ghost_recv[0], d.G * plane);
+        ghost_add_kernel<<<blocks_for((d.G + 1) * plane), 256, 0, h->stream>>>(st->rho_fixed + lp(st, d.z0) * plane, d.ghost_recv[1], (d.G + 1) * plane);
         HIP_TRY(h, hipGetLastError());
         st->rho_fresh = false;
     }
@@ -2039,8 +2106,8 @@ int dom_em_after_precalc(Ranks& rk)
 {
     for (fpic_handle* h : rk.hs) {
         State* st = h->es;
-        fill4_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<T*>(st->By), st->nodes, static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
-                                                                    static_cast<T>(st->B0[2]));
+        fill4_kernel<T><<<blocks_for(held_nodes(st)), 256, 0, h->stream>>>(static_cast<T*>(st->By), held_nodes(st), static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
+                                                                         static_cast<T>(st->B0[2]));
         HIP_TRY(h, hipGetLastError());
         if (int e = em_nodes<T>(h)) return e; // (every rank has solved the whole grid: its E is valid everywhere)
     }
@@ -2078,9 +2145,7 @@ int dom_em_substep(Ranks& rk)
         if (int e = multi ? em_nodes<T>(h, d.z0 - d.G - 1, std::min(st->nz, d.nzl + 2 * d.G + 3)) : em_nodes<T>(h)) return e;
         timing_begin(h, KC_PUSH);
         if (multi) { // the planes the slab's particles can deposit on
-            const int span = std::min(st->nz, d.nzl + 2 * d.H), lo = ((d.z0 - d.H) % st->nz + st->nz) % st->nz, head = std::min(span, st->nz - lo);
-            HIP_TRY(h, hipMemsetAsync(st->Jfix + 3 * lo * plane, 0, 3 * head * plane * sizeof(long long), h->stream));
-            if (span > head) HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, 3 * (span - head) * plane * sizeof(long long), h->stream));
+            if (int e = zero_planes(h, st->Jfix, 3 * plane * sizeof(long long), d.z0 - d.H, d.nzl + 2 * d.H)) return e;
         } else {
             HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, st->nodes * 3 * sizeof(long long), h->stream));
         }
@@ -2106,8 +2171,8 @@ int dom_em_substep(Ranks& rk)
         const EmCoef<T> co(h);
         if (multi) {
             // from above: the upper neighbour's lower ghost planes = my last H planes; from below: my first H planes
-            ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * (d.z0 + d.nzl - d.H) * plane, d.j_recv[0], count);
-            ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * d.z0 * plane, d.j_recv[1], count);
+            ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * lp(st, d.z0 + d.nzl - d.H) * plane, d.j_recv[0], count);
+            ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * lp(st, d.z0) * plane, d.j_recv[1], count);
             HIP_TRY(h, hipGetLastError());
             // B half a step on the slab and on the plane below it (the E update of the first owned plane reads it)
             if (int e = em_half_b<T>(h, co, d.z0 - 1, d.nzl + 1)) return e;
@@ -2262,11 +2327,46 @@ int device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes)
 {
     if (which != FPIC_BUF_RHO_FIXED) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown buffer %d", which);
     if (dptr) *dptr = h->es->rho_fixed;
-    if (bytes) *bytes = h->es->nodes * sizeof(long long);
+    if (bytes) *bytes = held_nodes(h->es) * sizeof(long long); // (a rank with slab-only arrays: its nzs planes from zs0 on)
     return FPIC_OK;
 }
 
 // ---- decomposition entry points (fpic_domain_*, fpic_group_*)
+
+// A rank whose cycle never touches a node outside its slab and `halo` planes on either side (+ 1 above: nodes, not
+// cells) gives back its whole-grid node arrays and keeps nzs = nzl + 2 halo + 1 planes of each, from plane z0 - halo on
+// (State::zs0, nzs; kernels map a plane through held_plane(), the host through lp()).  At 512^3 on eight ranks that is
+// 77 planes of 512: 0.15 of the grid (and the whole-grid transform buffer goes: the decomposed solve has its own).
+// FPIC_DOMAIN_COMPACT=0 keeps the whole-grid arrays (a development switch: both layouts run the same kernels).
+template <typename T>
+int keep_slab_only(fpic_handle* h, int halo)
+{
+    State* st = h->es;
+    const Domain& d = *st->dom;
+    const int nzs = d.nzl + 2 * halo + 1;
+    if (const char* v = std::getenv("FPIC_DOMAIN_COMPACT"); v && std::strcmp(v, "0") == 0) return FPIC_OK;
+    if (d.world < 2 || !st->own_fft || nzs >= st->nz) return FPIC_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    struct Arr { void** p; size_t per_node; };
+    const Arr arrs[] = { { reinterpret_cast<void**>(&st->rho_fixed), sizeof(long long) }, { &st->rho, sizeof(T) }, { &st->phi, sizeof(T) }, { &st->E4, 4 * sizeof(T) },
+                         { &st->Ey, 4 * sizeof(T) }, { &st->By, 4 * sizeof(T) }, { &st->B4n, 4 * sizeof(T) }, { reinterpret_cast<void**>(&st->Jfix), 3 * sizeof(long long) } };
+    st->zs0 = ((d.z0 - halo) % st->nz + st->nz) % st->nz; // (held_plane() takes it in [0, nz))
+    st->nzs = nzs;
+    for (const Arr& a : arrs) {
+        if (!*a.p) continue;
+        HIP_TRY(h, hipFree(*a.p));
+        *a.p = nullptr;
+        h->bytes_grid -= st->nodes * a.per_node;
+        if (int rc = dev_alloc(h, a.p, held_nodes(st) * a.per_node, &h->bytes_grid)) return rc;
+    }
+    if (st->hat) {
+        HIP_TRY(h, hipFree(st->hat));
+        st->hat = nullptr;
+        h->bytes_grid -= static_cast<size_t>(st->nx / 2 + 1) * st->ny * st->nz * 2 * sizeof(T);
+    }
+    for (Species& s : st->sp) s.binned = false; // (nothing is binned yet: the rank's particles arrive after this)
+    return FPIC_OK;
+}
 
 int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve)
 {
@@ -2327,6 +2427,9 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
         const size_t cbytes = nxh * st->ny * nzl * 2 * esz;
         if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc))) return rc;
         if (st->own_fft) { // the library's own passes work in place on hatA / hatB: no plans, no z-major copy
+            // nothing on this rank reads or writes a node outside its slab, the ghost planes of the deposit (G below, G + 1
+            // above) and the planes of phi their gradient needs (one more on each side): keep those
+            if ((rc = h->prec == FPIC_F32 ? keep_slab_only<float>(h, ghost_planes + 2) : keep_slab_only<double>(h, ghost_planes + 2))) return rc;
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             return FPIC_OK;
         }

@@ -86,6 +86,21 @@ __device__ __forceinline__ T wrap01(T u)
     return r;
 }
 
+// The node arrays of a handle hold the planes zs0, zs0 + 1, ..., zs0 + nzs - 1 along z (periodic in nz): all of them
+// (zs0 = 0, nzs = nz) for an undecomposed handle or a rank that keeps global arrays; its slab with the ghost / halo planes
+// for a rank of a COMPACT decomposition (fes_api.hip, domain_init), whose arrays have nzs planes only.  Kernels take the
+// global plane index of a node through held_plane(): the plane's place in the array, or -1 for a plane the handle does not
+// hold (what a particle that has outrun the ghost planes would touch there is dropped: it was never read either).
+struct Held {
+    int zs0, nzs; // 0 <= zs0 < nz
+};
+__device__ __forceinline__ int held_plane(int k, Held hd, int nz)
+{
+    int l = k - hd.zs0;
+    if (l < 0) l += nz;
+    return l < hd.nzs ? l : -1;
+}
+
 template <typename T>
 struct Push3Args {
     T* slab;                 // x,y,z,vx,vy,vz, each `stride` elements
@@ -94,6 +109,7 @@ struct Push3Args {
     const T* E4;             // node records (Ex,Ey,Ez,phi)
     unsigned long long* rho; // int64 node accumulators (two's complement adds)
     int nx, ny, nz;
+    Held held;               // the planes E4 and rho hold
     T hc, tx, ty, tz, sx, sy, sz, dx, dy, dz;
     int Z;                   // charge number of the species
     // tiled form
@@ -138,35 +154,39 @@ struct GlobalGrid {
     const T* E4;
     unsigned long long* rho;
     int nx, ny, nz;
+    Held held;
+    // LEAN: rolled up, for the tiled kernels' rare particle outside the window (less code and fewer registers there)
+    template <bool LEAN = false>
     __device__ __forceinline__ void gather(int i, int j, int k, const T (&fx)[2], const T (&fy)[2], const T (&fz)[2], T& Ex, T& Ey, T& Ez) const
     {
         Ex = Ey = Ez = static_cast<T>(0);
-#pragma unroll
+#pragma unroll LEAN ? 1 : 2
         for (int c = 0; c < 2; ++c)
-#pragma unroll
+#pragma unroll LEAN ? 1 : 2
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
-                    T e[4];
-                    fpic::load4(E4 + 4 * (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)), e);
+                    const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = held_plane((k + c == nz) ? 0 : k + c, held, nz);
+                    T e[4] = { 0, 0, 0, 0 };
+                    if (kk >= 0) fpic::load4(E4 + 4 * (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)), e);
                     const T w = (fx[a] * fy[b]) * fz[c];
                     Ex = fma_(w, e[0], Ex);
                     Ey = fma_(w, e[1], Ey);
                     Ez = fma_(w, e[2], Ez);
                 }
     }
+    template <bool LEAN = false>
     __device__ __forceinline__ void deposit(int i, int j, int k, const int (&wx)[2], const int (&wy)[2], const int (&wz)[2], int Z) const
     {
-#pragma unroll
+#pragma unroll LEAN ? 1 : 2
         for (int c = 0; c < 2; ++c)
-#pragma unroll
+#pragma unroll LEAN ? 1 : 2
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
+                    const int ii = (i + a == nx) ? 0 : i + a, jj = (j + b == ny) ? 0 : j + b, kk = held_plane((k + c == nz) ? 0 : k + c, held, nz);
                     const long long w = weight3(wx[a], wy[b], wz[c] * Z);
-                    if (w) atomicAdd(rho + (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)),
+                    if (w && kk >= 0) atomicAdd(rho + (static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk)),
                                      static_cast<unsigned long long>(w));
                 }
     }
@@ -210,7 +230,7 @@ struct WindowGrid {
     __device__ __forceinline__ void gather(int i, int j, int k, const T (&fx)[2], const T (&fy)[2], const T (&fz)[2], T& Ex, T& Ey, T& Ez) const
     {
         const int s = slot(i, j, k);
-        if (s < 0) { g.gather(i, j, k, fx, fy, fz, Ex, Ey, Ez); return; }
+        if (s < 0) { g.template gather<true>(i, j, k, fx, fy, fz, Ex, Ey, Ez); return; }
         Ex = Ey = Ez = static_cast<T>(0);
         if constexpr ((ABL & 2) != 0) { Ex = fx[0] * fy[1]; Ey = fy[0] * fz[1]; Ez = fz[0] * fx[1]; return; }
         if constexpr (sizeof(T) == 4) {
@@ -249,7 +269,7 @@ struct WindowGrid {
     __device__ __forceinline__ void deposit(int i, int j, int k, const int (&wx)[2], const int (&wy)[2], const int (&wz)[2], int Z) const
     {
         const int s = slot(i, j, k);
-        if (s < 0) { g.deposit(i, j, k, wx, wy, wz, Z); ++*spilled; return; }
+        if (s < 0) { g.template deposit<true>(i, j, k, wx, wy, wz, Z); ++*spilled; return; }
         if constexpr ((ABL & 1) != 0) { *spilled += static_cast<unsigned>(wx[0] * wy[1] * wz[0] == 12345); return; }
         const int wzz[2] = { __mul24(wz[0], Z), __mul24(wz[1], Z) };
 #pragma unroll
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(256) void push3_flat_kernel(Push3Args<T> a)
     const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
     if (base >= a.n) return;
     const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
-    const GlobalGrid<T> grid{ a.E4, a.rho, a.nx, a.ny, a.nz };
+    const GlobalGrid<T> grid{ a.E4, a.rho, a.nx, a.ny, a.nz, a.held };
     P3<T> q[PPT];
     load_state3(a, base, cnt, q);
 #pragma unroll
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(256) void push3_tail_kernel(Push3Args<T> a, size_t 
     const size_t r = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r >= count) return;
     const size_t s = first + r;
-    const GlobalGrid<T> grid{ a.E4, a.rho, a.nx, a.ny, a.nz };
+    const GlobalGrid<T> grid{ a.E4, a.rho, a.nx, a.ny, a.nz, a.held };
     P3<T> q;
     q.x = a.slab[s]; q.y = a.slab[a.stride + s]; q.z = a.slab[2 * a.stride + s];
     q.vx = a.slab[3 * a.stride + s]; q.vy = a.slab[4 * a.stride + s]; q.vz = a.slab[5 * a.stride + s];
@@ -503,23 +523,29 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     for (int s = threadIdx.x; s < ((ABL & 4) ? 0 : kWN); s += THREADS) {
         const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
         const int m = rem / kWX, l = rem - m * kWX;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - a.held.zs0 + n) % a.nz; // gk: among the planes held
         if (gi < 0) gi += a.nx;
         if (gj < 0) gj += a.ny;
         if (gk < 0) gk += a.nz;
         lrho[s] = 0ull;
         if constexpr (!DEPOSIT_ONLY) {
-            const T* src = a.E4 + 4 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk));
+            const int lk = gk < a.held.nzs ? gk : -1;
+            if (lk >= 0) {
+                const T* src = a.E4 + 4 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * lk));
 #pragma unroll
-            for (int p = 0; p < PIECES; ++p)
-                *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(src + p * Vec16<T>::N);
+                for (int p = 0; p < PIECES; ++p)
+                    *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(src + p * Vec16<T>::N);
+            } else { // a plane the rank does not hold (beyond its ghost planes): no particle of the tile gathers there
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lE[4 * s + c] = static_cast<T>(0);
+            }
         }
     }
     if (threadIdx.x < 3 * kNbr3) lcensus[threadIdx.x] = 0;
     __syncthreads();
     unsigned my_spill = 0;
     uint32_t census_own = 0;
-    const WindowGrid<T, ABL> grid{ GlobalGrid<T>{ a.E4, a.rho, a.nx, a.ny, a.nz }, lE, lrho, ox, oy, oz, &my_spill };
+    const WindowGrid<T, ABL> grid{ GlobalGrid<T>{ a.E4, a.rho, a.nx, a.ny, a.nz, a.held }, lE, lrho, ox, oy, oz, &my_spill };
     size_t g_begin, g_end;
     item_groups(a.work, blockIdx.x, *a.nwork, w, PPT, a.part, a.tiles_per_layer, a.layer_lo, a.layer_hi, g_begin, g_end);
 
@@ -644,11 +670,11 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
         if (v == 0ull) continue;
         const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
         const int m = rem / kWX, l = rem - m * kWX;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - a.held.zs0 + n) % a.nz;
         if (gi < 0) gi += a.nx;
         if (gj < 0) gj += a.ny;
         if (gk < 0) gk += a.nz;
-        atomicAdd(a.rho + (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)), v);
+        if (gk < a.held.nzs) atomicAdd(a.rho + (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)), v);
     }
     if constexpr (!DEPOSIT_ONLY) {
         if (threadIdx.x < kNbr3) {
@@ -739,11 +765,14 @@ __global__ __launch_bounds__(256) void set_pos3_kernel(const In* __restrict__ ao
 
 // out.set({E}) for the box: value[i][j][k][c] -> node record i + nx*(j + ny*k), phi = 0
 template <typename T, typename In>
-__global__ __launch_bounds__(256) void pack_field3_kernel(const In* __restrict__ in, int nx, int ny, int nz, T* __restrict__ E4)
+__global__ __launch_bounds__(256) void pack_field3_kernel(const In* __restrict__ in, int nx, int ny, int nz, T* __restrict__ E4, Held held)
 {
-    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c >= static_cast<size_t>(nx) * ny * nz) return;
-    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / (static_cast<size_t>(nx) * ny));
+    const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= static_cast<size_t>(nx) * ny * nz) return;
+    const int i = static_cast<int>(g % nx), j = static_cast<int>((g / nx) % ny), k = static_cast<int>(g / (static_cast<size_t>(nx) * ny));
+    const int lk = held_plane(k, held, nz);
+    if (lk < 0) return; // (a compact rank keeps the planes it holds)
+    const size_t c = i + static_cast<size_t>(nx) * (j + static_cast<size_t>(ny) * lk);
     const In* v = in + 3 * ((static_cast<size_t>(i) * ny + j) * nz + k);
     E4[4 * c] = static_cast<T>(v[0]); E4[4 * c + 1] = static_cast<T>(v[1]); E4[4 * c + 2] = static_cast<T>(v[2]); E4[4 * c + 3] = static_cast<T>(0);
 }
@@ -873,15 +902,17 @@ __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(256) void em_nodes_kernel(const T* __restrict__ Ey, const T* __restrict__ By, int nx, int ny, int nz, T* __restrict__ E4n,
-                                                       T* __restrict__ B4n, int k0, int nk)
+                                                       T* __restrict__ B4n, int k0, int nk, Held held)
 {
-    // planes k0 .. k0 + nk - 1 (periodic): the whole grid for one handle, the slab and its ghost planes for a rank
+    // planes k0 .. k0 + nk - 1 (periodic): the whole grid for one handle, the slab and its ghost planes for a rank; the
+    // arrays hold the planes `held` (the planes named and the one below them are held)
     const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
     if (t >= sz * nk) return;
-    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), k = (k0 + static_cast<int>(t / sz)) % nz;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), kg = (k0 + static_cast<int>(t / sz)) % nz;
+    const int k = held_plane(kg, held, nz), km = held_plane(kg ? kg - 1 : nz - 1, held, nz);
     const size_t c = i + sy * j + sz * k;
-    const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
+    const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1;
     E4n[4 * c] = static_cast<T>(0.5) * (FES_AT(Ey, im, j, k, 0) + FES_AT(Ey, i, j, k, 0));
     E4n[4 * c + 1] = static_cast<T>(0.5) * (FES_AT(Ey, i, jm, k, 1) + FES_AT(Ey, i, j, k, 1));
     E4n[4 * c + 2] = static_cast<T>(0.5) * (FES_AT(Ey, i, j, km, 2) + FES_AT(Ey, i, j, k, 2));
@@ -892,17 +923,18 @@ __global__ __launch_bounds__(256) void em_nodes_kernel(const T* __restrict__ Ey,
     B4n[4 * c + 3] = static_cast<T>(0);
 }
 
-// B -= cb * curl E (em_update_b)
+// B -= cb * curl E (em_update_b) on the planes k0 .. k0 + nk - 1 (they and the one above them are held)
 template <typename T>
 __global__ __launch_bounds__(256) void em_update_b_kernel(T* __restrict__ By, const T* __restrict__ Ey, int nx, int ny, int nz, T cbx, T cby, T cbz, int k0,
-                                                          int nk)
+                                                          int nk, Held held)
 {
     const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
     if (t >= sz * nk) return;
-    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), k = (k0 + static_cast<int>(t / sz)) % nz;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), kg = (k0 + static_cast<int>(t / sz)) % nz;
+    const int k = held_plane(kg, held, nz), kp = held_plane((kg + 1 == nz) ? 0 : kg + 1, held, nz);
     const size_t c = i + sy * j + sz * k;
-    const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1, kp = (k + 1 == nz) ? 0 : k + 1;
+    const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1;
     const T cx = (FES_AT(Ey, i, jp, k, 2) - FES_AT(Ey, i, j, k, 2)) * cby - (FES_AT(Ey, i, j, kp, 1) - FES_AT(Ey, i, j, k, 1)) * cbz;
     const T cy = (FES_AT(Ey, i, j, kp, 0) - FES_AT(Ey, i, j, k, 0)) * cbz - (FES_AT(Ey, ip, j, k, 2) - FES_AT(Ey, i, j, k, 2)) * cbx;
     const T cz = (FES_AT(Ey, ip, j, k, 1) - FES_AT(Ey, i, j, k, 1)) * cbx - (FES_AT(Ey, i, jp, k, 0) - FES_AT(Ey, i, j, k, 0)) * cby;
@@ -911,17 +943,19 @@ __global__ __launch_bounds__(256) void em_update_b_kernel(T* __restrict__ By, co
     By[4 * c + 2] = By[4 * c + 2] - cz;
 }
 
-// E += ce * curl B - je * J, with J = T((double)Jfix * scale) formed on the fly (em_j_real + em_update_e)
+// E += ce * curl B - je * J, with J = T((double)Jfix * scale) formed on the fly (em_j_real + em_update_e), on the planes
+// k0 .. k0 + nk - 1 (they and the one below them are held)
 template <typename T>
 __global__ __launch_bounds__(256) void em_update_e_kernel(T* __restrict__ Ey, const T* __restrict__ By, const long long* __restrict__ Jfix, int nx, int ny,
-                                                          int nz, T cex, T cey, T cez, T je, double jsx, double jsy, double jsz, int k0, int nk)
+                                                          int nz, T cex, T cey, T cez, T je, double jsx, double jsy, double jsz, int k0, int nk, Held held)
 {
     const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
     if (t >= sz * nk) return;
-    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), k = (k0 + static_cast<int>(t / sz)) % nz;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), kg = (k0 + static_cast<int>(t / sz)) % nz;
+    const int k = held_plane(kg, held, nz), km = held_plane(kg ? kg - 1 : nz - 1, held, nz);
     const size_t c = i + sy * j + sz * k;
-    const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1, km = k ? k - 1 : nz - 1;
+    const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1;
     const T cx = (FES_AT(By, i, j, k, 2) - FES_AT(By, i, jm, k, 2)) * cey - (FES_AT(By, i, j, k, 1) - FES_AT(By, i, j, km, 1)) * cez;
     const T cy = (FES_AT(By, i, j, k, 0) - FES_AT(By, i, j, km, 0)) * cez - (FES_AT(By, i, j, k, 2) - FES_AT(By, im, j, k, 2)) * cex;
     const T cz = (FES_AT(By, i, j, k, 1) - FES_AT(By, im, j, k, 1)) * cex - (FES_AT(By, i, j, k, 0) - FES_AT(By, i, jm, k, 0)) * cey;
@@ -933,15 +967,20 @@ __global__ __launch_bounds__(256) void em_update_e_kernel(T* __restrict__ Ey, co
     Ey[4 * c + 2] = (Ey[4 * c + 2] + cz) - je * jz;
 }
 
-// E on the Yee edges from phi (em_edge_gradient)
+// E on the Yee edges from phi (em_edge_gradient) on the planes k0 .. k0 + nk - 1 (they and the one above them are held)
 template <typename T>
-__global__ __launch_bounds__(256) void em_edge_gradient_kernel(const T* __restrict__ phi, int nx, int ny, int nz, T hx, T hy, T hz, T* __restrict__ Ey)
+__global__ __launch_bounds__(256) void em_edge_gradient_kernel(const T* __restrict__ phi, int nx, int ny, int nz, T hx, T hy, T hz, T* __restrict__ Ey, int k0, int nk,
+                                                               Held held)
 {
-    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (c >= sz * nz) return;
-    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / sz);
-    const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1, kp = (k + 1 == nz) ? 0 : k + 1;
+    if (t >= sz * nk) return;
+    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny);
+    int kg = (k0 + static_cast<int>(t / sz)) % nz;
+    if (kg < 0) kg += nz;
+    const int k = held_plane(kg, held, nz), kp = held_plane((kg + 1 == nz) ? 0 : kg + 1, held, nz);
+    const size_t c = i + sy * j + sz * k;
+    const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1;
     Ey[4 * c] = (phi[c] - phi[ip + sy * j + sz * k]) * hx;
     Ey[4 * c + 1] = (phi[c] - phi[i + sy * jp + sz * k]) * hy;
     Ey[4 * c + 2] = (phi[c] - phi[i + sy * j + sz * kp]) * hz;
@@ -955,17 +994,6 @@ __global__ __launch_bounds__(256) void fill4_kernel(T* __restrict__ a, size_t no
     const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= nodes) return;
     a[4 * c] = x; a[4 * c + 1] = y; a[4 * c + 2] = z; a[4 * c + 3] = static_cast<T>(0);
-}
-
-// value[i][j][k][c] -> 4 T per node (the lattice's own arrays)
-template <typename T, typename In>
-__global__ __launch_bounds__(256) void pack_lattice_kernel(const In* __restrict__ in, int nx, int ny, int nz, T* __restrict__ out4)
-{
-    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c >= static_cast<size_t>(nx) * ny * nz) return;
-    const int i = static_cast<int>(c % nx), j = static_cast<int>((c / nx) % ny), k = static_cast<int>(c / (static_cast<size_t>(nx) * ny));
-    const In* v = in + 3 * ((static_cast<size_t>(i) * ny + j) * nz + k);
-    out4[4 * c] = static_cast<T>(v[0]); out4[4 * c + 1] = static_cast<T>(v[1]); out4[4 * c + 2] = static_cast<T>(v[2]); out4[4 * c + 3] = static_cast<T>(0);
 }
 
 // doubled fixed-point lattice coordinate (em_coord)
@@ -982,7 +1010,7 @@ __device__ __forceinline__ long long floor_div_ll(long long a, long long s) { re
 // one straight segment inside one cell (current_segment).  Not inlined: the rare global path must not bloat the
 // unrolled particle loops of its callers.
 __device__ __attribute__((noinline)) void current_segment(const long long (&p1)[3], const long long (&p2)[3], const long long (&cell)[3], int nx, int ny, int nz, int Z,
-                                                unsigned long long* Jfix)
+                                                unsigned long long* Jfix, Held held)
 {
     constexpr long long S = 32768;
     long long d[3], A0[3], A1[3], c0[3], c1[3];
@@ -1009,14 +1037,15 @@ __device__ __attribute__((noinline)) void current_segment(const long long (&p1)[
                 const long long flux = d[m] * (3 * (b ? A1[u] : A0[u]) * (c ? A1[v] : A0[v]) + (b == c ? cross : -cross)) * Z;
                 long long idx[3];
                 idx[m] = c0[m]; idx[u] = b ? c1[u] : c0[u]; idx[v] = c ? c1[v] : c0[v];
-                if (flux) atomicAdd(Jfix + 3 * (static_cast<size_t>(idx[0]) + static_cast<size_t>(nx) * (static_cast<size_t>(idx[1]) + static_cast<size_t>(ny) * idx[2])) + m,
-                                    static_cast<unsigned long long>(flux));
+                const int lk = held_plane(static_cast<int>(idx[2]), held, nz);
+                if (flux && lk >= 0) atomicAdd(Jfix + 3 * (static_cast<size_t>(idx[0]) + static_cast<size_t>(nx) * (static_cast<size_t>(idx[1]) + static_cast<size_t>(ny) * lk)) + m,
+                                               static_cast<unsigned long long>(flux));
             }
     }
 }
 
 // the move a -> b_in (nearest periodic image) cut at the zigzag relay point (es3d_current)
-__device__ __forceinline__ void current_deposit(const long long (&a)[3], const long long (&b_in)[3], int nx, int ny, int nz, int Z, unsigned long long* Jfix)
+__device__ __forceinline__ void current_deposit(const long long (&a)[3], const long long (&b_in)[3], int nx, int ny, int nz, int Z, unsigned long long* Jfix, Held held)
 {
     constexpr long long S = 32768;
     const int n[3] = { nx, ny, nz };
@@ -1032,8 +1061,8 @@ __device__ __forceinline__ void current_deposit(const long long (&a)[3], const l
         cb[m] = floor_div_ll(b[m], S);
         r[m] = (ca[m] == cb[m]) ? (a[m] + b[m]) / 2 : (ca[m] > cb[m] ? ca[m] : cb[m]) * S;
     }
-    current_segment(a, r, ca, nx, ny, nz, Z, Jfix);
-    current_segment(r, b, cb, nx, ny, nz, Z, Jfix);
+    current_segment(a, r, ca, nx, ny, nz, Z, Jfix, held);
+    current_segment(r, b, cb, nx, ny, nz, Z, Jfix, held);
 }
 
 template <typename T>
@@ -1045,6 +1074,7 @@ struct EmPushArgs {
     const T* B4n;
     unsigned long long* Jfix;
     int nx, ny, nz;
+    Held held;               // the planes E4n, B4n and Jfix hold
     T h, hc, dx, dy, dz;
     int Z;
 };
@@ -1072,9 +1102,9 @@ __device__ __forceinline__ void em_boris_move(P3<T>& p, T E0, T E1, T E2, T B0, 
 
 // em_push + es3d_current of ONE particle against global memory: gathers through L2, the current with 8-byte global
 // atomics.  The body of the flat kernel, and the out-of-line rare path of the tiled kernel.
-template <typename T>
+template <typename T, bool LEAN = false>
 __device__ __forceinline__ void em_particle_global(P3<T>& p, const T* __restrict__ E4n, const T* __restrict__ B4n, unsigned long long* Jfix, int nx, int ny, int nz, T h, T hc,
-                                                   T dx, T dy, T dz, int Z)
+                                                   T dx, T dy, T dz, int Z, Held held)
 {
     const T q14 = static_cast<T>(1.0 / 16384.0);
     int i, j, k, w1;
@@ -1086,17 +1116,21 @@ __device__ __forceinline__ void em_particle_global(P3<T>& p, const T* __restrict
     axis(p.z, nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14;
     const long long hz0 = 2 * (static_cast<long long>(k) * 16384 + w1);
     T E[3] = { 0, 0, 0 }, B[3] = { 0, 0, 0 };
-#pragma unroll
+    // (LEAN: the tiled kernel's out-of-line copy, rolled up: the registers a callee uses are registers its caller must
+    // save around the call, and the caller is the hot loop)
+#pragma unroll LEAN ? 1 : 2
     for (int c = 0; c < 2; ++c)
-#pragma unroll
+#pragma unroll LEAN ? 1 : 2
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
-                const int ii = (i + aa == nx) ? 0 : i + aa, jj = (j + b == ny) ? 0 : j + b, kk = (k + c == nz) ? 0 : k + c;
-                const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * kk);
-                T e[4], bb[4];
-                fpic::load4(E4n + 4 * node, e);
-                fpic::load4(B4n + 4 * node, bb);
+                const int ii = (i + aa == nx) ? 0 : i + aa, jj = (j + b == ny) ? 0 : j + b, kk = held_plane((k + c == nz) ? 0 : k + c, held, nz);
+                const size_t node = static_cast<size_t>(ii) + static_cast<size_t>(nx) * (static_cast<size_t>(jj) + static_cast<size_t>(ny) * (kk < 0 ? 0 : kk));
+                T e[4] = { 0, 0, 0, 0 }, bb[4] = { 0, 0, 0, 0 };
+                if (kk >= 0) {
+                    fpic::load4(E4n + 4 * node, e);
+                    fpic::load4(B4n + 4 * node, bb);
+                }
                 const T w = (fx[aa] * fy[b]) * fz[c];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
@@ -1107,7 +1141,7 @@ __device__ __forceinline__ void em_particle_global(P3<T>& p, const T* __restrict
     em_boris_move<T>(p, E[0], E[1], E[2], B[0], B[1], B[2], h, hc, dx, dy, dz);
     const long long from[3] = { hx0, hy0, hz0 };
     const long long to[3] = { em_coord(p.x, nx), em_coord(p.y, ny), em_coord(p.z, nz) };
-    current_deposit(from, to, nx, ny, nz, Z, Jfix);
+    current_deposit(from, to, nx, ny, nz, Z, Jfix, held);
 }
 
 // Flat form (any particle order; used until the particles have been binned)
@@ -1120,7 +1154,7 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
     q.x = a.slab[p]; q.y = a.slab[a.stride + p]; q.z = a.slab[2 * a.stride + p];
     q.vx = a.slab[3 * a.stride + p]; q.vy = a.slab[4 * a.stride + p]; q.vz = a.slab[5 * a.stride + p];
     if (q.x < static_cast<T>(0)) return; // a migrated slot
-    em_particle_global<T>(q, a.E4n, a.B4n, a.Jfix, a.nx, a.ny, a.nz, a.h, a.hc, a.dx, a.dy, a.dz, a.Z);
+    em_particle_global<T>(q, a.E4n, a.B4n, a.Jfix, a.nx, a.ny, a.nz, a.h, a.hc, a.dx, a.dy, a.dz, a.Z, a.held);
     a.slab[p] = q.x; a.slab[a.stride + p] = q.y; a.slab[2 * a.stride + p] = q.z;
     a.slab[3 * a.stride + p] = q.vx; a.slab[4 * a.stride + p] = q.vy; a.slab[5 * a.stride + p] = q.vz;
 }
@@ -1154,7 +1188,11 @@ struct EmTileArgs {
     int part;                // see Push3Args
     uint32_t tiles_per_layer, layer_lo, layer_hi;
     unsigned long long* spilled;
+    const EmPushArgs<T>* resident; // a copy of p in device memory: what the out-of-line rare paths read their grid from
 };
+
+template <typename A>
+__global__ void store_args_kernel(A a, A* dst) { *dst = a; }
 
 // window slot of cell (i,j,k) (all eight corner nodes inside), or -1; cells lie within one box length of the grid
 template <typename T>
@@ -1242,13 +1280,14 @@ __device__ __forceinline__ void current_cell_fast(int wx, int wy, int wz, int d0
     }
 }
 
-// The rare moves of the tiled kernel, out of line, everything by value: from (f*) to (t*, nearest image) in single
-// fixed-point units (cell * 2^14 + weight).  es3d_current in doubled coordinates: the relay point, one segment per
-// cell, each into the LDS window when its cell lies inside and into global memory otherwise.  Returns the number of
-// segments that went to global memory.
+// The rare moves of the tiled kernel, out of line, by value: from (f*) to (t*, nearest image) in single fixed-point
+// units (cell * 2^14 + weight).  es3d_current in doubled coordinates: the relay point, one segment per cell, each into
+// the LDS window when its cell lies inside and into global memory otherwise (through g, the resident copy of the
+// arguments: a face crossing is one particle in ten and should not wait for a load; this is none).  Returns the number
+// of segments that went to global memory.
 template <typename T>
 __device__ __attribute__((noinline)) unsigned em_current_rare(int f0, int f1, int f2, int t0, int t1, int t2, int ox, int oy, int oz, int nx, int ny, int nz, int Z,
-                                                              FPIC_LDS unsigned long long* lJ, unsigned long long* Jfix)
+                                                              FPIC_LDS unsigned long long* lJ, const EmPushArgs<T>* g)
 {
     constexpr int S = 32768;
     const int from[3] = { 2 * f0, 2 * f1, 2 * f2 }, to[3] = { 2 * t0, 2 * t1, 2 * t2 };
@@ -1268,7 +1307,7 @@ __device__ __attribute__((noinline)) unsigned em_current_rare(int f0, int f1, in
             current_cell<T>(p1, p2, cell, s, Z, lJ);
         } else {
             const long long q1[3] = { p1[0], p1[1], p1[2] }, q2[3] = { p2[0], p2[1], p2[2] }, cc[3] = { cell[0], cell[1], cell[2] };
-            current_segment(q1, q2, cc, nx, ny, nz, Z, Jfix);
+            current_segment(q1, q2, cc, nx, ny, nz, Z, g->Jfix, g->held); // (a face crossing is one particle in ten; this, none)
             ++spilled;
         }
     };
@@ -1283,10 +1322,9 @@ __device__ __attribute__((noinline)) unsigned em_current_rare(int f0, int f1, in
 
 // a particle whose cell is not inside the window: the whole sub-step against global memory, out of line
 template <typename T>
-__device__ __attribute__((noinline)) P3<T> em_particle_rare(P3<T> p, const T* E4n, const T* B4n, unsigned long long* Jfix, int nx, int ny, int nz, T h, T hc, T dx, T dy,
-                                                            T dz, int Z)
+__device__ __attribute__((noinline)) P3<T> em_particle_rare(P3<T> p, const EmPushArgs<T>* g)
 {
-    em_particle_global<T>(p, E4n, B4n, Jfix, nx, ny, nz, h, hc, dx, dy, dz, Z);
+    em_particle_global<T, true>(p, g->E4n, g->B4n, g->Jfix, g->nx, g->ny, g->nz, g->h, g->hc, g->dx, g->dy, g->dz, g->Z, g->held);
     return p;
 }
 
@@ -1307,19 +1345,27 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
     using V = typename NatVec16<T>::type;
     constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
+    const Held hs = a.held;
+    const Held hf = a.held;
     for (int s = threadIdx.x; s < WN; s += kEmThreads) {
         const int n = s / (W * W), rem = s - n * (W * W);
         const int m = rem / W, l = rem - m * W;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - hs.zs0 + n) % a.nz; // gk: among the planes held
         if (gi < 0) gi += a.nx;
         if (gj < 0) gj += a.ny;
         if (gk < 0) gk += a.nz;
-        const size_t node = static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk);
+        const int lk = gk < hs.nzs ? gk : -1;
+        const size_t node = static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * (lk < 0 ? 0 : lk));
         lJ[3 * s] = 0ull; lJ[3 * s + 1] = 0ull; lJ[3 * s + 2] = 0ull;
+        if (lk >= 0) {
 #pragma unroll
-        for (int p = 0; p < PIECES; ++p) {
-            *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.E4n + 4 * node + p * Vec16<T>::N);
-            *reinterpret_cast<FPIC_LDS V*>(lB + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.B4n + 4 * node + p * Vec16<T>::N);
+            for (int p = 0; p < PIECES; ++p) {
+                *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.E4n + 4 * node + p * Vec16<T>::N);
+                *reinterpret_cast<FPIC_LDS V*>(lB + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.B4n + 4 * node + p * Vec16<T>::N);
+            }
+        } else { // a plane the rank does not hold: no particle of the tile gathers there
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { lE[4 * s + c] = static_cast<T>(0); lB[4 * s + c] = static_cast<T>(0); }
         }
     }
     __syncthreads();
@@ -1344,7 +1390,7 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
             const int s0 = em_slot<T>(i, j, k, ox, oy, oz, a.nx, a.ny, a.nz);
             if (s0 < 0) { // rare: the cell has left the window
                 P3<T> p{ x, y, z, v[3][q], v[4][q], v[5][q] };
-                p = em_particle_rare<T>(p, a.E4n, a.B4n, a.Jfix, a.nx, a.ny, a.nz, a.h, a.hc, a.dx, a.dy, a.dz, a.Z);
+                p = em_particle_rare<T>(p, t.resident);
                 v[0][q] = p.x; v[1][q] = p.y; v[2][q] = p.z; v[3][q] = p.vx; v[4][q] = p.vy; v[5][q] = p.vz;
                 ++my_spill;
                 continue;
@@ -1422,7 +1468,7 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
 #endif
             else
                 my_spill += em_current_rare<T>((i << 14) + wx1, (j << 14) + wy1, (k << 14) + wz1, (i << 14) + e0, (j << 14) + e1, (k << 14) + e2, ox, oy, oz, a.nx, a.ny,
-                                               a.nz, a.Z, lJ, a.Jfix);
+                                               a.nz, a.Z, lJ, t.resident);
         }
         if (cnt == PPT) {
 #pragma unroll
@@ -1443,11 +1489,11 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
         const int s = s3 / 3, m3 = s3 - 3 * s;
         const int n = s / (W * W), rem = s - n * (W * W);
         const int m = rem / W, l = rem - m * W;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz + n) % a.nz;
+        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - hf.zs0 + n) % a.nz;
         if (gi < 0) gi += a.nx;
         if (gj < 0) gj += a.ny;
         if (gk < 0) gk += a.nz;
-        atomicAdd(a.Jfix + 3 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)) + m3, val);
+        if (gk < hf.nzs) atomicAdd(a.Jfix + 3 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)) + m3, val);
     }
     if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));
 }
@@ -1657,10 +1703,11 @@ __global__ __launch_bounds__(256) void kspace_slab_kernel(T* __restrict__ hatB, 
     hatB[2 * c + 1] = hatB[2 * c + 1] * g;
 }
 
-// gradient_kernel on the planes k0 .. k0 + count - 1 (periodic)
+// gradient_kernel on the planes k0 .. k0 + count - 1 (periodic); phi and E4 hold the planes `held` (the planes named and
+// one beyond on either side are held)
 template <typename T>
 __global__ __launch_bounds__(256) void gradient_planes_kernel(const T* __restrict__ phi, int nx, int ny, int nz, int k0, int count, T hx, T hy, T hz,
-                                                              T* __restrict__ E4)
+                                                              T* __restrict__ E4, Held held)
 {
     const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
@@ -1669,10 +1716,11 @@ __global__ __launch_bounds__(256) void gradient_planes_kernel(const T* __restric
     int k = k0 + static_cast<int>(t / sz);
     k %= nz;
     if (k < 0) k += nz;
-    const size_t c = i + sy * j + sz * k;
     const int im = i ? i - 1 : nx - 1, ip = (i + 1 == nx) ? 0 : i + 1;
     const int jm = j ? j - 1 : ny - 1, jp = (j + 1 == ny) ? 0 : j + 1;
-    const int km = k ? k - 1 : nz - 1, kp = (k + 1 == nz) ? 0 : k + 1;
+    const int km = held_plane(k ? k - 1 : nz - 1, held, nz), kp = held_plane((k + 1 == nz) ? 0 : k + 1, held, nz);
+    k = held_plane(k, held, nz);
+    const size_t c = i + sy * j + sz * k;
     E4[4 * c] = (phi[im + sy * j + sz * k] - phi[ip + sy * j + sz * k]) * hx;
     E4[4 * c + 1] = (phi[i + sy * jm + sz * k] - phi[i + sy * jp + sz * k]) * hy;
     E4[4 * c + 2] = (phi[i + sy * j + sz * km] - phi[i + sy * j + sz * kp]) * hz;

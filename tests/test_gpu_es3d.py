@@ -470,6 +470,71 @@ def test_slab_decomposed_poisson_solve(fp, eo, precision, world, shape):
         s.destroy()
 
 
+def _decomposed_run(fp, spec, precision, world, G, pos, vel, frames, species_b=None):
+    """a group of `world` in-process ranks with the decomposed solve; returns per-rank read-backs and the particles"""
+    shape = (spec["nr"], spec["ny"], spec["nz"])
+    L = (spec["radius"], spec["length_y"], spec["height"])
+    nzl = shape[2] // world
+    own = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
+    order = np.argsort(own, kind="stable")
+    pos, vel, counts = pos[order], vel[order], np.bincount(own, minlength=world)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=2 * len(pos)), precision=precision)
+        s.domainInit(r, world, ghost_planes=G, migrate_every=2, distributed_solve=True)
+        first = int(counts[:r].sum())
+        s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    group.precalc()
+    for _ in range(frames):
+        group.step()
+    out = {"grid_bytes": [s.stats()["bytes_grid_state"] for s in ranks], "ranks": []}
+    for r, s in enumerate(ranks):
+        held = np.arange(r * nzl - G, (r + 1) * nzl + G + 1) % shape[2]     # what the cycle of this rank reads and writes
+        grids = {}
+        for name, which, kind in (("rho_fixed", fp.F3_RHO_FIXED, None), ("phi", fp.F3_PHI, np.float64), ("E", fp.F3_E, np.float64), ("rho", fp.F3_RHO, np.float64)):
+            a = s.readField(which) if kind is None else s.readField(which, kind)
+            grids[name] = a.reshape(shape[2], -1)[held if name != "rho" else held[G:G + nzl]]
+        part = s.domainGet(np.float64)
+        out["ranks"].append((grids, part, s.domainStats()))
+    for s in ranks:
+        s.destroy()
+    return out
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape,G", [(4, (16, 32, 64), 2), (8, (32, 16, 128), 3), (4, (16, 16, 32), 1), (2, (8, 16, 64), 2)])
+def test_slab_only_arrays_change_nothing(fp, monkeypatch, precision, world, shape, G):
+    """A rank of a decomposition with the decomposed solve keeps nzl + 2 (G + 2) + 1 planes of every node array instead of
+    the whole grid (fes_api.hip, keep_slab_only).  Both layouts run the same kernels on the same numbers: every grid the
+    cycle touches, every particle, the migration counters are bit-identical to the run that keeps whole-grid arrays
+    (FPIC_DOMAIN_COMPACT=0), the first and last slab's halo wraps around the box, and the grid memory of a rank shrinks."""
+    rng = np.random.default_rng(77 + world)
+    n = 30000
+    L = tuple(1e-3 * s for s in shape)
+    spec = box_spec(shape, L, count=n, dt=5e-12, macro_weight=1e15 * np.prod(L) / n)
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.02, (n, 3))
+    monkeypatch.setenv("FPIC_DOMAIN_COMPACT", "0")
+    whole = _decomposed_run(fp, spec, precision, world, G, pos, vel, frames=5)
+    monkeypatch.delenv("FPIC_DOMAIN_COMPACT")
+    slab = _decomposed_run(fp, spec, precision, world, G, pos, vel, frames=5)
+    for r in range(world):
+        (g0, p0, st0), (g1, p1, st1) = whole["ranks"][r], slab["ranks"][r]
+        for name in g0:
+            assert same_bits(g0[name], g1[name]) if g0[name].dtype.kind == "f" else np.array_equal(g0[name], g1[name]), (r, name)
+        i0, i1 = np.argsort(p0["ids"]), np.argsort(p1["ids"])          # (a rank holds its particles in no particular order)
+        assert np.array_equal(p0["ids"][i0], p1["ids"][i1]), r
+        assert same_bits(p0["position"][i0], p1["position"][i1]) and same_bits(p0["velocity"][i0], p1["velocity"][i1]), r
+        assert st0 == st1, r
+    assert sum(st["migrated"] for _, _, st in slab["ranks"]) > 0
+    nzs = shape[2] // world + 2 * (G + 2) + 1
+    assert nzs < shape[2]
+    esz = 4 if precision == "fp32" else 8
+    saved = (shape[2] - nzs) * shape[0] * shape[1] * (8 + 6 * esz) + (shape[0] // 2 + 1) * shape[1] * shape[2] * 2 * esz
+    assert all(w - c == saved for w, c in zip(whole["grid_bytes"], slab["grid_bytes"]))
+
+
 # ---------------------------------------------------------------------------- LDS-staged (two-level) first binning
 # Populations of 2^20 particles and more are binned by sort_scatter_kernel; FPIC_TWO_LEVEL_MIN (read when the handle is
 # created) lowers that size so that the small oracle-checked scenes above run through the same kernels: ragged last
