@@ -441,7 +441,7 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
         s_ = fp.makeCylindricalParticlePusher(dict(spec, count=cap), device=device, precision=precision)
         if nspecies == 2:
             s_.addSpecies(mi, qi, cap)
-        s_.domainInit(r, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=not em)
+        s_.domainInit(r, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=True)
         for sp in range(nspecies):
             p, v = particles(r, sp)
             s_.domainSet(p, v, first_id=r * share, species=sp)
@@ -523,7 +523,7 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
         comm = {"transport": "libfusionpic.so's own RCCL communicator (fpic_comm_init)", "rank": r_, "world": w_}
         if w_ != world:
             raise RuntimeError("fpic_comm_info reports a world of %d, the launcher has %d ranks" % (w_, world))
-    sim.domainInit(rank, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=not em and world > 1)
+    sim.domainInit(rank, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=world > 1)
     for sp in range(nspecies):
         p, v = c4_rank_particles(rank, world, sp, share, L, vth, 1.0 if sp == 0 else mi / spec["particle_mass"], local_rank)
         sim.domainSet(p, v, first_id=rank * share, species=sp)

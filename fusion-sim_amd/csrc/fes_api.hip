@@ -120,6 +120,7 @@ struct Domain {
     // transforms along z of the rank's share of the ky rows, and back; otherwise every rank transforms the whole grid
     bool distributed = false;
     int nyl = 0;
+    int phi_below = 0, phi_above = 0;   // planes of the potential a rank receives from its neighbours after the decomposed solve
     void *hatA = nullptr, *hatB = nullptr, *xbuf = nullptr; // [nzl][ny][nxh], [nz][nyl][nxh], transposition staging (complex T each)
     rocfft_plan p2f = nullptr, p2i = nullptr, pzf = nullptr, pzi = nullptr;
     rocfft_execution_info i2f = nullptr, i2i = nullptr, izf = nullptr, izi = nullptr;
@@ -631,6 +632,7 @@ template <typename T>
 int em_nodes(fpic_handle* h, int k0 = 0, int nk = -1)
 {
     State* st = h->es;
+    if (nk < 0 && compact(st)) { k0 = st->zs0 + 1; nk = st->nzs - 1; } // (a node reads the edges and faces of the plane below as well)
     if (nk < 0 || nk > st->nz) nk = st->nz;
     k0 = (k0 % st->nz + st->nz) % st->nz;
     em_nodes_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<const T*>(st->Ey), static_cast<const T*>(st->By), st->nx,
@@ -1661,9 +1663,10 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
         out.push_back({ up, down, f + 4 * lp(st, d.z0 + d.nzl - d.H) * plane, bytes, f + 4 * lp(st, below) * plane, bytes, 1 });
     } else { // X_PHI: the potential on the planes the gradient of my slab and its ghost planes needs
         T* phi = static_cast<T*>(st->phi);
-        const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.G - 1 + st->nz) % st->nz;
-        out.push_back({ down, up, phi + lp(st, d.z0) * plane, (d.G + 2) * plane * sizeof(T), phi + lp(st, above) * plane, (d.G + 2) * plane * sizeof(T), 0 });
-        out.push_back({ up, down, phi + lp(st, d.z0 + d.nzl - d.G - 1) * plane, (d.G + 1) * plane * sizeof(T), phi + lp(st, below) * plane, (d.G + 1) * plane * sizeof(T), 1 });
+        const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.phi_below + st->nz) % st->nz;
+        const size_t na = d.phi_above * plane * sizeof(T), nb = d.phi_below * plane * sizeof(T);
+        out.push_back({ down, up, phi + lp(st, d.z0) * plane, na, phi + lp(st, above) * plane, na, 0 });
+        out.push_back({ up, down, phi + lp(st, d.z0 + d.nzl - d.phi_below) * plane, nb, phi + lp(st, below) * plane, nb, 1 });
     }
 }
 
@@ -2001,10 +2004,17 @@ int solve_distributed(Ranks& rk)
         State* st = h->es;
         Domain& d = *st->dom;
         const size_t plane = static_cast<size_t>(st->nx) * st->ny;
-        const int count = d.nzl + 2 * d.G + 1;
-        gradient_planes_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
-            static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, d.z0 - d.G, count, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
-            static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4), held_of(st));
+        if (st->solver == FPIC_SOLVER_YEE) { // the initial E on the edges of the slab and of its H halo planes on either side
+            const int count = d.nzl + 2 * d.H;
+            em_edge_gradient_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
+                static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
+                static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey), ((d.z0 - d.H) % st->nz + st->nz) % st->nz, count, held_of(st));
+        } else {
+            const int count = d.nzl + 2 * d.G + 1;
+            gradient_planes_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
+                static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, d.z0 - d.G, count, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
+                static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4), held_of(st));
+        }
         HIP_TRY(h, hipGetLastError());
         timing_end(h);
         h->solve_launches++;
@@ -2418,7 +2428,12 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     }
     std::memset(d->counts_host, 0, 8 * sizeof(unsigned));
     for (Species& s : st->sp) s.n = 0; // the rank's particles arrive through domain_set_particles
-    if (distributed_solve && world > 1 && st->solver == FPIC_SOLVER_POISSON_FFT) {
+    // the full-EM mode solves once, for the initial field: with the library's own transforms (whose decomposed solve is the
+    // one handle's, bit for bit) its ranks can take the decomposed solve too, and then never hold the whole grid
+    const bool yee_decomposed = st->solver == FPIC_SOLVER_YEE && st->own_fft && st->ny % world == 0;
+    if (distributed_solve && world > 1 && (st->solver == FPIC_SOLVER_POISSON_FFT || yee_decomposed)) {
+        d->phi_below = st->solver == FPIC_SOLVER_YEE ? d->H : ghost_planes + 1;
+        d->phi_above = d->phi_below + 1;
         if (st->ny % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d rows along y do not divide into %d shares for the decomposed solve", st->ny, world);
         if (ghost_planes + 2 > nzl) return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- the decomposed solve needs ghost_planes + 2 <= %d planes per slab", nzl);
         d->distributed = true;

@@ -911,6 +911,7 @@ __global__ __launch_bounds__(256) void em_nodes_kernel(const T* __restrict__ Ey,
     if (t >= sz * nk) return;
     const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), kg = (k0 + static_cast<int>(t / sz)) % nz;
     const int k = held_plane(kg, held, nz), km = held_plane(kg ? kg - 1 : nz - 1, held, nz);
+    if ((k | km) < 0) return; // (a plane the caller should not have named)
     const size_t c = i + sy * j + sz * k;
     const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1;
     E4n[4 * c] = static_cast<T>(0.5) * (FES_AT(Ey, im, j, k, 0) + FES_AT(Ey, i, j, k, 0));
@@ -933,6 +934,7 @@ __global__ __launch_bounds__(256) void em_update_b_kernel(T* __restrict__ By, co
     if (t >= sz * nk) return;
     const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), kg = (k0 + static_cast<int>(t / sz)) % nz;
     const int k = held_plane(kg, held, nz), kp = held_plane((kg + 1 == nz) ? 0 : kg + 1, held, nz);
+    if ((k | kp) < 0) return;
     const size_t c = i + sy * j + sz * k;
     const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1;
     const T cx = (FES_AT(Ey, i, jp, k, 2) - FES_AT(Ey, i, j, k, 2)) * cby - (FES_AT(Ey, i, j, kp, 1) - FES_AT(Ey, i, j, k, 1)) * cbz;
@@ -954,6 +956,7 @@ __global__ __launch_bounds__(256) void em_update_e_kernel(T* __restrict__ Ey, co
     if (t >= sz * nk) return;
     const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), kg = (k0 + static_cast<int>(t / sz)) % nz;
     const int k = held_plane(kg, held, nz), km = held_plane(kg ? kg - 1 : nz - 1, held, nz);
+    if ((k | km) < 0) return;
     const size_t c = i + sy * j + sz * k;
     const int im = i ? i - 1 : nx - 1, jm = j ? j - 1 : ny - 1;
     const T cx = (FES_AT(By, i, j, k, 2) - FES_AT(By, i, jm, k, 2)) * cey - (FES_AT(By, i, j, k, 1) - FES_AT(By, i, j, km, 1)) * cez;
@@ -979,6 +982,7 @@ __global__ __launch_bounds__(256) void em_edge_gradient_kernel(const T* __restri
     int kg = (k0 + static_cast<int>(t / sz)) % nz;
     if (kg < 0) kg += nz;
     const int k = held_plane(kg, held, nz), kp = held_plane((kg + 1 == nz) ? 0 : kg + 1, held, nz);
+    if ((k | kp) < 0) return;
     const size_t c = i + sy * j + sz * k;
     const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1;
     Ey[4 * c] = (phi[c] - phi[ip + sy * j + sz * k]) * hx;
@@ -1720,6 +1724,7 @@ __global__ __launch_bounds__(256) void gradient_planes_kernel(const T* __restric
     const int jm = j ? j - 1 : ny - 1, jp = (j + 1 == ny) ? 0 : j + 1;
     const int km = held_plane(k ? k - 1 : nz - 1, held, nz), kp = held_plane((k + 1 == nz) ? 0 : k + 1, held, nz);
     k = held_plane(k, held, nz);
+    if ((k | km | kp) < 0) return; // (a plane the caller should not have named)
     const size_t c = i + sy * j + sz * k;
     E4[4 * c] = (phi[im + sy * j + sz * k] - phi[ip + sy * j + sz * k]) * hx;
     E4[4 * c + 1] = (phi[i + sy * jm + sz * k] - phi[i + sy * jp + sz * k]) * hy;

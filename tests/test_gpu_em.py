@@ -326,6 +326,97 @@ def test_slab_decomposed_em_from_precalc(fp, eo, precision):
         s.destroy()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape,ghost,start", [(4, (16, 16, 64), 2, "precalc"), (8, (16, 32, 128), 3, "precalc"), (4, (32, 16, 64), 1, "upload"),
+                                                     (2, (16, 16, 32), 2, "precalc")])
+def test_decomposed_em_with_slab_only_arrays(fp, eo, monkeypatch, precision, world, shape, ghost, start):
+    """distributed_solve on the ranks of a full-EM run (power-of-two lattice: the library's own transforms): the initial
+    field comes from the decomposed solve, whose phi is the one handle's bit for bit, and every rank keeps nzl + 2 H + 1
+    planes (H = ghost + 2) of its node arrays instead of the whole lattice.  From precalc() or from uploaded fields, over
+    frames with migration: the current grid, both lattice fields on the own planes and every particle bit-identical to one
+    handle's; the same with whole-grid arrays (FPIC_DOMAIN_COMPACT=0); the grid memory of a rank shrinks."""
+    rng = np.random.default_rng(23 + world)
+    L = tuple(1e-3 * s for s in shape)
+    n = shape[0] * shape[1] * shape[2] * 2
+    dt = cfl_dt(shape, L, 0.5)
+    dens = (0.02 / dt) ** 2 * eo.EPS0 * ME / QE ** 2
+    spec = em_spec(shape, L, n, dt, macro_weight=dens * np.prod(L) / n)
+    nzl = shape[2] // world
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.25, (n, 3))
+    owner = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
+    order = np.argsort(owner, kind="stable")
+    pos, vel, counts = pos[order], vel[order], np.bincount(owner, minlength=world)
+    E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
+
+    def prepare(sim):
+        if start == "upload":
+            sim.set(edge_E=E, face_B=B)
+        else:
+            sim.addB(0.0, 0.0, 0.01)
+
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.set(position=pos, velocity=vel)
+    prepare(one)
+    if start == "precalc":
+        one.precalc()
+    trace = []                                       # (edge E, face B, J, positions, velocities) of one handle, frame by frame
+    def snapshot_one():
+        p = one.getParticles()
+        return [one.readField(w).reshape(shape[2], -1) for w in (fp.F3_EDGE_E, fp.F3_FACE_B, fp.F3_J_FIXED)] + [p["position"], p["velocity"]]
+    trace.append(snapshot_one())
+    frames = 5
+    for _ in range(frames):
+        one.step()
+        trace.append(snapshot_one())
+    one.destroy()
+
+    grid_bytes = {}
+    for layout in ("whole", "slab"):
+        if layout == "whole":
+            monkeypatch.setenv("FPIC_DOMAIN_COMPACT", "0")
+        else:
+            monkeypatch.delenv("FPIC_DOMAIN_COMPACT")
+        ranks = []
+        for r in range(world):
+            s = fp.makeCylindricalParticlePusher(spec, precision=precision)
+            s.domainInit(r, world, ghost_planes=ghost, migrate_every=2, distributed_solve=True)
+            first = int(counts[:r].sum())
+            s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
+            prepare(s)
+            ranks.append(s)
+        group = fp.BoxGroup(ranks)
+        if start == "precalc":
+            group.precalc()
+        grid_bytes[layout] = [s.stats()["bytes_grid_state"] for s in ranks]
+        for frame in range(frames + 1):
+            ref = trace[frame]
+            for r, s in enumerate(ranks):
+                own = slice(r * nzl, (r + 1) * nzl)
+                for w, which in enumerate((fp.F3_EDGE_E, fp.F3_FACE_B, fp.F3_J_FIXED)):
+                    if which == fp.F3_J_FIXED and frame == 0:
+                        continue
+                    got = s.readField(which).reshape(shape[2], -1)[own]
+                    assert (np.array_equal if which == fp.F3_J_FIXED else same_bits)(got, ref[w][own]), (layout, frame, r, which)
+            parts = [s.domainGet() for s in ranks]
+            ids = np.concatenate([p["ids"] for p in parts])
+            assert np.array_equal(np.sort(ids), np.arange(n)), (layout, frame)
+            assert same_bits(np.concatenate([p["position"] for p in parts])[np.argsort(ids)], ref[3]), (layout, frame)
+            assert same_bits(np.concatenate([p["velocity"] for p in parts])[np.argsort(ids)], ref[4]), (layout, frame)
+            if frame < frames:
+                group.step()
+        stats = [s.domainStats() for s in ranks]
+        assert sum(st["migrated"] for st in stats) > 0 and all(st["lost"] == 0 for st in stats), layout
+        group.density()                              # (the frame loop's density() on slab-only arrays)
+        total = sum(int(s.readField(fp.F3_RHO_FIXED).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl].astype(object).sum()) for r, s in enumerate(ranks))
+        assert total == n * 2 ** 42, layout
+        for s in ranks:
+            s.destroy()
+    nzs = nzl + 2 * (ghost + 2) + 1
+    esz = 4 if precision == "fp32" else 8
+    saved = (shape[2] - nzs) * shape[0] * shape[1] * (8 + 24 + 18 * esz) + (shape[0] // 2 + 1) * shape[1] * shape[2] * 2 * esz
+    assert nzs < shape[2] and all(w - c == saved for w, c in zip(grid_bytes["whole"], grid_bytes["slab"]))
+
+
 def test_large_decomposed_em_is_bit_identical_to_one_handle(fp, eo):
     """1.2e7 electrons on a 64 x 64 x 128 Yee lattice over 8 in-process ranks (1.5e6 per rank: the staged two-level
     binning of the 8^3-cell tiles), migration every 4 sub-steps, from precalc(): after 4 frames the current grid and both

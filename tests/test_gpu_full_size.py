@@ -156,7 +156,8 @@ def test_configs3_at_full_size(fp, eo, bench):
     one.destroy()
     torch.cuda.empty_cache()
 
-    # the 8-slab decomposition on the same 512^3 grid (replicated solve: bit-comparable fields), 1e8 + 1e8 particles
+    # the 8-slab decomposition on the same 512^3 grid (decomposed solve with the library's own transforms: the one handle's
+    # field bit for bit; every rank keeps 77 of the 512 planes), 1e8 + 1e8 particles
     small = 200_000_000
     share = small // 2 // world
     spec2 = dict(spec, macro_weight=spec["macro_weight"] * total / small)
@@ -166,7 +167,7 @@ def test_configs3_at_full_size(fp, eo, bench):
     for r in range(world):
         s = fp.makeCylindricalParticlePusher(dict(spec2, count=int(share * 1.25)))
         s.addSpecies(mi, qi, int(share * 1.25))
-        s.domainInit(r, world, ghost_planes=4, migrate_every=8)
+        s.domainInit(r, world, ghost_planes=4, migrate_every=8, distributed_solve=True)
         ranks.append(s)
     for sp in range(2):
         for r in range(world):
