@@ -67,15 +67,37 @@ __device__ __forceinline__ double fma_(double a, double b, double c) { return __
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2_(float w, f32x2 e, f32x2 acc) { return __builtin_elementwise_fma(f32x2{ w, w }, e, acc); }
 
-// cell and upper weight of a normalised coordinate (es3d_axis)
+template <typename T> __device__ __forceinline__ T fract_(T v);
+template <> __device__ __forceinline__ float fract_<float>(float v) { return __builtin_amdgcn_fractf(v); }
+template <> __device__ __forceinline__ double fract_<double>(double v) { return __builtin_amdgcn_fract(v); }
+
+// cell and upper weight of a normalised coordinate (es3d_axis).  The same numbers in fewer instructions (the tiled
+// kernels are bound by their VALU work: profiles/r03_c3_traffic.json): for 0 <= g < 2^23, g - (T)(int)g is v_fract's
+// g - floor(g), exact either way; and "if (i >= n) i -= n" for 0 <= i <= n is the unsigned minimum of i and i - n.
 template <typename T>
 __device__ __forceinline__ void axis(T u, int n, int& i, int& w1)
 {
     const T g = u * static_cast<T>(n);
     i = static_cast<int>(g);
-    const T f = g - static_cast<T>(i);
-    if (i >= n) i -= n;
+    const T f = fract_(g);
+    i = static_cast<int>(min(static_cast<unsigned>(i), static_cast<unsigned>(i - n)));
     w1 = (static_cast<int>(f * static_cast<T>(32768)) + 1) >> 1;
+}
+
+// the lower weight as T: (16384 - w1) / 16384 = 1 - w1 / 16384, exact (both are multiples of 2^-14 in [0, 1])
+template <typename T>
+__device__ __forceinline__ void weights_of(int w1, T (&f)[2])
+{
+    f[1] = static_cast<T>(w1) * static_cast<T>(1.0 / 16384.0);
+    f[0] = static_cast<T>(1) - f[1];
+}
+
+// d mod n for -n < d < 2 n, as an unsigned number: whichever of d, d + n, d - n lies in [0, n) is the smallest of the
+// three taken as unsigned (one v_min3_u32 instead of two compare-and-select pairs)
+__device__ __forceinline__ unsigned wrap_near(int d, int n)
+{
+    const unsigned u = static_cast<unsigned>(d), m = static_cast<unsigned>(n);
+    return min(min(u, u + m), u - m);
 }
 
 template <typename T>
@@ -217,15 +239,9 @@ struct WindowGrid {
     // window slot of cell (i,j,k), or -1 when one of its eight nodes lies outside
     __device__ __forceinline__ int slot(int i, int j, int k) const
     {
-        int l = i - ox, m = j - oy, n = k - oz;
-        if (l < 0) l += g.nx;
-        if (l >= g.nx) l -= g.nx;
-        if (m < 0) m += g.ny;
-        if (m >= g.ny) m -= g.ny;
-        if (n < 0) n += g.nz;
-        if (n >= g.nz) n -= g.nz;
+        const unsigned l = wrap_near(i - ox, g.nx), m = wrap_near(j - oy, g.ny), n = wrap_near(k - oz, g.nz);
         const bool in = l <= Win<T>::X - 2 && m <= Win<T>::Y - 2 && n <= Win<T>::Z - 2;
-        return in ? __mul24(__mul24(n, Win<T>::Y) + m, Win<T>::X) + l : -1; // (24-bit multiplies are full rate)
+        return in ? static_cast<int>(__umul24(__umul24(n, Win<T>::Y) + m, Win<T>::X) + l) : -1; // (24-bit multiplies are full rate)
     }
     __device__ __forceinline__ void gather(int i, int j, int k, const T (&fx)[2], const T (&fy)[2], const T (&fz)[2], T& Ex, T& Ey, T& Ez) const
     {
@@ -289,12 +305,11 @@ struct WindowGrid {
 template <typename T, bool HAS_B, typename Grid>
 __device__ __forceinline__ void substep3(P3<T>& q, const Push3Args<T>& a, const Grid& grid, int& ni, int& nj, int& nk)
 {
-    const T q14 = static_cast<T>(1.0 / 16384.0);
     int i, j, k, w1;
     T fx[2], fy[2], fz[2];
-    axis(q.x, a.nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14;
-    axis(q.y, a.ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14;
-    axis(q.z, a.nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14;
+    axis(q.x, a.nx, i, w1); weights_of(w1, fx);
+    axis(q.y, a.ny, j, w1); weights_of(w1, fy);
+    axis(q.z, a.nz, k, w1); weights_of(w1, fz);
     T Ex, Ey, Ez;
     grid.gather(i, j, k, fx, fy, fz, Ex, Ey, Ez);
     const T ax = a.hc * Ex, ay = a.hc * Ey, az = a.hc * Ez;
@@ -1110,14 +1125,13 @@ template <typename T, bool LEAN = false>
 __device__ __forceinline__ void em_particle_global(P3<T>& p, const T* __restrict__ E4n, const T* __restrict__ B4n, unsigned long long* Jfix, int nx, int ny, int nz, T h, T hc,
                                                    T dx, T dy, T dz, int Z, Held held)
 {
-    const T q14 = static_cast<T>(1.0 / 16384.0);
     int i, j, k, w1;
     T fx[2], fy[2], fz[2];
-    axis(p.x, nx, i, w1); fx[1] = static_cast<T>(w1) * q14; fx[0] = static_cast<T>(16384 - w1) * q14;
+    axis(p.x, nx, i, w1); weights_of(w1, fx);
     const long long hx0 = 2 * (static_cast<long long>(i) * 16384 + w1);
-    axis(p.y, ny, j, w1); fy[1] = static_cast<T>(w1) * q14; fy[0] = static_cast<T>(16384 - w1) * q14;
+    axis(p.y, ny, j, w1); weights_of(w1, fy);
     const long long hy0 = 2 * (static_cast<long long>(j) * 16384 + w1);
-    axis(p.z, nz, k, w1); fz[1] = static_cast<T>(w1) * q14; fz[0] = static_cast<T>(16384 - w1) * q14;
+    axis(p.z, nz, k, w1); weights_of(w1, fz);
     const long long hz0 = 2 * (static_cast<long long>(k) * 16384 + w1);
     T E[3] = { 0, 0, 0 }, B[3] = { 0, 0, 0 };
     // (LEAN: the tiled kernel's out-of-line copy, rolled up: the registers a callee uses are registers its caller must
@@ -1202,17 +1216,10 @@ __global__ void store_args_kernel(A a, A* dst) { *dst = a; }
 template <typename T>
 __device__ __forceinline__ int em_slot(int i, int j, int k, int ox, int oy, int oz, int nx, int ny, int nz)
 {
-    int l = i - ox, m = j - oy, n = k - oz;
-    if (l < 0) l += nx;
-    if (l >= nx) l -= nx;
-    if (m < 0) m += ny;
-    if (m >= ny) m -= ny;
-    if (n < 0) n += nz;
-    if (n >= nz) n -= nz;
-    constexpr int W = EmWin<T>::W;
-    const bool in = static_cast<unsigned>(l) <= static_cast<unsigned>(W - 2) && static_cast<unsigned>(m) <= static_cast<unsigned>(W - 2) &&
-                    static_cast<unsigned>(n) <= static_cast<unsigned>(W - 2);
-    return in ? __mul24(__mul24(n, W) + m, W) + l : -1;
+    const unsigned l = wrap_near(i - ox, nx), m = wrap_near(j - oy, ny), n = wrap_near(k - oz, nz);
+    constexpr unsigned W = EmWin<T>::W;
+    const bool in = l <= W - 2 && m <= W - 2 && n <= W - 2;
+    return in ? static_cast<int>(__umul24(__umul24(n, W) + m, W) + l) : -1;
 }
 
 // fluxes of one straight segment inside the cell whose window slot is s (current_segment, LDS accumulators)
@@ -1374,7 +1381,6 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     }
     __syncthreads();
     unsigned my_spill = 0;
-    const T q14 = static_cast<T>(1.0 / 16384.0);
     size_t g_begin, g_end;
     item_groups(t.work, blockIdx.x, *t.nwork, w, PPT, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi, g_begin, g_end);
     for (size_t g = g_begin + threadIdx.x; g < g_end; g += kEmThreads) {
@@ -1399,9 +1405,8 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
                 ++my_spill;
                 continue;
             }
-            const T fx[2] = { static_cast<T>(16384 - wx1) * q14, static_cast<T>(wx1) * q14 };
-            const T fy[2] = { static_cast<T>(16384 - wy1) * q14, static_cast<T>(wy1) * q14 };
-            const T fz[2] = { static_cast<T>(16384 - wz1) * q14, static_cast<T>(wz1) * q14 };
+            T fx[2], fy[2], fz[2];
+            weights_of(wx1, fx); weights_of(wy1, fy); weights_of(wz1, fz);
             T E[3], B[3];
             if constexpr (sizeof(T) == 4) {
                 // float: each record of a ds_read_b128 is two register pairs; (E0, E1), (E2, -), (B0, B1), (B2, -) are
