@@ -470,13 +470,14 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     out["decomposed_in_process"] = {
         "ranks": world, "serial_ms_per_substep_all_ranks": 1e3 * el / sub,
         "note": "the ranks share one GPU and run one after the other: per-rank kernel times are in the rocprofv3 kernel stats of this command "
-                "(profiles/r02_c4_kernel_stats.csv: totals / ranks), not in this wall-clock figure",
+                "(profiles/r03_c4_kernel_stats.csv: the launches of the decomposed part / ranks), not in this wall-clock figure",
         "particles_migrated_per_substep": (sum(d["migrated"] for d in dom) - mig0[0]) / float(sub), "lost": sum(d["lost"] for d in dom),
         "ghost_planes": ghost, "migrate_every": migrate_every,
         "exchange_bytes_per_rank_per_substep":
             {"current_ghost_planes_int64_reduce": 2 * (ghost + 2) * plane * 3 * 8, "lattice_halo_copies_E_and_B": 2 * 2 * (ghost + 2) * plane * 4 * esz} if em else
             {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
-             "fft_transposes": 2 * 2 * (grid // 2 + 1) * grid * (grid // world) * 2 * esz * (world - 1) // world,
+             # (rows of the half spectrum are padded to whole 128-byte tiles in the library's own transform buffers)
+             "fft_transposes": 2 * 2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid * (grid // world) * 2 * esz * (world - 1) // world,
              "field_ghost_planes": 2 * 3 * plane * 4 * esz},
     }
     for s_ in ranks:
@@ -566,7 +567,8 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
         exchanges = {"current_ghost_planes_int64_reduce": 2 * (ghost + 2) * plane * 3 * 8, "lattice_halo_copies_E_and_B": 2 * 2 * (ghost + 2) * plane * 4 * esz}
     else:
         exchanges = {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
-                     "fft_transposes_all_to_all": 2 * (grid // 2 + 1) * grid * (grid // world) * 2 * esz * (world - 1) // world,
+                     # (rows of the half spectrum are padded to whole 128-byte tiles in the library's own transform buffers)
+                     "fft_transposes_all_to_all": 2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid * (grid // world) * 2 * esz * (world - 1) // world,
                      "potential_planes": (2 * ghost + 3) * plane * esz,
                      "migration_records_32B": 32 * dom["migrated"] // max(1, sub)}
     out = {

@@ -408,13 +408,31 @@ int fft_status(fpic_handle* h, rocfft_status s, const char* what)
 }
 
 // ---- the library's own FFT passes (fes_fft.hpp)
+// complex values per row of the half spectrum: nx / 2 + 1 for rocFFT's buffers; the library's own passes pad a row to whole
+// column tiles (129 -> 144 floats, 136 doubles), so that a tile's piece of a row is one aligned 128-byte line (column
+// passes 56 / 78 / 54 -> 45 / 72 / 39 us at 256^3, profiles/r03_fft_ablation.txt)
+template <typename T>
+size_t row_pitch(const State* st)
+{
+    const size_t nxh = st->nx / 2 + 1, c = fft_tile_columns<T>();
+    return st->own_fft ? (nxh + c - 1) / c * c : nxh;
+}
+
+// complex values of the whole-grid transform buffer (sized before it is known whether these passes or rocFFT will use it)
+template <typename T>
+size_t hat_values(const State* st)
+{
+    const size_t c = fft_tile_columns<T>(), nxh = st->nx / 2 + 1;
+    return (nxh + c - 1) / c * c * st->ny * st->nz;
+}
+
 template <typename T>
 int fft_x_forward(fpic_handle* h, const long long* fixed, const T* rho, double scale, size_t rows, T* hat)
 {
     State* st = h->es;
     const int ppw = fft_tile_columns<T>(); // pairs of rows per workgroup (two real rows ride on one complex transform)
     fft_x_forward_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(fixed, rho, scale, rows, st->nx, fft_log2(st->nx), ppw, hat,
-                                                                                                                 static_cast<const T*>(st->fft_tw[0]));
+                                                                                                                 static_cast<const T*>(st->fft_tw[0]), static_cast<int>(row_pitch<T>(st)));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -425,7 +443,7 @@ int fft_x_inverse(fpic_handle* h, const T* hat, size_t rows, T* phi)
     State* st = h->es;
     const int ppw = fft_tile_columns<T>();
     fft_x_inverse_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(hat, rows, st->nx, fft_log2(st->nx), ppw, phi,
-                                                                                                                 static_cast<const T*>(st->fft_tw[0]));
+                                                                                                                 static_cast<const T*>(st->fft_tw[0]), static_cast<int>(row_pitch<T>(st)));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
@@ -438,7 +456,7 @@ int fft_columns(fpic_handle* h, T* hat, size_t outer_stride, size_t stride, int 
     State* st = h->es;
     const T* twt = static_cast<const T*>(st->fft_tw[MODE == 2 ? 2 : 1]); // (the y passes and the z sweep: N is ny resp. nz)
     const int nxh = st->nx / 2 + 1;
-    const ColLayout L{ outer_stride, stride, outer, nxh, xbuf ? nyl : 0, nzl };
+    const ColLayout L{ outer_stride, stride, outer, nxh, static_cast<int>(row_pitch<T>(st)), xbuf ? nyl : 0, nzl };
     // (tiles of 16 complex floats / 8 doubles: 4, 8 and 32 columns were measured and lose, profiles/r03_fft_ablation.txt)
     constexpr int C = fft_tile_columns<T>();
     const unsigned tiles = static_cast<unsigned>((nxh + C - 1) / C);
@@ -476,7 +494,7 @@ int launch_solve(fpic_handle* h, bool convert = true)
     if (st->own_fft && (st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE)) {
         // five sweeps: x forward (straight from the integer grid), y forward, the whole z direction with the k-space
         // factor, y inverse, x inverse
-        const int nxh = st->nx / 2 + 1;
+        const size_t nxh = row_pitch<T>(st); // (the rows' pitch)
         const size_t rows = static_cast<size_t>(st->ny) * st->nz, line = static_cast<size_t>(st->ny) * nxh;
         T* hat = static_cast<T*>(st->hat);
         int rc;
@@ -924,13 +942,12 @@ int create_state(fpic_handle* h)
 {
     State* st = h->es;
     uint64_t* acc = &h->bytes_grid;
-    const int nxh = st->nx / 2 + 1;
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&st->rho_fixed), st->nodes * sizeof(long long), acc)) ||
         (rc = dev_alloc(h, &st->rho, st->nodes * sizeof(T), acc)) ||
         (rc = dev_alloc(h, &st->phi, st->nodes * sizeof(T), acc)) ||
         (rc = dev_alloc(h, &st->E4, st->nodes * 4 * sizeof(T), acc)) ||
-        (rc = dev_alloc(h, &st->hat, static_cast<size_t>(nxh) * st->ny * st->nz * 2 * sizeof(T), acc)) ||
+        (rc = dev_alloc(h, &st->hat, hat_values<T>(st) * 2 * sizeof(T), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&st->spilled), sizeof(unsigned long long), acc)))
         return rc;
     const int dims[3] = { st->nx, st->ny, st->nz };
@@ -1643,7 +1660,7 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
         out.push_back({ up, down, d.mig_send[1], d.counts_host[1] * rec, d.mig_recv[1], d.counts_host[5] * rec, 1 });
     } else if (which == X_TRANSPOSE || which == X_TRANSPOSE_BACK) {
         // all-to-all of equal chunks: chunk q of the send side goes to rank q and lands there as chunk `rank`
-        const size_t chunk = static_cast<size_t>(d.nzl) * d.nyl * (st->nx / 2 + 1) * 2 * sizeof(T);
+        const size_t chunk = static_cast<size_t>(d.nzl) * d.nyl * row_pitch<T>(st) * 2 * sizeof(T);
         const char* src = static_cast<const char*>(which == X_TRANSPOSE ? d.xbuf : d.hatB);
         char* dst = static_cast<char*>(which == X_TRANSPOSE ? d.hatB : d.xbuf);
         for (int q = 0; q < d.world; ++q) out.push_back({ q, q, src + q * chunk, chunk, dst + q * chunk, chunk, 0 });
@@ -1945,7 +1962,7 @@ int solve_distributed(Ranks& rk)
     if (int e = each([&](fpic_handle* h) -> int {
             State* st = h->es;
             Domain& d = *st->dom;
-            const int nxh = st->nx / 2 + 1;
+            const int nxh = static_cast<int>(row_pitch<T>(st)); // (the rows' pitch: nx / 2 + 1 with rocFFT)
             const size_t plane = static_cast<size_t>(st->nx) * st->ny;
             timing_begin(h, KC_SOLVE);
             if (own) { // x pass straight from the integer grid of the own planes, then the y pass
@@ -1966,7 +1983,7 @@ int solve_distributed(Ranks& rk)
     if (int e = each([&](fpic_handle* h) -> int {
             State* st = h->es;
             Domain& d = *st->dom;
-            const int nxh = st->nx / 2 + 1;
+            const int nxh = static_cast<int>(row_pitch<T>(st)); // (the rows' pitch: nx / 2 + 1 with rocFFT)
             if (own) // the whole z direction in one sweep over hatB [nz][nyl][nxh]: forward, k-space factor, inverse
                 return fft_columns<T, 2>(h, static_cast<T*>(d.hatB), nxh, static_cast<size_t>(d.nyl) * nxh, d.nyl, st->nz, d.rank * d.nyl);
             // hatB [nz][nyl][nxh] -> hatZ [nyl * nxh][nz], contiguous transforms along z, the k-space factor, and back
@@ -1988,7 +2005,7 @@ int solve_distributed(Ranks& rk)
     if (int e = each([&](fpic_handle* h) -> int {
             State* st = h->es;
             Domain& d = *st->dom;
-            const int nxh = st->nx / 2 + 1;
+            const int nxh = static_cast<int>(row_pitch<T>(st)); // (the rows' pitch: nx / 2 + 1 with rocFFT)
             const size_t plane = static_cast<size_t>(st->nx) * st->ny;
             const size_t total = static_cast<size_t>(nxh) * st->ny * d.nzl;
             if (own) { // (the y pass loads straight from the all-to-all's receive buffer: no unpack sweep)
@@ -2372,7 +2389,7 @@ int keep_slab_only(fpic_handle* h, int halo)
     if (st->hat) {
         HIP_TRY(h, hipFree(st->hat));
         st->hat = nullptr;
-        h->bytes_grid -= static_cast<size_t>(st->nx / 2 + 1) * st->ny * st->nz * 2 * sizeof(T);
+        h->bytes_grid -= hat_values<T>(st) * 2 * sizeof(T);
     }
     for (Species& s : st->sp) s.binned = false; // (nothing is binned yet: the rank's particles arrive after this)
     return FPIC_OK;
@@ -2439,7 +2456,7 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
         d->distributed = true;
         d->nyl = st->ny / world;
         const size_t nxh = st->nx / 2 + 1, esz = h->esize;
-        const size_t cbytes = nxh * st->ny * nzl * 2 * esz;
+        const size_t cbytes = (h->prec == FPIC_F32 ? row_pitch<float>(st) : row_pitch<double>(st)) * st->ny * nzl * 2 * esz;
         if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc))) return rc;
         if (st->own_fft) { // the library's own passes work in place on hatA / hatB: no plans, no z-major copy
             // nothing on this rank reads or writes a node outside its slab, the ghost planes of the deposit (G below, G + 1

@@ -209,7 +209,7 @@ __device__ __forceinline__ void fft_tile(FPIC_LDS C2<T>* buf, int ld, int cols, 
 // A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i (exact halvings).  A workgroup takes 2 * pairs_per_wg rows.
 template <typename T>
 __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long long* __restrict__ fixed, const T* __restrict__ rho, double scale, size_t rows, int nx, int logn,
-                                                                    int pairs_per_wg, T* __restrict__ hat, const T* __restrict__ twt)
+                                                                    int pairs_per_wg, T* __restrict__ hat, const T* __restrict__ twt, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
@@ -222,8 +222,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
         const int p = e / nx, i = e - p * nx;
         const size_t g = (row0 + 2 * p) * nx + i;
         // (rho given: the charge density already converted — a rank of a replicated solve has gathered the others' planes)
-        const T a = fixed ? static_cast<T>(static_cast<double>(fixed[g]) * scale) : rho[g];
-        const T b = fixed ? static_cast<T>(static_cast<double>(fixed[g + nx]) * scale) : rho[g + nx];
+        // (the charge grid is read once per sub-step: non-temporal)
+        const T a = fixed ? static_cast<T>(static_cast<double>(__builtin_nontemporal_load(fixed + g)) * scale) : rho[g];
+        const T b = fixed ? static_cast<T>(static_cast<double>(__builtin_nontemporal_load(fixed + g + nx)) * scale) : rho[g + nx];
         fesfft::stc<T>(buf, p * ld + fesfft::swz(i), C2<T>{ a, b });
     }
     __syncthreads();
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
     for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
         const int p = e / nxh, k = e - p * nxh;
         const C2<T> z = fesfft::ldc<T>(buf, p * ld + fesfft::swz(k)), w = fesfft::ldc<T>(buf, p * ld + fesfft::swz((nx - k) & (nx - 1)));
-        out[(row0 + 2 * p) * nxh + k] = C2<T>{ (z.x + w.x) * half, (z.y - w.y) * half };
-        out[(row0 + 2 * p + 1) * nxh + k] = C2<T>{ (z.y + w.y) * half, (w.x - z.x) * half };
+        out[(row0 + 2 * p) * pitch + k] = C2<T>{ (z.x + w.x) * half, (z.y - w.y) * half };
+        out[(row0 + 2 * p + 1) * pitch + k] = C2<T>{ (z.y + w.y) * half, (w.x - z.x) * half };
     }
 }
 
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
 // rows per complex transform again: Z[k] = A[k] + i B[k], Z[N-k] = conj A[k] + i conj B[k]; a = Re z, b = Im z
 template <typename T>
 __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __restrict__ hat, size_t rows, int nx, int logn, int pairs_per_wg, T* __restrict__ phi,
-                                                                    const T* __restrict__ twt)
+                                                                    const T* __restrict__ twt, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_lds[];
     FPIC_LDS C2<T>* buf = (FPIC_LDS C2<T>*)fft_lds;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
     const C2<T>* in = reinterpret_cast<const C2<T>*>(hat);
     for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
         const int p = e / nxh, k = e - p * nxh;
-        const C2<T> A = in[(row0 + 2 * p) * nxh + k], B = in[(row0 + 2 * p + 1) * nxh + k];
+        const C2<T> A = in[(row0 + 2 * p) * pitch + k], B = in[(row0 + 2 * p + 1) * pitch + k];
         fesfft::stc<T>(buf, p * ld + fesfft::swz(k), C2<T>{ A.x - B.y, A.y + B.x });
         if (k && k < nx - k) fesfft::stc<T>(buf, p * ld + fesfft::swz(nx - k), C2<T>{ A.x + B.y, B.x - A.y });
     }
@@ -269,26 +270,28 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
     }
 }
 
-// ---- column passes.  The half spectrum is [outer2][N or outer1][...][nxh] with the x index fastest; a tile is C
+// ---- column passes.  The half spectrum is [outer2][N or outer1][...][pitch] with the x index fastest and rows of
+// pitch >= nxh complex values (row_pitch in fes_api.hip: a multiple of the tile width, so that a tile's C consecutive
+// values of a row are ONE aligned 128-byte line instead of pieces of two: 129 -> 144 floats, 136 doubles); a tile is C
 // consecutive x of every point of ONE column line: element (idx, c) of tile (o, t) sits at
 //     base + o * outer_stride + idx * stride + t * C + c.
 // MODE 0: forward transform; 1: inverse; 2: forward, k-space factor, inverse — the whole z direction of the solve in one
 // sweep (the factor needs the mode indices: kx = t C + c, ky = y0 + o, kz = idx).
 struct ColLayout {
     size_t outer_stride, stride;   // complex elements
-    int outer, nxh;
+    int outer, nxh, pitch;
     // The y passes of a slab-decomposed solve exchange their lines with the other ranks (an all-to-all transposition): the
-    // forward pass STORES straight into the send buffer [q][nzl][nyl][nxh] — row ky = q nyl + yl of plane o goes to rank q
+    // forward pass STORES straight into the send buffer [q][nzl][nyl][pitch] — row ky = q nyl + yl of plane o goes to rank q
     // — and the inverse pass LOADS from the receive buffer of the same shape (nyl = 0: plain layout on both sides).  That
     // is the pack / unpack sweep of round 2 (26 + 39 us per rank at 512^3 / 8) done by address arithmetic.
     int nyl, nzl;
 };
 
-// element (idx, c) of the tile of line o in the exchange buffer: [q][nzl][nyl][nxh]
+// element (idx, c) of the tile of line o in the exchange buffer: [q][nzl][nyl][pitch]
 __device__ __forceinline__ size_t exchange_index(const ColLayout& L, int o, int idx, int i)
 {
     const int q = idx / L.nyl, yl = idx - q * L.nyl;
-    return ((static_cast<size_t>(q) * L.nzl + o) * L.nyl + yl) * L.nxh + i;
+    return ((static_cast<size_t>(q) * L.nzl + o) * L.nyl + yl) * L.pitch + i;
 }
 
 template <typename T, int MODE, int C = fft_tile_columns<T>()>

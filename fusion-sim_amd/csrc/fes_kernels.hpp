@@ -752,11 +752,11 @@ __global__ __launch_bounds__(256) void gradient_kernel(const T* __restrict__ phi
     o[3] = phi[c];
     if constexpr (sizeof(T) == 4) {
         V v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-        *reinterpret_cast<V*>(E4 + 4 * c) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<V*>(E4 + 4 * c)); // (read next by the push's staging, 2 GB later at 512^3)
     } else {
         V v0, v1; v0.x = o[0]; v0.y = o[1]; v1.x = o[2]; v1.y = o[3];
-        *reinterpret_cast<V*>(E4 + 4 * c) = v0;
-        *reinterpret_cast<V*>(E4 + 4 * c + 2) = v1;
+        __builtin_nontemporal_store(v0, reinterpret_cast<V*>(E4 + 4 * c));
+        __builtin_nontemporal_store(v1, reinterpret_cast<V*>(E4 + 4 * c + 2));
     }
 }
 
@@ -1731,10 +1731,19 @@ __global__ __launch_bounds__(256) void gradient_planes_kernel(const T* __restric
     k = held_plane(k, held, nz);
     if ((k | km | kp) < 0) return; // (a plane the caller should not have named)
     const size_t c = i + sy * j + sz * k;
-    E4[4 * c] = (phi[im + sy * j + sz * k] - phi[ip + sy * j + sz * k]) * hx;
-    E4[4 * c + 1] = (phi[i + sy * jm + sz * k] - phi[i + sy * jp + sz * k]) * hy;
-    E4[4 * c + 2] = (phi[i + sy * j + sz * km] - phi[i + sy * j + sz * kp]) * hz;
-    E4[4 * c + 3] = phi[c];
+    using V = typename NatVec16<T>::type;
+    const T o0 = (phi[im + sy * j + sz * k] - phi[ip + sy * j + sz * k]) * hx;
+    const T o1 = (phi[i + sy * jm + sz * k] - phi[i + sy * jp + sz * k]) * hy;
+    const T o2 = (phi[i + sy * j + sz * km] - phi[i + sy * j + sz * kp]) * hz;
+    const T o3 = phi[c];
+    if constexpr (sizeof(T) == 4) {
+        V v; v.x = o0; v.y = o1; v.z = o2; v.w = o3;
+        __builtin_nontemporal_store(v, reinterpret_cast<V*>(E4 + 4 * c)); // (as gradient_kernel)
+    } else {
+        V v0, v1; v0.x = o0; v0.y = o1; v1.x = o2; v1.y = o3;
+        __builtin_nontemporal_store(v0, reinterpret_cast<V*>(E4 + 4 * c));
+        __builtin_nontemporal_store(v1, reinterpret_cast<V*>(E4 + 4 * c + 2));
+    }
 }
 
 // ids of a freshly uploaded population: first + slot
