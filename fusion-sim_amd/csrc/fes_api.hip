@@ -2016,6 +2016,33 @@ int solve_distributed(Ranks& rk)
             HIP_TRY(h, hipGetLastError());
             return run_fft(h, d.p2i, d.i2i, d.hatA, static_cast<T*>(st->phi) + lp(st, d.z0) * plane, "rocfft_execute (2-D inverse)");
         })) return e;
+    // The potential's ghost planes travel (RCCL: on the communicator's stream) while the gradient of the planes that need
+    // none of them is formed: a plane's gradient reads its two neighbours, so the slab's inner nzl - 2 planes are free.
+    bool split = rk.hs[0]->es->solver != FPIC_SOLVER_YEE;
+    for (fpic_handle* h : rk.hs) split &= h->es->dom->overlap && h->es->dom->nzl >= 3;
+    auto gradient = [&](fpic_handle* h, int first, int count) -> int {
+        State* st = h->es;
+        const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+        gradient_planes_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
+            static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, first, count, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
+            static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4), held_of(st));
+        HIP_TRY(h, hipGetLastError());
+        return FPIC_OK;
+    };
+    if (split) {
+        if (int e = comm_fork(rk)) return e;
+        if (int e = exchange<T>(rk, X_PHI, /*on_comm_stream=*/true)) return e;
+        if (int e = each([&](fpic_handle* h) -> int { return gradient(h, h->es->dom->z0 + 1, h->es->dom->nzl - 2); })) return e;
+        if (int e = comm_join(rk)) return e;
+        return each([&](fpic_handle* h) -> int {
+            const Domain& d = *h->es->dom;
+            if (int e = gradient(h, d.z0 - d.G, d.G + 1)) return e;           // ghost planes below and the slab's first plane
+            if (int e = gradient(h, d.z0 + d.nzl - 1, d.G + 2)) return e;     // the slab's last plane and the ghost planes above
+            timing_end(h);
+            h->solve_launches++;
+            return FPIC_OK;
+        });
+    }
     if (int e = exchange<T>(rk, X_PHI)) return e;
     return each([&](fpic_handle* h) -> int {
         State* st = h->es;
@@ -2026,13 +2053,10 @@ int solve_distributed(Ranks& rk)
             em_edge_gradient_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
                 static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
                 static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey), ((d.z0 - d.H) % st->nz + st->nz) % st->nz, count, held_of(st));
-        } else {
-            const int count = d.nzl + 2 * d.G + 1;
-            gradient_planes_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
-                static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, d.z0 - d.G, count, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
-                static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4), held_of(st));
+            HIP_TRY(h, hipGetLastError());
+        } else if (int e = gradient(h, d.z0 - d.G, d.nzl + 2 * d.G + 1)) {
+            return e;
         }
-        HIP_TRY(h, hipGetLastError());
         timing_end(h);
         h->solve_launches++;
         return FPIC_OK;
