@@ -50,15 +50,20 @@ E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
 
 one = fp.makeCylindricalParticlePusher(spec, precision=precision)
 one.set(position=pos, velocity=vel)
-if em:
+em_from_precalc = em and case.get("precalc")
+if em and not em_from_precalc:
     one.set(edge_E=E, face_B=B)
 else:
+    if em:
+        one.addB(0.0, 0.0, 0.01)
     one.precalc()
 frames = case.get("frames", 4)
 for _ in range(frames):
     one.step()
 ref = one.getParticles()
-fields = [fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B] if em else [fp.F3_RHO_FIXED] + ([] if dist_solve else [fp.F3_E])
+# (the library's own transforms on power-of-two grids: the decomposed solve is the one handle's, bit for bit)
+own_fft = all(s_ & (s_ - 1) == 0 and s_ >= 8 for s_ in shape)
+fields = [fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B] if em else [fp.F3_RHO_FIXED] + ([] if dist_solve and not own_fft else [fp.F3_E])
 ref_f = {w: one.readField(w).reshape(shape[2], -1) for w in fields}
 
 uid = fp.commUniqueId()
@@ -70,9 +75,11 @@ def rank_main(r):
         s.domainInit(r, world, ghost_planes=G, migrate_every=every, distributed_solve=dist_solve)
         first = int(counts[:r].sum())
         s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
-        if em:
+        if em and not em_from_precalc:
             s.set(edge_E=E, face_B=B)
         else:
+            if em:
+                s.addB(0.0, 0.0, 0.01)
             s.precalc()
         for _ in range(frames):
             s.step()
@@ -130,12 +137,26 @@ def test_rccl_transport_electrostatic_replicated_solve(tmp_path, precision, worl
     assert res["migrated"] > 0 and res["lost"] == 0
 
 
-@pytest.mark.parametrize("world,shape,ghost", [(2, (16, 12, 16), 2), (4, (18, 16, 24), 2), (2, (32, 16, 64), 3)])
+@pytest.mark.parametrize("world,shape,ghost", [(2, (16, 12, 16), 2), (4, (18, 16, 24), 2), (2, (32, 16, 64), 3), (4, (16, 32, 64), 2)])
 def test_rccl_transport_slab_decomposed_solve(tmp_path, world, shape, ghost):
     res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=2, em=False, distributed_solve=True, precision="fp32", n=20000, seed=7)
     # another summation order in the solve: particles agree to rounding, so a few 14-bit weights of the integer charge grid
     # may differ by a unit; its total is exact regardless
     assert res["ids_ok"] and res["pos_err"] <= 1e-4 and res["charge_total_same"] and res["charge_max_rel_diff"] <= 1e-3, res
+    assert res["migrated"] > 0 and res["lost"] == 0
+    if all(n & (n - 1) == 0 for n in shape):
+        # power-of-two grid: the library's own transforms, slab-only arrays, the potential's ghost planes travelling beside
+        # the inner gradient — and every number the one handle's
+        assert res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape,ghost,every", [(2, (16, 16, 64), 2, 4), (4, (16, 16, 64), 1, 2)])
+def test_rccl_transport_full_em_from_a_decomposed_precalc(tmp_path, precision, world, shape, ghost, every):
+    """distributed_solve on full-EM ranks over the (stand-in) RCCL transport: the initial field from the decomposed solve,
+    slab-only arrays, then the cycle's exchanges — everything bit-identical to one handle started the same way"""
+    res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=every, em=True, distributed_solve=True, precalc=True, precision=precision, n=15000, seed=13)
+    assert res["ids_ok"] and res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
     assert res["migrated"] > 0 and res["lost"] == 0
 
 
