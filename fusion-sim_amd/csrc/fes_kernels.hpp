@@ -1181,8 +1181,9 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 // int64 current accumulators of a tile and its halo fit in LDS (11^3 nodes x 56 B = 74.5 KB float, x 88 B = 117 KB double).
 // A particle's gather is 16 ds_read_b128 (float), its current 12 ds_add_u64 when it stays in its cell (the two
 // half-segments of es3d_current are merged: their sum equals the whole segment's fluxes exactly).  Everything else — a
-// face crossing, a cell outside the window, a weight rounded up to a whole cell — is an out-of-line call with its
-// arguments BY VALUE, so that the common path keeps no state in memory.
+// face crossing, a cell outside the window, a weight rounded up to a whole cell — is an out-of-line call with the
+// particle's numbers BY VALUE (and the grid through a resident copy of the arguments), so that the common path keeps no
+// state in memory.
 constexpr int kEL = 3;                 // log2 of the EM tile edge
 constexpr int kET = 1 << kEL;
 constexpr int kEmThreads = 768;
