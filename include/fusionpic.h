@@ -329,7 +329,12 @@ int fpic_comm_set_overlap(fpic_handle* h, int enable);
 /* distributed_solve = 0: every rank gathers rho and transforms the whole grid (the N-rank run is then bit-identical to one GPU);
  * 1: the Poisson solve is decomposed too — 2-D transforms of the owned planes, an all-to-all transposition (each pair of ranks
  * exchanges nz/N * ny/N * (nx/2+1) complex values), transforms along z on ny/N rows, the transposition back, and G+1 / G+2 planes
- * of the potential from the neighbours: no rank touches the whole grid, fields agree with one GPU to rounding (needs ny % N == 0) */
+ * of the potential from the neighbours: no rank touches the whole grid, fields agree with one GPU to rounding (needs ny % N == 0).
+ * On power-of-two grids (the library's own transforms) the decomposed solve is the one handle's bit for bit, full-EM handles
+ * take it for their initial field as well, and the rank then KEEPS ONLY ITS SLAB: nz/N + 2 (ghost_planes + 2) + 1 planes of
+ * every node array instead of nz (FPIC_DOMAIN_COMPACT=0 keeps whole-grid arrays).  Call it on a fresh handle: node fields
+ * uploaded before it are dropped (upload after).  fpic_read_field3 still fills a whole-grid-shaped array: the planes the
+ * rank holds in their places, zero elsewhere; fpic_device_buffer(FPIC_BUF_RHO_FIXED) is then the held planes only. */
 int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve);
 /* the rank's initial particles (positions anywhere in its slab +- ghost planes); their global indices are first_id, first_id+1, ... */
 int fpic_domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype);
