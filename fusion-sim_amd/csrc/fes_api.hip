@@ -1827,7 +1827,7 @@ int migrate(Ranks& rk)
                 uint32_t lo = 0, hi = 0;
                 const bool faces_only = s.binned && interior_layers(st, lo, hi);
                 const uint32_t per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
-                mig_pack_kernel<T><<<blocks_for(s.n, 256 * kMigPer), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
+                mig_pack_kernel<T><<<std::min<unsigned>(blocks_for(s.n, 256 * kMigPer), 4096u), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
                                                                           static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]),
                                                                           d.mig_cap, d.counts_dev, riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty,
                                                                           faces_only ? s.tile_start2[s.wl] : nullptr, lo * per_layer, hi * per_layer);

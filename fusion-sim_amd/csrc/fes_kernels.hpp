@@ -421,6 +421,50 @@ __global__ __launch_bounds__(256) void push3_flat_kernel(Push3Args<T> a)
     if constexpr (!DEPOSIT_ONLY) store_state3(a, base, cnt, q);
 }
 
+// A workgroup's bumps of per-tile counters, gathered in a 32-entry LDS table first: the particles a migration moves sit
+// in a few tiles per workgroup and hundreds per tile, and as many global atomics on one counter serialise.  tally_add:
+// any thread, any time between tally_reset and tally_flush (both called by every thread of the workgroup).
+constexpr int kTallySlots = 32;
+struct TileTally {
+    uint32_t key[kTallySlots], val[kTallySlots];
+};
+__device__ __forceinline__ void tally_reset(TileTally& t)
+{
+    if (threadIdx.x < kTallySlots) { t.key[threadIdx.x] = ~0u; t.val[threadIdx.x] = 0; }
+    __syncthreads();
+}
+template <bool ADD>
+__device__ __forceinline__ void tally_add(TileTally& t, uint32_t key, uint32_t* __restrict__ counters)
+{
+    uint32_t h = key & (kTallySlots - 1);
+    for (int probe = 0; probe < kTallySlots; ++probe, h = (h + 1) & (kTallySlots - 1)) {
+        const uint32_t old = atomicCAS(&t.key[h], ~0u, key);
+        if (old == ~0u || old == key) { atomicAdd(&t.val[h], 1u); return; }
+    }
+    if (ADD) atomicAdd(counters + key, 1u); else atomicSub(counters + key, 1u); // (table full: straight to the counter)
+}
+template <bool ADD>
+__device__ __forceinline__ void tally_flush(TileTally& t, uint32_t* __restrict__ counters)
+{
+    __syncthreads();
+    if (threadIdx.x < kTallySlots && t.key[threadIdx.x] != ~0u && t.val[threadIdx.x]) {
+        if (ADD) atomicAdd(counters + t.key[threadIdx.x], t.val[threadIdx.x]); else atomicSub(counters + t.key[threadIdx.x], t.val[threadIdx.x]);
+    }
+}
+
+// Runs of equal keys over consecutive lanes of a wavefront (every lane of the wavefront calls this): the run's first
+// lane and its length.  A migration's records arrive almost in tile order, so that the per-tile counters they bump see one
+// atomic per run instead of one per record (hundreds of records per counter: contended atomics were most of those passes).
+__device__ __forceinline__ void wave_runs(uint32_t key, int& head_lane, int& length)
+{
+    const int lane = static_cast<int>(threadIdx.x & 63);
+    const uint32_t prev = __shfl_up(key, 1);
+    const unsigned long long heads = __ballot(lane == 0 || key != prev);
+    head_lane = 63 - __clzll(static_cast<long long>(heads & (~0ull >> (63 - lane))));
+    const unsigned long long rest = head_lane == 63 ? 0ull : heads >> (head_lane + 1);
+    length = rest ? 1 + (__ffsll(static_cast<long long>(rest)) - 1) : 64 - head_lane;
+}
+
 // The arrivals of a migration (appended behind the sorted array, in no order) inside a re-binning launch: pushed
 // against the global grid, stored in the other particle set at their bin (the tile of the position they arrived
 // with, which the migration added to the census), counted in the census of the new positions.
@@ -428,20 +472,32 @@ template <typename T, bool HAS_B>
 __global__ __launch_bounds__(256) void push3_tail_kernel(Push3Args<T> a, size_t first, size_t count)
 {
     const size_t r = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (r >= count) return;
-    const size_t s = first + r;
+    const bool active = r < count;
+    const size_t s = first + (active ? r : 0);
+    const int lane = static_cast<int>(threadIdx.x & 63);
     const GlobalGrid<T> grid{ a.E4, a.rho, a.nx, a.ny, a.nz, a.held };
     P3<T> q;
     q.x = a.slab[s]; q.y = a.slab[a.stride + s]; q.z = a.slab[2 * a.stride + s];
     q.vx = a.slab[3 * a.stride + s]; q.vy = a.slab[4 * a.stride + s]; q.vz = a.slab[5 * a.stride + s];
-    const uint32_t bin = key_of<T>(q.x, q.y, q.z, a.nx, a.ny, a.nz, a.ntx, a.nty);
-    const size_t d = static_cast<size_t>(a.dst_tile_start[bin]) + atomicAdd(a.dst_tile_cursor + bin, 1u);
-    int ni, nj, nk;
-    substep3<T, HAS_B>(q, a, grid, ni, nj, nk);
-    atomicAdd(a.tile_count + tile_key3<4, 4, 3>(ni, nj, nk, a.ntx, a.nty), 1u);
-    a.dst_slab[d] = q.x; a.dst_slab[a.stride + d] = q.y; a.dst_slab[2 * a.stride + d] = q.z;
-    a.dst_slab[3 * a.stride + d] = q.vx; a.dst_slab[4 * a.stride + d] = q.vy; a.dst_slab[5 * a.stride + d] = q.vz;
-    a.dst_id[d] = a.id[s];
+    // the arrivals come almost in tile order: a run of one tile's records takes its places with ONE returning atomic
+    const uint32_t bin = active ? key_of<T>(q.x, q.y, q.z, a.nx, a.ny, a.nz, a.ntx, a.nty) : ~0u;
+    int head, len;
+    wave_runs(bin, head, len);
+    uint32_t run_base = 0;
+    if (active && head == lane) run_base = atomicAdd(a.dst_tile_cursor + bin, static_cast<uint32_t>(len));
+    run_base = __shfl(run_base, head);
+    __shared__ TileTally tally;
+    tally_reset(tally);
+    if (active) {
+        const size_t d = static_cast<size_t>(a.dst_tile_start[bin]) + run_base + static_cast<uint32_t>(lane - head);
+        int ni, nj, nk;
+        substep3<T, HAS_B>(q, a, grid, ni, nj, nk);
+        tally_add<true>(tally, tile_key3<4, 4, 3>(ni, nj, nk, a.ntx, a.nty), a.tile_count); // (the census of the new positions)
+        a.dst_slab[d] = q.x; a.dst_slab[a.stride + d] = q.y; a.dst_slab[2 * a.stride + d] = q.z;
+        a.dst_slab[3 * a.stride + d] = q.vx; a.dst_slab[4 * a.stride + d] = q.vy; a.dst_slab[5 * a.stride + d] = q.vz;
+        a.dst_id[d] = a.id[s];
+    }
+    tally_flush<true>(tally, a.tile_count);
 }
 
 // A workgroup tracks its own tile and the 26 around it (periodic) in LDS when it counts or ranks particles
@@ -1536,54 +1592,66 @@ __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, c
     // (the leavers of a sorted array sit in the tiles along the two faces: counted in LDS first, so that the two
     // message counters see one atomic per workgroup and direction instead of one per particle)
     __shared__ unsigned l_cnt[2], l_base[2], l_lost;
-    if (threadIdx.x < 2) l_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 2) l_lost = 0;
-    __syncthreads();
-    const size_t first = static_cast<size_t>(blockIdx.x) * (256 * kMigPer);
-    uint32_t flags = 0; // two bits per particle of this lane: 1 = down, 2 = up
+    __shared__ TileTally tally;
+    // a fixed grid walks the chunks of the slots that are scanned (n - skip of them): with three quarters of a slab's
+    // slots skipped, a grid sized for n spent most of the pass launching workgroups that had nothing to do
+    const size_t live = n - skip;
+    for (size_t first = static_cast<size_t>(blockIdx.x) * (256 * kMigPer); first < live; first += static_cast<size_t>(gridDim.x) * (256 * kMigPer)) {
+        if (threadIdx.x < 2) l_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 2) l_lost = 0;
+        tally_reset(tally);
+        uint32_t flags = 0; // two bits per particle of this lane: 1 = down, 2 = up
+        T xs[kMigPer], zs[kMigPer];
 #pragma unroll
-    for (int k = 0; k < kMigPer; ++k) {
-        size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
-        if (s >= skip_from) s += skip;
-        if (s >= n) continue;
-        if (slab[s] < static_cast<T>(0)) continue;
-        int kz, w;
-        axis(slab[2 * stride + s], nz, kz, w);
-        int d = kz - z0;                    // planes above the slab's first, periodic
-        if (d < 0) d += nz;
-        if (d < nzl) continue;              // still at home
-        const int above = d - nzl, below = nz - d - 1; // cells beyond the upper / lower face
-        const bool go_up = world == 2 ? true : above <= below;
-        if ((above <= below ? above : below) >= reach) atomicAdd(&l_lost, 1u);
-        atomicAdd(&l_cnt[go_up ? 1 : 0], 1u);
-        flags |= (go_up ? 2u : 1u) << (2 * k);
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        const unsigned c = l_cnt[threadIdx.x];
-        l_base[threadIdx.x] = c ? atomicAdd(counts + threadIdx.x, c) : 0u;
-        l_cnt[threadIdx.x] = 0;
-    }
-    if (threadIdx.x == 2 && l_lost) atomicAdd(counts + 2, l_lost);
-    __syncthreads();
-    if (!flags) return;
+        for (int k = 0; k < kMigPer; ++k) { // (all loads first: one latency for the sixteen slots, not sixteen)
+            size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+            if (s >= skip_from) s += skip;
+            const bool in = s < n;
+            xs[k] = in ? slab[s] : static_cast<T>(-1);
+            zs[k] = in ? slab[2 * stride + s] : static_cast<T>(0);
+        }
 #pragma unroll
-    for (int k = 0; k < kMigPer; ++k) {
-        const unsigned dir = (flags >> (2 * k)) & 3u;
-        if (!dir) continue;
-        size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
-        if (s >= skip_from) s += skip;
-        const unsigned slot = l_base[dir - 1] + atomicAdd(&l_cnt[dir - 1], 1u);
-        if (slot >= cap) { atomicAdd(counts + 3, 1u); continue; } // stays (and is reported): no room in the message
-        MigRecord<T> r;
+        for (int k = 0; k < kMigPer; ++k) {
+            if (xs[k] < static_cast<T>(0)) continue; // (beyond the array, or the slot of a particle that has left)
+            int kz, w;
+            axis(zs[k], nz, kz, w);
+            int d = kz - z0;                    // planes above the slab's first, periodic
+            if (d < 0) d += nz;
+            if (d < nzl) continue;              // still at home
+            const int above = d - nzl, below = nz - d - 1; // cells beyond the upper / lower face
+            const bool go_up = world == 2 ? true : above <= below;
+            if ((above <= below ? above : below) >= reach) atomicAdd(&l_lost, 1u);
+            atomicAdd(&l_cnt[go_up ? 1 : 0], 1u);
+            flags |= (go_up ? 2u : 1u) << (2 * k);
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const unsigned c = l_cnt[threadIdx.x];
+            l_base[threadIdx.x] = c ? atomicAdd(counts + threadIdx.x, c) : 0u;
+            l_cnt[threadIdx.x] = 0;
+        }
+        if (threadIdx.x == 2 && l_lost) atomicAdd(counts + 2, l_lost);
+        __syncthreads();
 #pragma unroll
-        for (int f = 0; f < 6; ++f) r.v[f] = slab[f * stride + s];
-        r.id = id[s];
-        r.slot = static_cast<uint32_t>(s);
-        (dir == 2 ? up : down)[slot] = r;
-        slab[s] = static_cast<T>(-1);
-        // the census of the last push counted it in its tile: the next bin table is laid out without it
-        if (census) atomicSub(census + key_of<T>(r.v[0], r.v[1], r.v[2], nx, ny, nz, ntx, nty), 1u);
+        for (int k = 0; k < kMigPer; ++k) {
+            const unsigned dir = (flags >> (2 * k)) & 3u;
+            if (!dir) continue;
+            size_t s = first + static_cast<size_t>(k) * 256 + threadIdx.x;
+            if (s >= skip_from) s += skip;
+            const unsigned slot = l_base[dir - 1] + atomicAdd(&l_cnt[dir - 1], 1u);
+            if (slot >= cap) { atomicAdd(counts + 3, 1u); continue; } // stays (and is reported): no room in the message
+            MigRecord<T> r;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) r.v[f] = slab[f * stride + s];
+            r.id = id[s];
+            r.slot = static_cast<uint32_t>(s);
+            (dir == 2 ? up : down)[slot] = r;
+            slab[s] = static_cast<T>(-1);
+            // the census of the last push counted it in its tile: the next bin table is laid out without it
+            if (census) tally_add<false>(tally, key_of<T>(r.v[0], r.v[1], r.v[2], nx, ny, nz, ntx, nty), census);
+        }
+        if (census) tally_flush<false>(tally, census);
+        __syncthreads(); // (the counters are reset at the top of the next round)
     }
 }
 
@@ -1592,12 +1660,20 @@ __global__ __launch_bounds__(256) void mig_append_kernel(const MigRecord<T>* __r
                                                          uint32_t* __restrict__ census = nullptr, int nx = 0, int ny = 0, int nz = 0, int ntx = 0, int nty = 0)
 {
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= count) return;
-    const MigRecord<T> m = in[r];
+    const bool active = r < count;
+    MigRecord<T> m{};
+    if (active) {
+        m = in[r];
 #pragma unroll
-    for (int f = 0; f < 6; ++f) slab[f * stride + first + r] = m.v[f];
-    id[first + r] = m.id;
-    if (census) atomicAdd(census + key_of<T>(m.v[0], m.v[1], m.v[2], nx, ny, nz, ntx, nty), 1u); // ... and with the arrivals
+        for (int f = 0; f < 6; ++f) slab[f * stride + first + r] = m.v[f];
+        id[first + r] = m.id;
+    }
+    if (census) { // ... and with the arrivals: one atomic per run of records of one tile
+        const uint32_t key = active ? key_of<T>(m.v[0], m.v[1], m.v[2], nx, ny, nz, ntx, nty) : ~0u;
+        int head, len;
+        wave_runs(key, head, len);
+        if (active && head == static_cast<int>(threadIdx.x & 63)) atomicAdd(census + key, static_cast<uint32_t>(len));
+    }
 }
 
 // the two message counters counted every leaver; the messages hold at most `cap` records each (the others stayed)
