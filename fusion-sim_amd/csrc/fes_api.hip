@@ -52,6 +52,7 @@ struct Species {
     bool rebin_now = false;     // the push in flight is that re-binning (a push in two parts decides once)
     uint32_t* chunk_census = nullptr;  // 27 words per work item: the new positions of the last in-place launch by neighbour slot
     bool chunk_census_fresh = false;   // ... of the live work list and slots: the next re-binning launch need not count
+    int chunk_census_form = 0;         // ... written by a whole launch (0) or by the two parts of a rank's launch (1)
     void* em_args = nullptr;           // EmPushArgs of the last full-EM launch, resident for the kernel's out-of-line paths
 };
 
@@ -267,11 +268,17 @@ int launch_push(fpic_handle* h, Species& s, int part = 0)
             const bool rebin = s.rebin_now;
             a.part = part;
             interior_layers(st, a.layer_lo, a.layer_hi);
-            // an undecomposed handle's in-place launch leaves the per-item census the next re-binning launch starts from
-            // (a decomposition's migration changes the slots in between: it counts)
-            const bool chunkwise = !st->dom && part == 0;
-            a.chunk_census = chunkwise && (!rebin || s.chunk_census_fresh) ? s.chunk_census : nullptr;
-            s.chunk_census_fresh = chunkwise && !rebin;
+            // An in-place launch leaves the per-item census the next re-binning launch starts from.  On a rank of a
+            // decomposition a migration lies in between: it changes slots of the layers along the faces only (leavers; the
+            // arrivals sit in the tail), so those items count again and the interior's read theirs.  The census belongs
+            // to the launch form that wrote it: a two-part launch hands one straddling group of slots to another item
+            // than a whole launch does (item_groups).
+            const bool ranks = st->dom && st->dom->world > 1;
+            const int form = part == 0 ? 0 : 1;
+            a.chunk_census = !rebin || (s.chunk_census_fresh && s.chunk_census_form == form) ? s.chunk_census : nullptr;
+            a.census_interior_only = ranks ? 1 : 0;
+            if (part != 1) s.chunk_census_fresh = !rebin; // (after the last part)
+            if (!rebin) s.chunk_census_form = form;
             if (rebin && has_b) push3_tiles_kernel<T, true, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (rebin) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
             else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
@@ -1916,7 +1923,7 @@ int migrate(Ranks& rk)
                     // exchanges no longer pair up — never depends on one rank's population; later arrivals are binned by
                     // the separate passes of the next migration
                     s.n = 0;
-                    s.rebin_pending = s.census_fresh = false;
+                    s.rebin_pending = s.census_fresh = s.chunk_census_fresh = false;
                     s.binned = true;
                     s.tail_first = s.tail_count = 0;
                 }

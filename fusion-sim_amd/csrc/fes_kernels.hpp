@@ -146,8 +146,10 @@ struct Push3Args {
     unsigned long long* spilled;
     // census of the NEW positions per work item and neighbour slot (27 words per item), written by every in-place launch:
     // the re-binning launch that follows (same work list, same slots) takes its per-bin counts from it instead of
-    // counting the chunk again — one read of x, y, z less (nullptr: count, e.g. after a migration changed the slots)
+    // counting the chunk again — one read of x, y, z less (nullptr: count).  census_interior_only: a migration since then
+    // has changed slots of the layers along the slab's faces (leavers) — their items count, the interior's read
     uint32_t* chunk_census;
+    int census_interior_only;
     uint32_t* tile_count;            // census of the NEW positions per tile, zeroed by the host
     // REBIN launch: the other particle set and its bin table
     const uint32_t* id;
@@ -624,7 +626,12 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
         // Pass A: the chunk's LOADED positions per destination bin — what the launch before counted as its new positions
         // (chunk_census), or counted now — then one range per bin is reserved
         uint32_t own_count = 0;
-        if (a.chunk_census) {
+        bool counted_before = a.chunk_census != nullptr;
+        if (counted_before && a.census_interior_only) {
+            const uint32_t layer = w.tile / a.tiles_per_layer;
+            counted_before = layer >= a.layer_lo && layer < a.layer_hi;
+        }
+        if (counted_before) {
             if (threadIdx.x < kNbr3) lrank[threadIdx.x] = a.chunk_census[static_cast<size_t>(blockIdx.x) * kNbr3 + threadIdx.x];
         } else
         for (size_t g = g_begin + threadIdx.x; g < g_end; g += THREADS) {
