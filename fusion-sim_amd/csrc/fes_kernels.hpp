@@ -50,7 +50,7 @@ struct Win {
     static constexpr int N = X * Y * Z;
 };
 constexpr int kPushThreads3 = 1024;                // 16 waves per CU: 14 % faster than 512 (profiles/r02_push3_ablation.txt)
-constexpr int kChunk3 = 32768;                   // particles per workgroup and chunk
+constexpr int kChunk3 = 65536;                   // particles per workgroup and chunk
 constexpr int kMaxTiles3 = 40960;                // LDS histogram limit of the one-level binning passes: 160 KB (256^3: 8192 tiles of 16x16x8, 32768 of 8x8x8)
 constexpr int kMaxTilesStaged3 = 1 << 20;        // beyond kMaxTiles3 (512^3: 65536 / 262144 tiles): global-atomic census + the staged two-level scatter (<= 1024^2 bins)
 constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
