@@ -52,7 +52,10 @@ struct Species {
     bool rebin_now = false;     // the push in flight is that re-binning (a push in two parts decides once)
     uint32_t* chunk_census = nullptr;  // 27 words per work item: the new positions of the last in-place launch by neighbour slot
     bool chunk_census_fresh = false;   // ... of the live work list and slots: the next re-binning launch need not count
-    int chunk_census_form = 0;         // ... written by a whole launch (0) or by the two parts of a rank's launch (1)
+    int chunk_census_form = 0;         // ... written by a whole launch (0) or by the two parts of a rank's launch (1),
+                                       //     bit 1: over the joint work list of every species (State::joint_work) instead of its own
+    size_t chunk_census_items = 0;     // work items the census has room for
+    uint64_t layout = 0;               // counts the changes of the live bin table (what a joint work list is built from)
     void* em_args = nullptr;           // EmPushArgs of the last full-EM launch, resident for the kernel's out-of-line paths
 };
 
@@ -78,6 +81,13 @@ struct State {
     void *work_f = nullptr, *work_i = nullptr;
     double B0[3] = { 0, 0, 0 };
     unsigned long long* spilled = nullptr;
+    // the work list of a launch that pushes every binned species (Push3Joint): items (tile, k), rebuilt when a species'
+    // bin table has changed
+    fpic::BlockWork* joint_work = nullptr;
+    uint32_t* joint_nwork = nullptr;
+    size_t joint_cap = 0;
+    std::vector<std::pair<size_t, uint64_t>> joint_built_from; // (species, layout) of the list in joint_work
+    bool joint_now = false;            // the two parts of one sub-step's launch use the same list
     unsigned long long* spilled_host = nullptr; // pinned, 2 lagged slots
     hipEvent_t spill_event[2] = {};
     bool spill_pending[2] = {};
@@ -179,6 +189,7 @@ int alloc_species(fpic_handle* h, Species& s)
     s.work_cap = (s.cap + kChunk3 - 1) / kChunk3 + st->ntiles;
     uint64_t* acc = &h->bytes_grid;
     int rc;
+    s.chunk_census_items = s.work_cap;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&s.chunk_census), sizeof(uint32_t) * kNbr3 * s.work_cap, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_count), sizeof(uint32_t) * st->ntiles, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&s.tile_cursor), sizeof(uint32_t) * (st->ntiles + fpic::kSortMaxBins + 1), acc))) // + chunk_first of the two-level binning
@@ -231,6 +242,7 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     a.Z = s.Z;
     a.ntx = st->ntx; a.nty = st->nty; a.ntz = st->ntz;
     a.work = s.work2[s.wl]; a.nwork = s.nwork2[s.wl];
+    a.tile_start = s.tile_start2[s.wl];
     a.chunk_census = nullptr;
     a.part = 0; a.tiles_per_layer = static_cast<uint32_t>(st->ntx) * st->nty; a.layer_lo = a.layer_hi = 0;
     a.spilled = st->spilled;
@@ -243,69 +255,162 @@ Push3Args<T> push_args(fpic_handle* h, const Species& s)
     return a;
 }
 
-// part 0: the whole species in one launch.  A rank of a decomposition may push in two parts: 1 = the tile layers along
-// the slab's faces (and the arrivals of a migration), 2 = the interior; the re-binning decision, the census reset and the
-// switch of the particle sets are taken once.
-template <typename T, bool DEPOSIT_ONLY>
-int launch_push(fpic_handle* h, Species& s, int part = 0)
+// The joint work list of `set` (binned species): items (tile, k), k-th piece of kChunk3 slots of the tile in every species'
+// bin table.  Rebuilt when a member's table has changed since it was built.
+template <typename T>
+int ensure_joint_list(fpic_handle* h, const std::vector<size_t>& set)
 {
     State* st = h->es;
-    Push3Args<T> a = push_args<T>(h, s);
+    std::vector<std::pair<size_t, uint64_t>> sig;
+    size_t need = st->ntiles + 1;
+    for (size_t i : set) { sig.push_back({ i, st->sp[i].layout }); need += st->sp[i].cap / kChunk3 + 1; }
+    if (need > st->joint_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (st->joint_work) (void)hipFree(st->joint_work);
+        st->joint_work = nullptr;
+        if (int rc = dev_alloc(h, reinterpret_cast<void**>(&st->joint_work), sizeof(BlockWork) * need, &h->bytes_grid)) return rc;
+        if (!st->joint_nwork)
+            if (int rc = dev_alloc(h, reinterpret_cast<void**>(&st->joint_nwork), sizeof(uint32_t), &h->bytes_grid)) return rc;
+        st->joint_cap = need;
+        st->joint_built_from.clear();
+    }
+    for (size_t i : set) { // the per-item census of every member has room for the joint list's items
+        Species& s = st->sp[i];
+        if (s.chunk_census_items >= st->joint_cap) continue;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (s.chunk_census) (void)hipFree(s.chunk_census);
+        s.chunk_census = nullptr;
+        if (int rc = dev_alloc(h, reinterpret_cast<void**>(&s.chunk_census), sizeof(uint32_t) * kNbr3 * st->joint_cap, &h->bytes_grid)) return rc;
+        s.chunk_census_items = st->joint_cap;
+        s.chunk_census_fresh = false;
+    }
+    if (sig == st->joint_built_from) return FPIC_OK;
+    JointTables tabs{};
+    tabs.n = static_cast<int>(set.size());
+    for (size_t k = 0; k < set.size(); ++k) tabs.tile_start[k] = st->sp[set[k]].tile_start2[st->sp[set[k]].wl];
+    joint_scan_kernel<<<1, 1024, 0, h->stream>>>(tabs, st->ntiles, static_cast<uint32_t>(kChunk3), st->joint_work, st->joint_nwork);
+    HIP_TRY(h, hipGetLastError());
+    st->joint_built_from = sig;
+    return FPIC_OK;
+}
+
+// The push (or, DEPOSIT_ONLY, the deposit) of every species of the handle.  part 0: whole; a rank of a decomposition may
+// push in two parts: 1 = the tile layers along the slab's faces (and the arrivals of a migration), 2 = the interior; the
+// re-binning decision, the census reset and the switch of the particle sets are taken once.  Binned species share ONE
+// launch where they can (two or more of them, all re-binning or none): a tile's window is then staged and flushed once
+// for all of them (FPIC_PUSH_JOINT=0: one launch per species, a development switch).
+template <typename T, bool DEPOSIT_ONLY>
+int launch_push_all(fpic_handle* h, int part = 0)
+{
+    State* st = h->es;
     const bool has_b = st->B0[0] != 0 || st->B0[1] != 0 || st->B0[2] != 0;
-    if (s.n == 0) return FPIC_OK;
-    // (the full-EM mode bins by 8x8x8-cell tiles: its charge grid — a diagnostic there — takes the flat form)
-    if (s.binned && st->solver != FPIC_SOLVER_YEE) {
-        const unsigned grid = static_cast<unsigned>(s.work_cap);
-        constexpr size_t lds = push3_lds_bytes<T>();
-        if constexpr (DEPOSIT_ONLY) {
-            push3_tiles_kernel<T, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
-        } else {
+    std::vector<size_t> tiled;
+    for (size_t i = 0; i < st->sp.size(); ++i) {
+        Species& s = st->sp[i];
+        if (s.n == 0) continue;
+        // (the full-EM mode bins by 8x8x8-cell tiles: its charge grid — a diagnostic there — takes the flat form)
+        if (s.binned && st->solver != FPIC_SOLVER_YEE) { tiled.push_back(i); continue; }
+        if (part == 2) continue; // (an unbinned species is pushed whole with the first part)
+        Push3Args<T> a = push_args<T>(h, s);
+        const size_t lanes = (s.n + Vec16<T>::N - 1) / Vec16<T>::N;
+        if (has_b && !DEPOSIT_ONLY) push3_flat_kernel<T, true, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+        else push3_flat_kernel<T, false, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
+        HIP_TRY(h, hipGetLastError());
+        if (!DEPOSIT_ONLY) s.census_fresh = s.chunk_census_fresh = false;
+    }
+    if (tiled.empty()) return FPIC_OK;
+    constexpr size_t lds = push3_lds_bytes<T>();
+    // one launch for all of them?  (decided with the first part; the second part walks the same list)
+    if (part != 2) {
+        const char* v = std::getenv("FPIC_PUSH_JOINT");
+        const bool allowed = !(v && std::strcmp(v, "0") == 0);
+        bool same = true;
+        for (size_t i : tiled) same &= DEPOSIT_ONLY || st->sp[i].rebin_pending == st->sp[tiled[0]].rebin_pending;
+        st->joint_now = allowed && same && tiled.size() >= 2 && tiled.size() <= static_cast<size_t>(kJointMax);
+    }
+    const bool joint = st->joint_now && tiled.size() >= 2;
+    if (joint)
+        if (int rc = ensure_joint_list<T>(h, tiled)) return rc;
+    // per species: the state a launch starts from, and its arguments
+    std::vector<Push3Args<T>> args(tiled.size());
+    bool rebin = false;
+    for (size_t k = 0; k < tiled.size(); ++k) {
+        Species& s = st->sp[tiled[k]];
+        Push3Args<T>& a = args[k];
+        a = push_args<T>(h, s);
+        if constexpr (!DEPOSIT_ONLY) {
             if (part != 2) {
                 s.rebin_now = s.rebin_pending;
                 s.census_fresh = s.rebin_pending = false;
                 HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
             }
-            const bool rebin = s.rebin_now;
             a.part = part;
             interior_layers(st, a.layer_lo, a.layer_hi);
             // An in-place launch leaves the per-item census the next re-binning launch starts from.  On a rank of a
             // decomposition a migration lies in between: it changes slots of the layers along the faces only (leavers; the
             // arrivals sit in the tail), so those items count again and the interior's read theirs.  The census belongs
-            // to the launch form that wrote it: a two-part launch hands one straddling group of slots to another item
-            // than a whole launch does (item_groups).
+            // to the launch form that wrote it: its items are those of one work list (the species' own or the joint one),
+            // and a two-part launch hands one straddling group of slots to another item than a whole launch does
+            // (species_groups).
             const bool ranks = st->dom && st->dom->world > 1;
-            const int form = part == 0 ? 0 : 1;
-            a.chunk_census = !rebin || (s.chunk_census_fresh && s.chunk_census_form == form) ? s.chunk_census : nullptr;
+            const int form = (part == 0 ? 0 : 1) | (joint ? 2 : 0);
+            a.chunk_census = !s.rebin_now || (s.chunk_census_fresh && s.chunk_census_form == form) ? s.chunk_census : nullptr;
             a.census_interior_only = ranks ? 1 : 0;
-            if (part != 1) s.chunk_census_fresh = !rebin; // (after the last part)
-            if (!rebin) s.chunk_census_form = form;
-            if (rebin && has_b) push3_tiles_kernel<T, true, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
-            else if (rebin) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(a);
-            else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
-            else push3_tiles_kernel<T, false, false><<<grid, kPushThreads3, lds, h->stream>>>(a);
-            if (part != 2 && rebin && s.tail_count) { // the arrivals of the migration that asked for this re-binning
-                if (has_b) push3_tail_kernel<T, true><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(a, s.tail_first, s.tail_count);
-                else push3_tail_kernel<T, false><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(a, s.tail_first, s.tail_count);
+            if (part != 1) s.chunk_census_fresh = !s.rebin_now; // (after the last part)
+            if (!s.rebin_now) s.chunk_census_form = form;
+            if (k == 0) rebin = s.rebin_now;
+        }
+    }
+    // the launches: one over the joint list, or one per species over its own
+    auto launch = [&](const Push3Joint<T>& J, unsigned grid, bool re) -> int {
+        if constexpr (DEPOSIT_ONLY) {
+            push3_tiles_kernel<T, false, true><<<grid, kPushThreads3, lds, h->stream>>>(J);
+        } else {
+            if (re && has_b) push3_tiles_kernel<T, true, false, true><<<grid, kPushThreads3, lds, h->stream>>>(J);
+            else if (re) push3_tiles_kernel<T, false, false, true><<<grid, kPushThreads3, lds, h->stream>>>(J);
+            else if (has_b) push3_tiles_kernel<T, true, false><<<grid, kPushThreads3, lds, h->stream>>>(J);
+            else push3_tiles_kernel<T, false, false><<<grid, kPushThreads3, lds, h->stream>>>(J);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return FPIC_OK;
+    };
+    if (joint) {
+        Push3Joint<T> J{};
+        J.nsp = static_cast<int>(tiled.size());
+        for (size_t k = 0; k < tiled.size(); ++k) J.sp[k] = args[k];
+        J.work = st->joint_work; J.nwork = st->joint_nwork; J.chunk = static_cast<uint32_t>(kChunk3);
+        if (int rc = launch(J, static_cast<unsigned>(st->joint_cap), rebin)) return rc;
+    } else {
+        for (size_t k = 0; k < tiled.size(); ++k) {
+            Species& s = st->sp[tiled[k]];
+            Push3Joint<T> J{};
+            J.nsp = 1; J.sp[0] = args[k];
+            J.work = args[k].work; J.nwork = args[k].nwork; J.chunk = 0;
+            if (int rc = launch(J, static_cast<unsigned>(s.work_cap), DEPOSIT_ONLY ? false : s.rebin_now)) return rc;
+        }
+    }
+    if constexpr (!DEPOSIT_ONLY) {
+        for (size_t k = 0; k < tiled.size(); ++k) {
+            Species& s = st->sp[tiled[k]];
+            const bool re = s.rebin_now;
+            if (part != 2 && re && s.tail_count) { // the arrivals of the migration that asked for this re-binning
+                if (has_b) push3_tail_kernel<T, true><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(args[k], s.tail_first, s.tail_count);
+                else push3_tail_kernel<T, false><<<blocks_for(s.tail_count), 256, 0, h->stream>>>(args[k], s.tail_first, s.tail_count);
+                HIP_TRY(h, hipGetLastError());
             }
-            HIP_TRY(h, hipGetLastError());
             if (part != 1) {
                 s.census_fresh = true;
-                if (rebin) { // this launch was the binning: the other set and the other tables are live now
+                if (re) { // this launch was the binning: the other set and the other tables are live now
                     s.cur ^= 1;
                     s.wl ^= 1;
+                    s.layout++;
                     if (s.n_after) s.n = s.n_after;
                     s.tail_first = s.tail_count = s.n_after = 0;
                 }
                 s.rebin_now = false;
             }
         }
-    } else if (part != 2) { // (an unbinned species is pushed whole with the first part)
-        const size_t lanes = (s.n + Vec16<T>::N - 1) / Vec16<T>::N;
-        if (has_b && !DEPOSIT_ONLY) push3_flat_kernel<T, true, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
-        else push3_flat_kernel<T, false, DEPOSIT_ONLY><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
-        if (!DEPOSIT_ONLY) s.census_fresh = s.chunk_census_fresh = false;
     }
-    HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
 
@@ -374,6 +479,7 @@ int launch_bin(fpic_handle* h, Species& s)
     HIP_TRY(h, hipGetLastError());
     if (!two_level) s.cur ^= 1;
     s.wl = nw;
+    s.layout++;
     s.binned = true;
     s.ids_identity = false;
     s.census_fresh = s.rebin_pending = s.chunk_census_fresh = false; // tile_count now describes this binning, not a push
@@ -609,9 +715,7 @@ int deposit_cycle(fpic_handle* h, int part = 0)
         }
         HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
     }
-    int rc = FPIC_OK;
-    for (Species& s : st->sp)
-        if ((rc = launch_push<T, DEPOSIT_ONLY>(h, s, part))) break;
+    const int rc = launch_push_all<T, DEPOSIT_ONLY>(h, part);
     if (part != 1) timing_end(h);
     return rc;
 }
@@ -1120,7 +1224,8 @@ void release(fpic_handle* h)
     for (void* p : { st->Ey, st->By, st->B4n, static_cast<void*>(st->Jfix), st->fft_tw[0], st->fft_tw[1], st->fft_tw[2] })
         if (p) (void)hipFree(p);
     for (void* p : { static_cast<void*>(st->rho_fixed), st->rho, st->hat, st->phi, st->E4, static_cast<void*>(st->k2[0]), static_cast<void*>(st->k2[1]),
-                     static_cast<void*>(st->k2[2]), st->work_f, st->work_i, static_cast<void*>(st->spilled) })
+                     static_cast<void*>(st->k2[2]), st->work_f, st->work_i, static_cast<void*>(st->spilled), static_cast<void*>(st->joint_work),
+                     static_cast<void*>(st->joint_nwork) })
         if (p) (void)hipFree(p);
     if (st->spilled_host) (void)hipHostFree(st->spilled_host);
     for (hipEvent_t e : st->spill_event) if (e) (void)hipEventDestroy(e);

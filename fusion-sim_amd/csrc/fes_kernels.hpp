@@ -150,6 +150,7 @@ struct Push3Args {
     // has changed slots of the layers along the slab's faces (leavers) — their items count, the interior's read
     uint32_t* chunk_census;
     int census_interior_only;
+    const uint32_t* tile_start;      // the live bin table: slots [tile_start[t], tile_start[t + 1]) hold tile t
     uint32_t* tile_count;            // census of the NEW positions per tile, zeroed by the host
     // REBIN launch: the other particle set and its bin table
     const uint32_t* id;
@@ -558,6 +559,84 @@ __device__ __forceinline__ void item_groups(const BlockWork* __restrict__ work, 
     if (part == 1 && b > 0 && in_part(work[b - 1].tile, 2, tiles_per_layer, layer_lo, layer_hi)) g_begin = w.begin / ppt;
 }
 
+// One launch pushes every species of a handle: a workgroup stages its tile's window once, takes the tile's particles of
+// each species in turn — all of them deposit into the one accumulator window — and flushes once.  At 512^3 / 2e9 (15 000
+// particles per tile and species) the windows of two launches were 12 + 6 GB per sub-step beside 96 GB of particles.
+// A joint work item is (tile, k): the k-th piece of `chunk` slots of the tile in every species' bin table; chunk == 0: one
+// species with its own list of items (tile, begin, end).
+constexpr int kJointMax = 4;
+template <typename T>
+struct Push3Joint {
+    Push3Args<T> sp[kJointMax];   // (the grid, the decomposition and the launch constants are the same in all of them)
+    int nsp;
+    const BlockWork* work;
+    const uint32_t* nwork;
+    uint32_t chunk;
+};
+
+// the joint work list from the species' bin tables: tile t contributes max over the species of ceil(n_s(t) / chunk) items
+// (tile, k), in tile order.  One workgroup of 1024 threads (the tables have at most 2^20 tiles).
+struct JointTables {
+    const uint32_t* tile_start[kJointMax];
+    int n;
+};
+__global__ __launch_bounds__(1024) void joint_scan_kernel(JointTables tabs, uint32_t ntiles, uint32_t chunk, BlockWork* __restrict__ work, uint32_t* __restrict__ nwork)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (ntiles + 1023u) / 1024u;
+    const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    auto items_of = [&](uint32_t t) {
+        uint32_t m = 0;
+        for (int s = 0; s < tabs.n; ++s) {
+            const uint32_t c = tabs.tile_start[s][t + 1] - tabs.tile_start[s][t];
+            const uint32_t k = (c + chunk - 1) / chunk;
+            m = k > m ? k : m;
+        }
+        return m;
+    };
+    uint32_t mine = 0;
+    for (uint32_t t = t0; t < t1; ++t) mine += items_of(t);
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { // inclusive scan
+        const uint32_t v = threadIdx.x >= static_cast<unsigned>(d) ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t at = part[threadIdx.x] - mine;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t m = items_of(t);
+        for (uint32_t k = 0; k < m; ++k) work[at++] = BlockWork{ t, k, 0u, 0u };
+    }
+    if (threadIdx.x == 1023) *nwork = part[1023];
+}
+
+// The slots of a work item in one species, in groups of PPT: a group that straddles two items belongs to the earlier one
+// (begin rounds up, end rounds up).  In a two-part launch the group that holds the first slot of the layer along the
+// upper face — B = tile_start[layer_hi * tiles_per_layer] — holds particles of that face layer, which may deposit on
+// planes that are exchanged before the interior is pushed: the interior never takes it (part 2), the item that begins at B
+// does (part 1).
+template <typename T>
+__device__ __forceinline__ void species_groups(const Push3Joint<T>& j, const Push3Args<T>& a, const BlockWork& w, int ppt, size_t& g_begin, size_t& g_end)
+{
+    uint32_t b0 = w.begin, b1 = w.end;
+    if (j.chunk) {
+        const uint32_t t0 = a.tile_start[w.tile], t1 = a.tile_start[w.tile + 1];
+        const unsigned long long lo = static_cast<unsigned long long>(t0) + static_cast<unsigned long long>(w.begin) * j.chunk;
+        b0 = lo < t1 ? static_cast<uint32_t>(lo) : t1;
+        b1 = t1 - b0 > j.chunk ? b0 + j.chunk : t1;
+    }
+    g_begin = (static_cast<size_t>(b0) + ppt - 1) / ppt;
+    g_end = (static_cast<size_t>(b1) + ppt - 1) / ppt;
+    if (a.part != 0) {
+        const uint32_t B = a.tile_start[a.layer_hi * a.tiles_per_layer];
+        if (a.part == 2) { if (g_end > B / ppt) g_end = B / ppt; }
+        else if (b0 == B && b1 > b0) g_begin = B / ppt;
+    }
+}
+
+
 template <typename T>
 constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 * sizeof(T) + 8) + 3 * kNbr3 * sizeof(uint32_t) + 16; }
 
@@ -573,7 +652,7 @@ constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 
 // ABL: development probe bits, timing only (scripts/ablate_push3.hip): 1 = no LDS accumulation, 2 = no field
 // gather, 4 = no window staging / flush.  The library instantiates ABL = 0 only.
 template <typename T, bool HAS_B, bool DEPOSIT_ONLY, bool REBIN = false, int THREADS = kPushThreads3, int ABL = 0>
-__global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
+__global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
 {
     static_assert(!(REBIN && DEPOSIT_ONLY), "precalc() never re-bins");
     constexpr int PPT = Vec16<T>::N;
@@ -584,27 +663,28 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     FPIC_LDS uint32_t* lcensus = (FPIC_LDS uint32_t*)(lrho + kWN);
     FPIC_LDS uint32_t* lrank = lcensus + kNbr3;
     FPIC_LDS uint32_t* lrange = lrank + kNbr3;
-    if (blockIdx.x >= *a.nwork) return;
-    const BlockWork w = a.work[blockIdx.x];
-    if (!in_part(w.tile, a.part, a.tiles_per_layer, a.layer_lo, a.layer_hi)) return;
-    const int ti = static_cast<int>(w.tile % a.ntx), tj = static_cast<int>((w.tile / a.ntx) % a.nty), tk = static_cast<int>(w.tile / (a.ntx * a.nty));
+    const Push3Args<T>& c0 = J.sp[0]; // (what is the same for every species is read from the first)
+    if (blockIdx.x >= *J.nwork) return;
+    const BlockWork w = J.work[blockIdx.x];
+    if (!in_part(w.tile, c0.part, c0.tiles_per_layer, c0.layer_lo, c0.layer_hi)) return;
+    const int ti = static_cast<int>(w.tile % c0.ntx), tj = static_cast<int>((w.tile / c0.ntx) % c0.nty), tk = static_cast<int>(w.tile / (c0.ntx * c0.nty));
     const int ox = ti * kTX - kHalo, oy = tj * kTY - kHalo, oz = tk * kTZ - kHalo;
-    const Neighbourhood3 nb{ ti, tj, tk, a.ntx, a.nty, a.ntz };
+    const Neighbourhood3 nb{ ti, tj, tk, c0.ntx, c0.nty, c0.ntz };
     // stage the window: one node record (16 B float / 32 B double) per lane and iteration
     using V = typename NatVec16<T>::type;
     constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
     for (int s = threadIdx.x; s < ((ABL & 4) ? 0 : kWN); s += THREADS) {
         const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
         const int m = rem / kWX, l = rem - m * kWX;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - a.held.zs0 + n) % a.nz; // gk: among the planes held
-        if (gi < 0) gi += a.nx;
-        if (gj < 0) gj += a.ny;
-        if (gk < 0) gk += a.nz;
+        int gi = (ox + l) % c0.nx, gj = (oy + m) % c0.ny, gk = (oz - c0.held.zs0 + n) % c0.nz; // gk: among the planes held
+        if (gi < 0) gi += c0.nx;
+        if (gj < 0) gj += c0.ny;
+        if (gk < 0) gk += c0.nz;
         lrho[s] = 0ull;
         if constexpr (!DEPOSIT_ONLY) {
-            const int lk = gk < a.held.nzs ? gk : -1;
+            const int lk = gk < c0.held.nzs ? gk : -1;
             if (lk >= 0) {
-                const T* src = a.E4 + 4 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * lk));
+                const T* src = c0.E4 + 4 * (static_cast<size_t>(gi) + static_cast<size_t>(c0.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(c0.ny) * lk));
 #pragma unroll
                 for (int p = 0; p < PIECES; ++p)
                     *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(src + p * Vec16<T>::N);
@@ -617,10 +697,12 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     if (threadIdx.x < 3 * kNbr3) lcensus[threadIdx.x] = 0;
     __syncthreads();
     unsigned my_spill = 0;
+    const WindowGrid<T, ABL> grid{ GlobalGrid<T>{ c0.E4, c0.rho, c0.nx, c0.ny, c0.nz, c0.held }, lE, lrho, ox, oy, oz, &my_spill };
+    for (int sp = 0; sp < J.nsp; ++sp) {
+    const Push3Args<T>& a = J.sp[sp];
     uint32_t census_own = 0;
-    const WindowGrid<T, ABL> grid{ GlobalGrid<T>{ a.E4, a.rho, a.nx, a.ny, a.nz, a.held }, lE, lrho, ox, oy, oz, &my_spill };
     size_t g_begin, g_end;
-    item_groups(a.work, blockIdx.x, *a.nwork, w, PPT, a.part, a.tiles_per_layer, a.layer_lo, a.layer_hi, g_begin, g_end);
+    species_groups(J, a, w, PPT, g_begin, g_end);
 
     if constexpr (REBIN) {
         // Pass A: the chunk's LOADED positions per destination bin — what the launch before counted as its new positions
@@ -742,18 +824,6 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
     }
     if (census_own) __hip_atomic_fetch_add(lcensus, census_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    // flush the non-zero accumulators: consecutive lanes take consecutive slots of one window row
-    for (int s = threadIdx.x; s < ((ABL & 4) ? 0 : kWN); s += THREADS) {
-        const unsigned long long v = lrho[s];
-        if (v == 0ull) continue;
-        const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
-        const int m = rem / kWX, l = rem - m * kWX;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - a.held.zs0 + n) % a.nz;
-        if (gi < 0) gi += a.nx;
-        if (gj < 0) gj += a.ny;
-        if (gk < 0) gk += a.nz;
-        if (gk < a.held.nzs) atomicAdd(a.rho + (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)), v);
-    }
     if constexpr (!DEPOSIT_ONLY) {
         if (threadIdx.x < kNbr3) {
             const uint32_t c = lcensus[threadIdx.x];
@@ -764,7 +834,25 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Args<T> a)
             }
         }
     }
-    if (my_spill) atomicAdd(a.spilled, static_cast<unsigned long long>(my_spill));
+    if (sp + 1 < J.nsp) { // the next species counts from zero
+        __syncthreads();
+        if (threadIdx.x < 3 * kNbr3) lcensus[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    } // species
+    // flush the non-zero accumulators: consecutive lanes take consecutive slots of one window row
+    for (int s = threadIdx.x; s < ((ABL & 4) ? 0 : kWN); s += THREADS) {
+        const unsigned long long v = lrho[s];
+        if (v == 0ull) continue;
+        const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
+        const int m = rem / kWX, l = rem - m * kWX;
+        int gi = (ox + l) % c0.nx, gj = (oy + m) % c0.ny, gk = (oz - c0.held.zs0 + n) % c0.nz;
+        if (gi < 0) gi += c0.nx;
+        if (gj < 0) gj += c0.ny;
+        if (gk < 0) gk += c0.nz;
+        if (gk < c0.held.nzs) atomicAdd(c0.rho + (static_cast<size_t>(gi) + static_cast<size_t>(c0.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(c0.ny) * gk)), v);
+    }
+    if (my_spill) atomicAdd(c0.spilled, static_cast<unsigned long long>(my_spill));
 }
 
 // ------------------------------------------------------------------ field solve

@@ -33,13 +33,15 @@ __global__ void fillwork(BlockWork* w, uint32_t* nwork, int ntiles, int per_tile
 }
 
 template <int THREADS, int ABL>
-float run(Push3Args<float> a, unsigned grid, int reps) {
+float run(Push3Args<float> one, unsigned grid, int reps) {
     const size_t lds = push3_lds_bytes<float>();
+    Push3Joint<float> a{};   // (one species with its own work list: chunk = 0)
+    a.nsp = 1; a.sp[0] = one; a.work = one.work; a.nwork = one.nwork; a.chunk = 0;
     CK(hipFuncSetAttribute((const void*)push3_tiles_kernel<float, false, false, false, THREADS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     push3_tiles_kernel<float, false, false, false, THREADS, ABL><<<grid, THREADS, lds>>>(a); CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; ++r) { CK(hipMemsetAsync(a.rho, 0, (size_t)a.nx * a.ny * a.nz * 8)); push3_tiles_kernel<float, false, false, false, THREADS, ABL><<<grid, THREADS, lds>>>(a); }
+    for (int r = 0; r < reps; ++r) { CK(hipMemsetAsync(one.rho, 0, (size_t)one.nx * one.ny * one.nz * 8)); push3_tiles_kernel<float, false, false, false, THREADS, ABL><<<grid, THREADS, lds>>>(a); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / reps;
 }

@@ -536,6 +536,49 @@ def test_slab_only_arrays_change_nothing(fp, monkeypatch, precision, world, shap
     assert all(w - c == saved for w, c in zip(whole["grid_bytes"], slab["grid_bytes"]))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("shape,counts,with_b", [((32, 32, 16), (60000, 60000), False), ((48, 32, 24), (90001, 2500, 40000), True),
+                                                 ((16, 16, 8), (70000, 9), False)])
+def test_species_sharing_a_launch(fp, monkeypatch, precision, shape, counts, with_b):
+    """Binned species are pushed by ONE launch (a tile's window staged and flushed once for all of them, Push3Joint): over
+    re-binnings, with populations of very different sizes (tiles that are empty in one species, tiles of several work items
+    in another), every particle and the integer charge grid are those of one launch per species (FPIC_PUSH_JOINT=0), whose
+    parity with the oracle the tests above hold."""
+    rng = np.random.default_rng(len(counts) * 100 + shape[0])
+    L = tuple(1e-3 * s for s in shape)
+    spec = box_spec(shape, L, count=counts[0], dt=2e-12, macro_weight=1e12 * np.prod(L) / counts[0])
+    masses = [ME, MP, 4 * MP][:len(counts)]
+    charges = [QE, -QE, -2 * QE][:len(counts)]
+    state = [(rng.random((n, 3)) * L, rng.normal(0, 0.02, (n, 3))) for n in counts]
+    state[1][0][:, 2] = rng.random(len(state[1][0])) * L[2] * 0.3          # the second species fills a third of the box: empty tiles
+
+    def run(joint):
+        if joint:
+            monkeypatch.delenv("FPIC_PUSH_JOINT", raising=False)
+        else:
+            monkeypatch.setenv("FPIC_PUSH_JOINT", "0")
+        sim = fp.makeCylindricalParticlePusher(dict(spec, sort_interval=3), precision=precision)
+        for sp in range(1, len(counts)):
+            sim.addSpecies(masses[sp], charges[sp], counts[sp])
+        for sp, (p, v) in enumerate(state):
+            sim.set(position=p, velocity=v, species=sp)
+        if with_b:
+            sim.addB(0.0, 0.02, 0.05)
+        sim.precalc()
+        out = []
+        for _ in range(4):
+            sim.step()
+            out.append(([sim.getParticles(species=sp) for sp in range(len(counts))], sim.readField(fp.F3_RHO_FIXED)))
+        sim.destroy()
+        return out
+
+    together, apart = run(True), run(False)
+    for frame, ((pa, ra), (pb, rb)) in enumerate(zip(together, apart)):
+        assert np.array_equal(ra, rb), frame
+        for sp in range(len(counts)):
+            assert same_bits(pa[sp]["position"], pb[sp]["position"]) and same_bits(pa[sp]["velocity"], pb[sp]["velocity"]), (frame, sp)
+
+
 # ---------------------------------------------------------------------------- LDS-staged (two-level) first binning
 # Populations of 2^20 particles and more are binned by sort_scatter_kernel; FPIC_TWO_LEVEL_MIN (read when the handle is
 # created) lowers that size so that the small oracle-checked scenes above run through the same kernels: ragged last
