@@ -640,7 +640,8 @@ __device__ __forceinline__ void species_groups(const Push3Joint<T>& j, const Pus
 template <typename T>
 constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 * sizeof(T) + 8) + 3 * kNbr3 * sizeof(uint32_t) + 16; }
 
-// Tiled form for binned particles: one workgroup per chunk of one tile's particles.
+// Tiled form for binned particles: one workgroup per work item — a piece of one tile's particles, of every species of
+// the launch in turn (Push3Joint): the window is staged once, every species adds into it, it is flushed once.
 //
 // Every launch also counts the NEW positions per tile (census): the table the next re-binning is
 // laid out from.  REBIN makes this launch the re-binning as well: the bin of a particle is the tile
