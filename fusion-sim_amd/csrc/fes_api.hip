@@ -747,9 +747,13 @@ int substep(fpic_handle* h)
         if (int rc = bin_all<T>(h, false)) return rc;
     if (int rc = deposit_cycle<T, false>(h)) return rc;
     const int slot = static_cast<int>(st->spill_seq++ & 1);
-    HIP_TRY(h, hipMemcpyAsync(st->spilled_host + slot, st->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipEventRecord(st->spill_event[slot], h->stream));
-    st->spill_pending[slot] = true;
+    // (a re-binning launch still works in the OLD tiles' windows: its count of deposits outside them is the reason it was
+    // asked for, not a reading of the new order — taken as one, it asked for a second re-binning two sub-steps later)
+    if (!rebin) {
+        HIP_TRY(h, hipMemcpyAsync(st->spilled_host + slot, st->spilled, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipEventRecord(st->spill_event[slot], h->stream));
+        st->spill_pending[slot] = true;
+    }
     st->substeps_since_bin++;
     h->step_launches++;
     h->particle_updates += total_particles(st);
