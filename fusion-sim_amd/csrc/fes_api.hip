@@ -805,6 +805,7 @@ int em_push_all(fpic_handle* h, int part = 0)
             t.part = part; t.tiles_per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
             interior_layers(st, t.layer_lo, t.layer_hi);
             t.spilled = st->spilled;
+            t.tile_start = s.tile_start2[s.wl];
             if (part != 2) { // (the second part of a split push follows the first on this stream with the same grid)
                 if (!s.em_args)
                     if (int rc = dev_alloc(h, &s.em_args, sizeof(EmPushArgs<double>), &h->bytes_grid)) return rc;

@@ -1,0 +1,46 @@
+// fes_groups.hpp — which slots of a species' tile-ordered particle array a work item of the tiled CART3D push takes, and in
+// which groups of PPT slots.  Plain integer rules, shared by the kernels (fes_kernels.hpp) and a host test
+// (tests/native/groups_test.cpp, g++): the one bug of round 3 that cost days was a group of four slots pushed by the
+// wrong part of a two-part launch.
+#ifndef FES_GROUPS_HPP
+#define FES_GROUPS_HPP
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define FESGRP_HD __host__ __device__ __forceinline__
+#else
+#define FESGRP_HD inline
+#endif
+
+namespace fesgrp {
+
+// items a tile contributes to a joint work list: the most pieces of `chunk` slots any species needs for it
+FESGRP_HD uint32_t pieces_of(uint32_t count, uint32_t chunk) { return (count + chunk - 1) / chunk; }
+
+// piece k of a tile whose slots are [t0, t1): [b0, b1), empty (b0 == b1 == t1) when the species has fewer pieces
+FESGRP_HD void piece(uint32_t t0, uint32_t t1, uint32_t k, uint32_t chunk, uint32_t& b0, uint32_t& b1)
+{
+    const unsigned long long lo = static_cast<unsigned long long>(t0) + static_cast<unsigned long long>(k) * chunk;
+    b0 = lo < t1 ? static_cast<uint32_t>(lo) : t1;
+    b1 = t1 - b0 > chunk ? b0 + chunk : t1;
+}
+
+// The slots [b0, b1) of a work item in groups of ppt: groups [g_begin, g_end).  A group that straddles two items belongs
+// to the earlier one (begin rounds up, end rounds up).  In a two-part launch (part 1: the tile layers along the slab's
+// faces, part 2: the interior, whose slots are [A, B): B = the first slot of the layer along the upper face) the group
+// that holds slot B holds particles of that face layer, which may deposit on planes that are exchanged before the
+// interior is pushed: the interior gives it up (part 2) and the item that begins at B takes it (part 1) — when there is
+// such an item (B < n: the species has particles at or beyond the upper face) and when the group's first slot is the
+// interior's (>= A; with fewer interior slots than that the group begins in the lower face, whose item part 1 runs anyway).
+// part 0: one launch, no exception.  n: the slots of the array.
+FESGRP_HD void groups(uint32_t b0, uint32_t b1, int ppt, int part, uint32_t A, uint32_t B, uint32_t n, size_t& g_begin, size_t& g_end)
+{
+    g_begin = (static_cast<size_t>(b0) + ppt - 1) / ppt;
+    g_end = (static_cast<size_t>(b1) + ppt - 1) / ppt;
+    if (part == 2) { if (B < n && g_end > B / ppt) g_end = B / ppt; }
+    else if (part == 1 && b0 == B && b1 > b0 && static_cast<size_t>(B / ppt) * ppt >= A) g_begin = B / ppt;
+}
+
+} // namespace fesgrp
+#endif

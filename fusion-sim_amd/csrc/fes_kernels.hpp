@@ -25,6 +25,7 @@
 // once and written once per sub-step (48 B fp32 / 96 B fp64 per update).
 #pragma once
 
+#include "fes_groups.hpp"
 #include "fpic_kernels.hpp"
 
 namespace fes {
@@ -545,19 +546,6 @@ __device__ __forceinline__ bool in_part(uint32_t tile, int part, uint32_t tiles_
     return (part == 2) == interior;
 }
 
-// The particles of a work item are taken in groups of PPT slots; a group that straddles two items belongs to the earlier
-// one (begin rounds up, end rounds up).  In a two-part launch the group between the LAST interior item and the first item
-// of the layer along the upper face holds particles of that face layer — they may deposit on planes that are exchanged
-// before the interior is pushed — so there, and only there, it goes with the later item: the interior item gives it up,
-// the face item takes it.
-__device__ __forceinline__ void item_groups(const BlockWork* __restrict__ work, uint32_t b, uint32_t nwork, const BlockWork& w, int ppt, int part, uint32_t tiles_per_layer,
-                                            uint32_t layer_lo, uint32_t layer_hi, size_t& g_begin, size_t& g_end)
-{
-    g_begin = (static_cast<size_t>(w.begin) + ppt - 1) / ppt;
-    g_end = (static_cast<size_t>(w.end) + ppt - 1) / ppt;
-    if (part == 2 && b + 1 < nwork && !in_part(work[b + 1].tile, 2, tiles_per_layer, layer_lo, layer_hi)) g_end = w.end / ppt;
-    if (part == 1 && b > 0 && in_part(work[b - 1].tile, 2, tiles_per_layer, layer_lo, layer_hi)) g_begin = w.begin / ppt;
-}
 
 // One launch pushes every species of a handle: a workgroup stages its tile's window once, takes the tile's particles of
 // each species in turn — all of them deposit into the one accumulator window — and flushes once.  At 512^3 / 2e9 (15 000
@@ -588,8 +576,7 @@ __global__ __launch_bounds__(1024) void joint_scan_kernel(JointTables tabs, uint
     auto items_of = [&](uint32_t t) {
         uint32_t m = 0;
         for (int s = 0; s < tabs.n; ++s) {
-            const uint32_t c = tabs.tile_start[s][t + 1] - tabs.tile_start[s][t];
-            const uint32_t k = (c + chunk - 1) / chunk;
+            const uint32_t k = fesgrp::pieces_of(tabs.tile_start[s][t + 1] - tabs.tile_start[s][t], chunk);
             m = k > m ? k : m;
         }
         return m;
@@ -621,19 +608,9 @@ template <typename T>
 __device__ __forceinline__ void species_groups(const Push3Joint<T>& j, const Push3Args<T>& a, const BlockWork& w, int ppt, size_t& g_begin, size_t& g_end)
 {
     uint32_t b0 = w.begin, b1 = w.end;
-    if (j.chunk) {
-        const uint32_t t0 = a.tile_start[w.tile], t1 = a.tile_start[w.tile + 1];
-        const unsigned long long lo = static_cast<unsigned long long>(t0) + static_cast<unsigned long long>(w.begin) * j.chunk;
-        b0 = lo < t1 ? static_cast<uint32_t>(lo) : t1;
-        b1 = t1 - b0 > j.chunk ? b0 + j.chunk : t1;
-    }
-    g_begin = (static_cast<size_t>(b0) + ppt - 1) / ppt;
-    g_end = (static_cast<size_t>(b1) + ppt - 1) / ppt;
-    if (a.part != 0) {
-        const uint32_t B = a.tile_start[a.layer_hi * a.tiles_per_layer];
-        if (a.part == 2) { if (g_end > B / ppt) g_end = B / ppt; }
-        else if (b0 == B && b1 > b0) g_begin = B / ppt;
-    }
+    if (j.chunk) fesgrp::piece(a.tile_start[w.tile], a.tile_start[w.tile + 1], w.begin, j.chunk, b0, b1);
+    const uint32_t A = a.part != 0 ? a.tile_start[a.layer_lo * a.tiles_per_layer] : 0u, B = a.part != 0 ? a.tile_start[a.layer_hi * a.tiles_per_layer] : 0u;
+    fesgrp::groups(b0, b1, ppt, a.part, A, B, a.tile_start[a.ntx * a.nty * a.ntz], g_begin, g_end);
 }
 
 
@@ -1359,6 +1336,7 @@ struct EmTileArgs {
     int part;                // see Push3Args
     uint32_t tiles_per_layer, layer_lo, layer_hi;
     unsigned long long* spilled;
+    const uint32_t* tile_start;    // the live bin table (the slots of the interior layers: fes_groups.hpp)
     const EmPushArgs<T>* resident; // a copy of p in device memory: what the out-of-line rare paths read their grid from
 };
 
@@ -1535,7 +1513,10 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     __syncthreads();
     unsigned my_spill = 0;
     size_t g_begin, g_end;
-    item_groups(t.work, blockIdx.x, *t.nwork, w, PPT, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi, g_begin, g_end);
+    {
+        const uint32_t A = t.part != 0 ? t.tile_start[t.layer_lo * t.tiles_per_layer] : 0u, B = t.part != 0 ? t.tile_start[t.layer_hi * t.tiles_per_layer] : 0u;
+        fesgrp::groups(w.begin, w.end, PPT, t.part, A, B, t.tile_start[t.ntx * t.nty * t.ntz], g_begin, g_end);
+    }
     for (size_t g = g_begin + threadIdx.x; g < g_end; g += kEmThreads) {
         const size_t base = g * PPT;
         const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
