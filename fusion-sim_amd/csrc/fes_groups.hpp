@@ -1,7 +1,8 @@
-// fes_groups.hpp — which slots of a species' tile-ordered particle array a work item of the tiled CART3D push takes, and in
-// which groups of PPT slots.  Plain integer rules, shared by the kernels (fes_kernels.hpp) and a host test
-// (tests/native/groups_test.cpp, g++): the one bug of round 3 that cost days was a group of four slots pushed by the
-// wrong part of a two-part launch.
+// fes_groups.hpp — the integer rules of the tiled pushes that are easy to get wrong at an edge: which slots of a species'
+// tile-ordered particle array a work item takes and in which groups of PPT slots, the place of a plane in a rank's
+// slab-only arrays, the periodic distance inside a tile's window.  Plain functions shared by the kernels
+// (fes_kernels.hpp) and a host test (tests/native/groups_test.cpp, g++): the one bug of round 3 that cost days was a group
+// of four slots pushed by the wrong part of a two-part launch.
 #ifndef FES_GROUPS_HPP
 #define FES_GROUPS_HPP
 #include <cstddef>
@@ -43,4 +44,32 @@ FESGRP_HD void groups(uint32_t b0, uint32_t b1, int ppt, int part, uint32_t A, u
 }
 
 } // namespace fesgrp
+
+namespace fes {
+
+// The node arrays of a handle hold the planes zs0, zs0 + 1, ..., zs0 + nzs - 1 along z (periodic in nz): all of them
+// (zs0 = 0, nzs = nz) for an undecomposed handle or a rank that keeps global arrays; its slab with the ghost / halo planes
+// for a rank of a COMPACT decomposition (fes_api.hip, keep_slab_only), whose arrays have nzs planes only.  Kernels take the
+// global plane index of a node through held_plane(): the plane's place in the array, or -1 for a plane the handle does not
+// hold (what a particle that has outrun the ghost planes would touch there is dropped: it was never read either).
+struct Held {
+    int zs0, nzs; // 0 <= zs0 < nz
+};
+FESGRP_HD int held_plane(int k, Held hd, int nz)
+{
+    int l = k - hd.zs0;
+    if (l < 0) l += nz;
+    return l < hd.nzs ? l : -1;
+}
+
+// d mod n for -n < d < 2 n, as an unsigned number: whichever of d, d + n, d - n lies in [0, n) is the smallest of the
+// three taken as unsigned (one v_min3_u32 instead of two compare-and-select pairs)
+FESGRP_HD unsigned wrap_near(int d, int n)
+{
+    const unsigned u = static_cast<unsigned>(d), m = static_cast<unsigned>(n);
+    const unsigned a = u < u + m ? u : u + m, b = u - m;
+    return a < b ? a : b;
+}
+
+} // namespace fes
 #endif

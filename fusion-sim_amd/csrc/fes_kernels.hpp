@@ -93,13 +93,6 @@ __device__ __forceinline__ void weights_of(int w1, T (&f)[2])
     f[0] = static_cast<T>(1) - f[1];
 }
 
-// d mod n for -n < d < 2 n, as an unsigned number: whichever of d, d + n, d - n lies in [0, n) is the smallest of the
-// three taken as unsigned (one v_min3_u32 instead of two compare-and-select pairs)
-__device__ __forceinline__ unsigned wrap_near(int d, int n)
-{
-    const unsigned u = static_cast<unsigned>(d), m = static_cast<unsigned>(n);
-    return min(min(u, u + m), u - m);
-}
 
 template <typename T>
 __device__ __forceinline__ T wrap01(T u)
@@ -109,20 +102,6 @@ __device__ __forceinline__ T wrap01(T u)
     return r;
 }
 
-// The node arrays of a handle hold the planes zs0, zs0 + 1, ..., zs0 + nzs - 1 along z (periodic in nz): all of them
-// (zs0 = 0, nzs = nz) for an undecomposed handle or a rank that keeps global arrays; its slab with the ghost / halo planes
-// for a rank of a COMPACT decomposition (fes_api.hip, domain_init), whose arrays have nzs planes only.  Kernels take the
-// global plane index of a node through held_plane(): the plane's place in the array, or -1 for a plane the handle does not
-// hold (what a particle that has outrun the ghost planes would touch there is dropped: it was never read either).
-struct Held {
-    int zs0, nzs; // 0 <= zs0 < nz
-};
-__device__ __forceinline__ int held_plane(int k, Held hd, int nz)
-{
-    int l = k - hd.zs0;
-    if (l < 0) l += nz;
-    return l < hd.nzs ? l : -1;
-}
 
 template <typename T>
 struct Push3Args {

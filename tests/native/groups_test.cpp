@@ -77,6 +77,34 @@ int main()
             }
         }
     }
-    std::printf("cases=%d\nok\n", cases);
+    // held_plane: a rank's slab with `halo` planes on either side (+ 1: nodes), periodic; every plane the rank touches has
+    // its own place in [0, nzs), every other plane none — for every rank, the first and last included (their halo wraps)
+    int planes = 0;
+    for (int seed = 1; seed <= 2000; ++seed) {
+        std::mt19937 rng(seed);
+        auto rnd = [&](int lo, int hi) { return lo + static_cast<int>(rng() % static_cast<unsigned>(hi - lo + 1)); };
+        const int world = rnd(2, 9), nzl = rnd(3, 40), nz = world * nzl, halo = rnd(1, 8);
+        const int nzs = nzl + 2 * halo + 1;
+        if (nzs >= nz) continue; // (such a rank keeps whole-grid arrays)
+        for (int rank = 0; rank < world; ++rank) {
+            const int z0 = rank * nzl;
+            const fes::Held hd{ ((z0 - halo) % nz + nz) % nz, nzs };
+            std::vector<int> seen(nzs, 0);
+            for (int k = 0; k < nz; ++k) {
+                int d = k - (z0 - halo);                 // distance above the first held plane, periodic
+                d = (d % nz + nz) % nz;
+                const int l = fes::held_plane(k, hd, nz);
+                if (d < nzs) { if (l != d) return fail("held_plane: a held plane in the wrong place", seed); seen[l]++; }
+                else if (l != -1) return fail("held_plane: a plane the rank does not hold has a place", seed);
+                ++planes;
+            }
+            for (int v : seen) if (v != 1) return fail("held_plane: places not one to one", seed);
+        }
+    }
+    // wrap_near(d, n) == d mod n for -n < d < 2 n
+    for (int n = 1; n <= 70; ++n)
+        for (int d = -n + 1; d < 2 * n; ++d)
+            if (fes::wrap_near(d, n) != static_cast<unsigned>(((d % n) + n) % n)) return fail("wrap_near", n);
+    std::printf("cases=%d planes=%d\nok\n", cases, planes);
     return 0;
 }

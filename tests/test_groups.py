@@ -4,7 +4,9 @@ launch hands from the interior to the upper face), built for the HOST with g++ a
 every group of every species is pushed exactly once — by one launch, or by the two parts together — and the interior's
 launch never pushes a particle of a face layer (whose deposits must be complete before the ghost planes travel).  Found
 while writing it: an interior whose last group holds no face particle (a species absent from the upper face) lost that
-group, and an interior of fewer than four slots had its neighbours' shared group pushed twice."""
+group, and an interior of fewer than four slots had its neighbours' shared group pushed twice.  The same program checks
+held_plane() — the place of a plane in a rank's slab-only arrays, first and last rank's wrapping halo included — and the
+window's periodic distance wrap_near()."""
 import os
 import subprocess
 
