@@ -983,8 +983,16 @@ def main():
         # N = 1, 2, 4, 8 of the driver's plain `bench.py --gpus N` trace the strong-scaling curve in this block, over the
         # library's own RCCL communicator (there is no other transport here: a failure to set it up ends the run).
         torch.cuda.empty_cache()
-        block = box_workload(args, rank, world, local_rank, dist if distributed else None, steps=max(2, args.steps // 5), warmup=1,
-                             cpu=not args.no_cpu_baseline)
+        try:
+            block = box_workload(args, rank, world, local_rank, dist if distributed else None, steps=max(2, args.steps // 5), warmup=1,
+                                 cpu=not args.no_cpu_baseline)
+        except Exception as e:  # loud, but the headline measured above is not lost with it: the line, then a non-zero exit
+            if rank == 0:
+                out["strong_c4"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("bench.py: the strong_c4 block failed on rank %d: %r\n" % (rank, e))
+            sys.stderr.flush()
+            os._exit(4)  # (the other ranks may sit in a collective of the library: the launcher ends them)
         if rank == 0:
             block["what"] = ("north_star's strong-scaling workload (BASELINE configs[3]) measured in the same run at this N: value = total "
                              "particle-updates/s of the whole decomposed job; the driver's ratio value(N)/value(1) of THIS block is the >= 6x curve")
