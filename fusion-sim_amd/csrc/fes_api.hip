@@ -54,6 +54,7 @@ struct Species {
     bool chunk_census_fresh = false;   // ... of the live work list and slots: the next re-binning launch need not count
     int chunk_census_form = 0;         // ... written by a whole launch (0) or by the two parts of a rank's launch (1),
                                        //     bit 1: over the joint work list of every species (State::joint_work) instead of its own
+    uint64_t chunk_census_list = 0;    // ... and which build of the joint list its items are those of (State::joint_build)
     size_t chunk_census_items = 0;     // work items the census has room for
     uint64_t layout = 0;               // counts the changes of the live bin table (what a joint work list is built from)
     void* em_args = nullptr;           // EmPushArgs of the last full-EM launch, resident for the kernel's out-of-line paths
@@ -87,6 +88,7 @@ struct State {
     uint32_t* joint_nwork = nullptr;
     size_t joint_cap = 0;
     std::vector<std::pair<size_t, uint64_t>> joint_built_from; // (species, layout) of the list in joint_work
+    uint64_t joint_build = 0;          // counts the rebuilds (a per-item census belongs to the list it was written over)
     bool joint_now = false;            // the two parts of one sub-step's launch use the same list
     unsigned long long* spilled_host = nullptr; // pinned, 2 lagged slots
     hipEvent_t spill_event[2] = {};
@@ -291,6 +293,7 @@ int ensure_joint_list(fpic_handle* h, const std::vector<size_t>& set)
     joint_scan_kernel<<<1, 1024, 0, h->stream>>>(tabs, st->ntiles, static_cast<uint32_t>(kChunk3), st->joint_work, st->joint_nwork);
     HIP_TRY(h, hipGetLastError());
     st->joint_built_from = sig;
+    st->joint_build++;
     return FPIC_OK;
 }
 
@@ -354,10 +357,11 @@ int launch_push_all(fpic_handle* h, int part = 0)
             // (species_groups).
             const bool ranks = st->dom && st->dom->world > 1;
             const int form = (part == 0 ? 0 : 1) | (joint ? 2 : 0);
-            a.chunk_census = !s.rebin_now || (s.chunk_census_fresh && s.chunk_census_form == form) ? s.chunk_census : nullptr;
+            const uint64_t list = joint ? st->joint_build : 0;
+            a.chunk_census = !s.rebin_now || (s.chunk_census_fresh && s.chunk_census_form == form && s.chunk_census_list == list) ? s.chunk_census : nullptr;
             a.census_interior_only = ranks ? 1 : 0;
             if (part != 1) s.chunk_census_fresh = !s.rebin_now; // (after the last part)
-            if (!s.rebin_now) s.chunk_census_form = form;
+            if (!s.rebin_now) { s.chunk_census_form = form; s.chunk_census_list = list; }
             if (k == 0) rebin = s.rebin_now;
         }
     }
