@@ -543,11 +543,17 @@ size_t hat_values(const State* st)
     return (nxh + c - 1) / c * c * st->ny * st->nz;
 }
 
+// pairs of real rows per workgroup of the x passes (two rows ride on one complex transform): about 4096 points — 16 pairs
+// of 256, 8 of 512 (512^3: x forward 525 -> 428 us, x inverse 353 -> 326 with 8 instead of 16; 4 pairs and, at 256^3, 8 or 4
+// are slower: profiles/r03_fft_ablation.txt)
+template <typename T>
+int x_pairs_per_workgroup(int nx) { return std::max(2, std::min<int>(fft_tile_columns<T>(), 4096 / nx)); }
+
 template <typename T>
 int fft_x_forward(fpic_handle* h, const long long* fixed, const T* rho, double scale, size_t rows, T* hat)
 {
     State* st = h->es;
-    const int ppw = fft_tile_columns<T>(); // pairs of rows per workgroup (two real rows ride on one complex transform)
+    const int ppw = x_pairs_per_workgroup<T>(st->nx);
     fft_x_forward_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(fixed, rho, scale, rows, st->nx, fft_log2(st->nx), ppw, hat,
                                                                                                                  static_cast<const T*>(st->fft_tw[0]), static_cast<int>(row_pitch<T>(st)));
     HIP_TRY(h, hipGetLastError());
@@ -558,7 +564,7 @@ template <typename T>
 int fft_x_inverse(fpic_handle* h, const T* hat, size_t rows, T* phi)
 {
     State* st = h->es;
-    const int ppw = fft_tile_columns<T>();
+    const int ppw = x_pairs_per_workgroup<T>(st->nx);
     fft_x_inverse_kernel<T><<<blocks_for(rows, 2 * ppw), kFftThreads, fft_lds_bytes<T>(st->nx, ppw), h->stream>>>(hat, rows, st->nx, fft_log2(st->nx), ppw, phi,
                                                                                                                  static_cast<const T*>(st->fft_tw[0]), static_cast<int>(row_pitch<T>(st)));
     HIP_TRY(h, hipGetLastError());
