@@ -580,8 +580,18 @@ int fft_columns(fpic_handle* h, T* hat, size_t outer_stride, size_t stride, int 
     const T* twt = static_cast<const T*>(st->fft_tw[MODE == 2 ? 2 : 1]); // (the y passes and the z sweep: N is ny resp. nz)
     const int nxh = st->nx / 2 + 1;
     const ColLayout L{ outer_stride, stride, outer, nxh, static_cast<int>(row_pitch<T>(st)), xbuf ? nyl : 0, nzl };
-    // (tiles of 16 complex floats / 8 doubles: 4, 8 and 32 columns were measured and lose, profiles/r03_fft_ablation.txt)
+    // (tiles of 16 complex floats / 8 doubles = one 128-byte line per row; at 256 points 4, 8 and 32 columns were measured
+    // and lose.  Columns of 512 floats take half tiles: about 4096 points per workgroup again, as in the x passes — twice the
+    // workgroups in flight: z sweep 674 -> 574 us, y inverse 385 -> 364 at 512^3, profiles/r03_fft_ablation.txt)
     constexpr int C = fft_tile_columns<T>();
+    if (N >= 512 && sizeof(T) == 4) {
+        constexpr int H = C / 2;
+        const unsigned tiles = static_cast<unsigned>((nxh + H - 1) / H);
+        fft_columns_kernel<T, MODE, H><<<static_cast<unsigned>(outer) * tiles, kFftThreads, fft_lds_bytes<T>(N, H), h->stream>>>(
+            hat, xbuf, L, N, fft_log2(N), y0, st->k2[0], st->k2[1], st->k2[2], 1.0 / (kEps0 * static_cast<double>(st->nodes)), twt);
+        HIP_TRY(h, hipGetLastError());
+        return FPIC_OK;
+    }
     const unsigned tiles = static_cast<unsigned>((nxh + C - 1) / C);
     fft_columns_kernel<T, MODE><<<static_cast<unsigned>(outer) * tiles, kFftThreads, fft_lds_bytes<T>(N, C), h->stream>>>(
         hat, xbuf, L, N, fft_log2(N), y0, st->k2[0], st->k2[1], st->k2[2], 1.0 / (kEps0 * static_cast<double>(st->nodes)), twt);
