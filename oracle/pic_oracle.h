@@ -77,6 +77,10 @@ void orc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
                     int physical_a);                                                                   \
     void P##deposit(const REAL* pos, const REAL* vel, size_t n, const float* stamp, int nr, int nz,    \
                     REAL* moments);                                                                    \
+    void P##deposit_raster(const REAL* pos, const REAL* vel, size_t n, const float* stamp, int nr,     \
+                           int nz, REAL* moments, int subpixel_bits);                                 \
+    void P##raster_cells(const REAL* pos, size_t n, int nr, int nz, int subpixel_bits, int32_t* ci,    \
+                         int32_t* cj);                                                                 \
     void P##deposit_cic(const REAL* pos, const REAL* vel, size_t n, int nr, int nz, REAL* moments);    \
     void P##deposit_cells(const REAL* pos, size_t n, int nr, int nz, int32_t* cells);                  \
     void P##normalise(const REAL* moments, int nr, int nz, REAL* norm);                                \

@@ -101,7 +101,10 @@ def inv_cdf(pdf):
 class OracleSim:
     """CPU twin of empic.makeCylindricalParticlePusher(spec) (empic.js:30)."""
 
-    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None, rng="reference", seed=0, threads=1, shape="ref11"):
+    def __init__(self, spec, dtype=np.float32, physical_a=False, count=None, rng="reference", seed=0, threads=1, shape="ref11", raster_bits=0):
+        # raster_bits > 0: the point sprites as a rasteriser with that many sub-pixel bits draws them (deposit_raster in
+        # pic_oracle_impl.h: snapped window coordinates, y down, cropped instead of discarded); 0: the ideal sprite
+        self.raster_bits = int(raster_bits)
         self.shape = shape  # "ref11": the reference's 11x11 stamp; "cic": the bilinear extension
         # threads > 1: the OpenMP build (timing only: the threaded deposit sums in another order)
         self.threads = int(threads)
@@ -227,6 +230,10 @@ class OracleSim:
         if self.shape == "cic":   # extension: bilinear deposit on the four nearest cell centres
             self._f("deposit_cic")(_p(self.pos_A), _p(self.vel_A), ctypes.c_size_t(self.n), self.nr, self.nz, _p(self.moments))
             return
+        if self.raster_bits:
+            self._f("deposit_raster")(_p(self.pos_A), _p(self.vel_A), ctypes.c_size_t(self.n), _p(self.stamp), self.nr, self.nz,
+                                      _p(self.moments), self.raster_bits)
+            return
         self._f("deposit_threads" if self.threads > 1 else "deposit")(
             _p(self.pos_A), _p(self.vel_A), ctypes.c_size_t(self.n), _p(self.stamp), self.nr, self.nz, _p(self.moments))
 
@@ -249,6 +256,12 @@ class OracleSim:
         out = np.zeros(self.n, dtype=np.int32)
         self._f("deposit_cells")(_p(self.pos_A), ctypes.c_size_t(self.n), self.nr, self.nz, _p(out))
         return out
+
+    def raster_cells(self, bits=None):
+        """Sprite-centre cells (ci, cj) under the rasterised convention; INT32_MIN for dropped points."""
+        ci, cj = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
+        self._f("raster_cells")(_p(self.pos_A), ctypes.c_size_t(self.n), self.nr, self.nz, int(bits or self.raster_bits), _p(ci), _p(cj))
+        return ci, cj
 
     def positions(self):
         return self.pos_A.reshape(self.n, 4)[:, :3]

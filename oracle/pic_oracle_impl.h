@@ -237,6 +237,92 @@ void FN(deposit)(const REAL* pos, const REAL* vel, size_t n, const float* stamp,
     }
 }
 
+/* The same draw as a REAL rasteriser executes it (tests/golden/webgl_*: the reference run by Chromium's WebGL 1 on
+ * ANGLE/SwiftShader, oracle/make_golden_webgl.py).  deposit() above assumes window coordinates of infinite precision and
+ * the whole-point clipping of the GL ES 2.0 text; a rasteriser does neither.  What SwiftShader does, and what this
+ * function restates (subpixel_bits = b, SwiftShader: 4 = gl.getParameter(SUBPIXEL_BITS)):
+ *   - clip coordinates (2r-1, 2z-1) in float (empic.js:997);
+ *   - viewport transform to a fixed-point window position in pixel-centre coordinates (pixel p's centre at p*2^b), y
+ *     running DOWNWARDS: X = rint(X0 + ndc.x*Wb), Y = rint(Y0 + ndc.y*(-Hb)) with Wb = (nr/2)*2^b, X0 = Wb - 2^(b-1)
+ *     (same with nz), one float rounding per operation, rint = round half to even;
+ *   - the sprite is the square X +- 11*2^(b-1); a pixel is covered when its centre lies inside, left/top edges
+ *     inclusive: columns p0 .. p0+10 with p0 = ceil((X - 11*2^(b-1)) / 2^b), rows likewise counted from the top;
+ *     gl_PointCoord's NEAREST texel of covered pixel k of a row or column is k (observed: exact);
+ *   - a point is NOT discarded when its centre leaves the clip volume: the square is clipped, i.e. the footprint is
+ *     cropped at the target's edges whatever the centre is (centres up to 5.5 pixels outside still deposit); only
+ *     non-finite positions are dropped;
+ *   - blending in particle order.
+ * A particle whose window coordinate lies within 2^-(b+1) pixels above a pixel edge therefore lands one cell lower
+ * than under deposit()'s convention (1/16 of the particles per axis at b = 4, 1/256 at b = 8).  Not modelled:
+ * SwiftShader flushes denormal products to zero and, on a measure-zero set, covers a 12th row/column whose texels
+ * repeat the stamp's outermost ring (values <= 1.7e-34): fixtures agree to 1e-33 of the image's maximum, bit for bit
+ * above that. */
+static inline int FN(raster_origin)(REAL u, int W, int bits, int y_down, int* first)
+{
+    REAL ndc = (REAL)2 * u - (REAL)1;
+    REAL wb = (REAL)W * (REAL)0.5 * (REAL)(1 << bits);
+    REAL x0 = wb - (REAL)(1 << bits) * (REAL)0.5;
+    REAL t = ndc * (y_down ? -wb : wb);
+    REAL s = x0 + t;
+    if (!(s > (REAL)-1073741824.0 && s < (REAL)1073741824.0)) return 0; /* NaN, infinite or absurd: dropped */
+    long X = lrint((double)s); /* round half to even (the default rounding mode), as cvtps2dq does */
+    long half = 11L * (1L << bits) / 2;
+    long a = X - half, sc = 1L << bits;
+    long p0 = (a >= 0) ? (a + sc - 1) / sc : -((-a) / sc); /* ceil(a / sc) */
+    *first = y_down ? (int)(W - 1 - (p0 + 10)) : (int)p0;
+    return 1;
+}
+
+void FN(deposit_raster)(const REAL* pos, const REAL* vel, size_t n, const float* stamp,
+                        int nr, int nz, REAL* moments, int subpixel_bits)
+{
+    size_t ncell = (size_t)nr * nz;
+    for (size_t c = 0; c < 4 * ncell; ++c) moments[c] = (REAL)0;
+    for (size_t p = 0; p < n; ++p) {
+        const REAL* P = pos + 4 * p;
+        const REAL* V = vel + 4 * p;
+        REAL r = SQRT(P[0] * P[0] + P[1] * P[1]);
+        REAL z = P[2];
+        int i0, j0;
+        if (!FN(raster_origin)(r, nr, subpixel_bits, 0, &i0) || !FN(raster_origin)(z, nz, subpixel_bits, 1, &j0)) continue;
+        if (i0 >= nr || i0 + 10 < 0 || j0 >= nz || j0 + 10 < 0) continue;
+        REAL dx = P[0] / r, dy = P[1] / r;
+        REAL vr = V[0] * dx + V[1] * dy;
+        REAL va = V[1] * dx - V[0] * dy;
+        REAL col[4] = { (REAL)0.001 * vr, (REAL)0.001 * va, (REAL)0.001 * V[2], (REAL)0.001 * (REAL)1 };
+        for (int dj = 0; dj < 11; ++dj) {
+            int j = j0 + dj;
+            if (j < 0 || j >= nz) continue;
+            for (int di = 0; di < 11; ++di) {
+                int i = i0 + di;
+                if (i < 0 || i >= nr) continue;
+                REAL w = (REAL)stamp[di + 11 * (10 - dj)];
+                REAL* m = moments + 4 * ((size_t)i + (size_t)nr * j);
+                m[0] += col[0] * w;
+                m[1] += col[1] * w;
+                m[2] += col[2] * w;
+                m[3] += col[3] * w;
+            }
+        }
+    }
+}
+
+/* Sprite-centre cells of deposit_raster(): (first column + 5, first row + 5); they may lie up to 6 cells outside the
+ * grid.  ci = INT32_MIN for a dropped point. */
+void FN(raster_cells)(const REAL* pos, size_t n, int nr, int nz, int subpixel_bits, int32_t* ci, int32_t* cj)
+{
+    for (size_t p = 0; p < n; ++p) {
+        const REAL* P = pos + 4 * p;
+        REAL r = SQRT(P[0] * P[0] + P[1] * P[1]);
+        int i0, j0;
+        if (!FN(raster_origin)(r, nr, subpixel_bits, 0, &i0) || !FN(raster_origin)(P[2], nz, subpixel_bits, 1, &j0)) {
+            ci[p] = INT32_MIN; cj[p] = INT32_MIN;
+            continue;
+        }
+        ci[p] = i0 + 5; cj[p] = j0 + 5;
+    }
+}
+
 /* EXTENSION (SURVEY.md 8(b) key shape:'cic'; no reference counterpart, parity unpinned): the same vertex colour
  * spread bilinearly over the four cell CENTRES around the point instead of the 11x11 stamp.  With the window
  * coordinates (gi, gj) = (r*nr, z*nz) of empic.js:997-999: i0 = floor(gi - 0.5), f = gi - 0.5 - i0, weights

@@ -1,18 +1,25 @@
 """The dense-solver restatement (oracle/sor_oracle.c) against the reference's own
-makeSORIterative evaluated in software (tests/golden/swgl_sor.*, oracle/make_golden.js
-section 9).  Every texture and every number solve() returns is compared bit for bit."""
+makeSORIterative: run by a real WebGL (tests/golden/webgl_sor.*, oracle/make_golden_webgl.py:
+Chromium's ANGLE/SwiftShader executing matrix_webgl.js) and evaluated in software
+(tests/golden/swgl_sor.*, oracle/make_golden.js section 9).  Every texture and every number
+solve() returns is compared bit for bit, against both."""
 import numpy as np
 import pytest
 
 from helpers import load_f32gz, load_json, same_bits
 from sor_oracle import OracleSOR
 
-META = load_json("swgl_sor.json")
-BLOB = load_f32gz(META["file"])
+FIXTURES = {}
+for _name in ("swgl_sor", "webgl_sor"):
+    _m = load_json(_name + ".json")
+    FIXTURES[_name] = (_m, load_f32gz(_m["file"]))
+META, BLOB = FIXTURES["swgl_sor"]
+CASES = [(f, c) for f in sorted(FIXTURES) for c in sorted(FIXTURES[f][0]["cases"])]
 
 
-def arr(at):
-    return BLOB[at[0]: at[0] + at[1]]
+def arr(at, blob=None):
+    blob = BLOB if blob is None else blob
+    return blob[at[0]: at[0] + at[1]]
 
 
 def num(v):
@@ -23,9 +30,11 @@ def same_number(a, b):
     return (np.isnan(a) and np.isnan(b)) or a == b
 
 
-@pytest.mark.parametrize("name", sorted(META["cases"]))
-def test_solver_replay_is_bit_identical(name):
-    case = META["cases"][name]
+@pytest.mark.parametrize("fixture,name", CASES)
+def test_solver_replay_is_bit_identical(fixture, name):
+    meta, blob = FIXTURES[fixture]
+    case = meta["cases"][name]
+    arr = lambda at: blob[at[0]: at[0] + at[1]]
     L = case["vec_length"]
     eq = OracleSOR(case["n_power"], case["relaxation"])
     assert eq.vec_length == L and eq.vec_height == case["vec_height"]
@@ -43,6 +52,21 @@ def test_solver_replay_is_bit_identical(name):
         assert same_bits(res["result"], arr(call["result"]))
         assert same_number(res["diff"], num(call["diff"])), (res["diff"], call["diff"])
         assert same_number(res["correlation"], num(call["correlation"])), (res["correlation"], call["correlation"])
+
+
+def test_the_real_webgl_and_the_software_evaluator_agree_bit_for_bit():
+    """No transcendental and no division by a varying in these shaders: the two fixtures hold the same numbers."""
+    (ms, bs), (mw, bw) = FIXTURES["swgl_sor"], FIXTURES["webgl_sor"]
+    assert sorted(ms["cases"]) == sorted(mw["cases"])
+    assert mw["gl"]["version"].startswith("WebGL 1.0")
+    for name, cs in ms["cases"].items():
+        cw = mw["cases"][name]
+        for key in ("A", "b", "x0", "x_after_init"):
+            assert same_bits(arr(cs[key], bs), arr(cw[key], bw)), (name, key)
+        for a, b in zip(cs["calls"], cw["calls"]):
+            assert a["iterations"] == b["iterations"] and a["diff"] == b["diff"] and a["correlation"] == b["correlation"]
+            for key in ("result", "x_result", "x_guess", "x_stats", "R", "C"):
+                assert same_bits(arr(a[key], bs), arr(b[key], bw)), (name, key)
 
 
 def test_fixture_covers_the_quirks():
