@@ -996,16 +996,19 @@ int upload_vel(fpic_handle* h, Species& s, const In* host, size_t first, size_t 
 }
 
 template <typename T, typename Out>
-int download_vec3(fpic_handle* h, const Species& s, Out* host, int first)
+int download_vec3(fpic_handle* h, const Species& s, Out* host, int first, size_t from = 0, size_t count = ~size_t(0), size_t stride = 1)
 {
+    // `count` of the caller's particles from, from + stride, ... (everything by default), in pieces of `chunk` output slots
+    if (count == ~size_t(0)) count = s.n;
+    if (!count) return FPIC_OK;
     const size_t chunk = 8u << 20;
     Out* stage = nullptr;
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, s.n) * 3 * sizeof(Out)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, count) * 3 * sizeof(Out)));
     const T* a = static_cast<const T*>(s.slab[s.cur]);
-    for (size_t b = 0; b < s.n; b += chunk) {
-        const size_t m = std::min(chunk, s.n - b);
+    for (size_t b = 0; b < count; b += chunk) {
+        const size_t m = std::min(chunk, count - b);
         get_vec3_kernel<T, Out><<<blocks_for(s.n), 256, 0, h->stream>>>(a + first * s.n_pad, a + (first + 1) * s.n_pad, a + (first + 2) * s.n_pad,
-                                                                      s.id[s.cur], s.n, b, m, stage);
+                                                                      s.id[s.cur], s.n, b, m, stage, from, stride);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(host + 3 * b, stage, m * 3 * sizeof(Out), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1016,16 +1019,18 @@ int download_vec3(fpic_handle* h, const Species& s, Out* host, int first)
 }
 
 template <typename T>
-int download_cells(fpic_handle* h, const Species& s, int32_t* cells)
+int download_cells(fpic_handle* h, const Species& s, int32_t* cells, size_t from = 0, size_t count = ~size_t(0), size_t stride = 1)
 {
     State* st = h->es;
+    if (count == ~size_t(0)) count = s.n;
+    if (!count) return FPIC_OK;
     const size_t chunk = 16u << 20;
     int32_t* stage = nullptr;
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, s.n) * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&stage), std::min(chunk, count) * sizeof(int32_t)));
     const T* a = static_cast<const T*>(s.slab[s.cur]);
-    for (size_t b = 0; b < s.n; b += chunk) {
-        const size_t m = std::min(chunk, s.n - b);
-        cells3_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a, a + s.n_pad, a + 2 * s.n_pad, s.id[s.cur], s.n, b, m, st->nx, st->ny, st->nz, stage);
+    for (size_t b = 0; b < count; b += chunk) {
+        const size_t m = std::min(chunk, count - b);
+        cells3_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a, a + s.n_pad, a + 2 * s.n_pad, s.id[s.cur], s.n, b, m, st->nx, st->ny, st->nz, stage, from, stride);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(cells + b, stage, m * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1313,33 +1318,46 @@ int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* 
     return rc;
 }
 
-int get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype)
+// the caller's particles first, first + stride, ..., n of them (n = ~0: all of them from `first` on at that stride)
+static int check_range(fpic_handle* h, const Species& s, uint64_t first, uint64_t& n, uint64_t stride)
+{
+    if (stride < 1) return fail(h, FPIC_ERR_INVALID_ARG, ".stride <- must be at least 1");
+    const uint64_t most = first < s.n ? (s.n - first + stride - 1) / stride : 0;
+    if (n == ~0ull) n = most;
+    if (n > most) return fail(h, FPIC_ERR_INVALID_ARG, ".n <- %llu particles from %llu at stride %llu: the species has %llu", static_cast<unsigned long long>(n),
+                              static_cast<unsigned long long>(first), static_cast<unsigned long long>(stride), static_cast<unsigned long long>(s.n));
+    return FPIC_OK;
+}
+
+int get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype, uint64_t from, uint64_t n, uint64_t stride)
 {
     if (h->es->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle holds a changing subset of the particles: read it with fpic_domain_get_particles");
     if (int rc = check_species(h, species)) return rc;
     const Species& s = h->es->sp[species];
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
+    if (int rc = check_range(h, s, from, n, stride)) return rc;
     int rc = FPIC_OK;
     for (int pass = 0; pass < 2 && rc == FPIC_OK; ++pass) {
         void* dst = pass == 0 ? pos_aos : vel_aos;
-        if (!dst || !s.n) continue;
+        if (!dst || !s.n || !n) continue;
         const int first = pass == 0 ? 0 : 3;
         if (h->prec == FPIC_F32)
-            rc = dtype == FPIC_F32 ? download_vec3<float, float>(h, s, static_cast<float*>(dst), first) : download_vec3<float, double>(h, s, static_cast<double*>(dst), first);
+            rc = dtype == FPIC_F32 ? download_vec3<float, float>(h, s, static_cast<float*>(dst), first, from, n, stride) : download_vec3<float, double>(h, s, static_cast<double*>(dst), first, from, n, stride);
         else
-            rc = dtype == FPIC_F32 ? download_vec3<double, float>(h, s, static_cast<float*>(dst), first) : download_vec3<double, double>(h, s, static_cast<double*>(dst), first);
+            rc = dtype == FPIC_F32 ? download_vec3<double, float>(h, s, static_cast<float*>(dst), first, from, n, stride) : download_vec3<double, double>(h, s, static_cast<double*>(dst), first, from, n, stride);
     }
     return rc;
 }
 
-int get_cells(fpic_handle* h, int species, int32_t* cells)
+int get_cells(fpic_handle* h, int species, int32_t* cells, uint64_t from, uint64_t n, uint64_t stride)
 {
     if (h->es->dom) return fail(h, FPIC_ERR_STATE, "a decomposed handle holds a changing subset of the particles: read it with fpic_domain_get_particles");
     if (int rc = check_species(h, species)) return rc;
     if (!cells) return fail(h, FPIC_ERR_INVALID_ARG, ".cells <- Non-optional property is undefined!");
     const Species& s = h->es->sp[species];
-    if (!s.n) return FPIC_OK;
-    return h->prec == FPIC_F32 ? download_cells<float>(h, s, cells) : download_cells<double>(h, s, cells);
+    if (int rc = check_range(h, s, from, n, stride)) return rc;
+    if (!s.n || !n) return FPIC_OK;
+    return h->prec == FPIC_F32 ? download_cells<float>(h, s, cells, from, n, stride) : download_cells<double>(h, s, cells, from, n, stride);
 }
 
 // ---- checkpoint of an undecomposed box: header, per species the raw particle state in the caller's order, the fields

@@ -11,8 +11,8 @@ void release(fpic_handle* h);
 int add_species(fpic_handle* h, double mass, double charge, uint64_t count, int* index);
 int set_particles(fpic_handle* h, int species, const void* pos_aos, const void* vel_aos, uint64_t first, uint64_t n, int dtype);
 uint64_t species_count(const fpic_handle* h, int species);
-int get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype);
-int get_cells(fpic_handle* h, int species, int32_t* cells);
+int get_particles(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype, uint64_t first = 0, uint64_t n = ~0ull, uint64_t stride = 1);
+int get_cells(fpic_handle* h, int species, int32_t* cells, uint64_t first = 0, uint64_t n = ~0ull, uint64_t stride = 1);
 int add_b(fpic_handle* h, double bx, double by, double bz);
 int set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int nz, int dtype);
 int read_field3(fpic_handle* h, int which, void* out, int dtype);

@@ -903,11 +903,13 @@ __global__ __launch_bounds__(256) void pack_field3_kernel(const In* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void cells3_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
                                                      const uint32_t* __restrict__ id, size_t n, size_t chunk_begin, size_t chunk_n, int nx, int ny,
-                                                     int nz, int32_t* __restrict__ cells)
+                                                     int nz, int32_t* __restrict__ cells, size_t first = 0, size_t stride = 1)
 {
     const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    const size_t p = id[s];
+    size_t p = id[s];
+    if (p < first || (p - first) % stride) return;   // slot k = the caller's particle first + k * stride (get_vec3_kernel)
+    p = (p - first) / stride;
     if (p < chunk_begin || p >= chunk_begin + chunk_n) return;
     int i, j, k, w;
     axis(x[s], nx, i, w); axis(y[s], ny, j, w); axis(z[s], nz, k, w);

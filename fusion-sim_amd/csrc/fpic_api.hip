@@ -235,6 +235,7 @@ int launch_push(fpic_handle* h, int nsub)
     a.id = h->id[h->cur];
     a.seed_lo = h->spec.rng_seed_lo; a.seed_hi = h->spec.rng_seed_hi;
     a.t0 = h->t_substep;
+    a.raster_bits = h->spec.raster_subpixel_bits;
     const bool ctr = h->spec.rng_mode == 1;
     const size_t lanes = (h->n + Vec16<T>::N - 1) / Vec16<T>::N;
     // binned, fusion not switched off: the push also counts the particles per tile and, on a re-binning
@@ -257,7 +258,7 @@ int launch_push(fpic_handle* h, int nsub)
     if (fuse) {
         HIP_TRY(h, hipMemsetAsync(h->tile_count, 0, sizeof(uint32_t) * h->ntiles, h->stream));
         if constexpr (sizeof(T) == 4) {
-            const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
+            const size_t gcells = sums_cells(h->nr, h->nz);
             if (sums) {
                 HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
                 HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
@@ -368,7 +369,7 @@ int launch_bin(fpic_handle* h)
 template <typename T>
 int launch_cell_sums(fpic_handle* h)
 {
-    const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
+    const size_t gcells = sums_cells(h->nr, h->nz);
     timing_begin(h, KC_DEPOSIT);
     HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color [0,0,0,0] (empic.js:1476)
     HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
@@ -377,7 +378,8 @@ int launch_cell_sums(fpic_handle* h)
             arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work2[h->wl], h->nwork2[h->wl], static_cast<T*>(h->cell_sums), h->spilled);
     else
         cell_sums_kernel<T><<<static_cast<unsigned>(h->work_cap), kSumsThreads, kSumsLdsBytes, h->stream>>>(
-            arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work2[h->wl], h->nwork2[h->wl], static_cast<T*>(h->cell_sums), h->spilled);
+            arrays<T>(h, h->cur), h->nr, h->nz, h->ntx, h->work2[h->wl], h->nwork2[h->wl], static_cast<T*>(h->cell_sums), h->spilled,
+            h->spec.raster_subpixel_bits);
     timing_end(h);
     HIP_TRY(h, hipGetLastError());
     return record_spill(h);
@@ -507,7 +509,7 @@ int create_state(fpic_handle* h)
         if (int rc = dev_alloc(h, reinterpret_cast<void**>(&h->id[s]), h->n_pad * sizeof(uint32_t), &h->bytes_particles)) return rc;
     }
     const size_t rgba = h->ncell * 4 * sizeof(T);
-    const size_t gcells = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1);
+    const size_t gcells = sums_cells(h->nr, h->nz);
     struct { void** p; size_t bytes; } grids[] = {
         { &h->E, rgba }, { &h->B, rgba }, { &h->sink, rgba }, { &h->moments, rgba }, { &h->norm, rgba }, { &h->avg, rgba },
         { &h->shape_half, rgba }, { &h->shape_tenth, rgba },
@@ -784,6 +786,8 @@ int validate_spec(const fpic_spec* s)
     if (s->rng_mode != 0 && s->rng_mode != 1) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".rng_mode <- must be 0 (reference) or 1 (counter)");
     if (s->unfused_deposit < 0 || s->unfused_deposit > 2) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".unfused_deposit <- must be 0, 1 or 2");
     if (s->shape != FPIC_SHAPE_REF11 && s->shape != FPIC_SHAPE_CIC) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".shape <- must be 0 (ref11) or 1 (cic)");
+    if (s->raster_subpixel_bits < 0 || s->raster_subpixel_bits > 8) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".raster_subpixel_bits <- must be 0 (ideal sprites) or 1..8");
+    if (s->raster_subpixel_bits && s->shape != FPIC_SHAPE_REF11) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".raster_subpixel_bits <- only the reference's point sprites are rasterised (shape 0)");
     if (s->geometry != FPIC_GEOM_CYL_RZ && s->geometry != FPIC_GEOM_CART3D) return fail(nullptr, FPIC_ERR_INVALID_ARG, ".geometry <- must be 0 (cyl_rz) or 1 (cart3d)");
     return FPIC_OK;
 }
@@ -1131,7 +1135,7 @@ static int density_reduced(fpic_handle* h)
 {
     fcomm::Comm* c = h->comm;
     const fdyn::Rccl& rc = fdyn::rccl();
-    const size_t count = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1) * 4;
+    const size_t count = sums_cells(h->nr, h->nz) * 4;
     const ncclDataType_t dt = h->prec == FPIC_F32 ? ncclFloat : ncclDouble;
     if (!c->overlap) {
         if (int e = fcomm::check(h, rc.AllReduce(h->cell_sums, h->cell_sums, count, dt, ncclSum, c->nccl, h->stream), "ncclAllReduce")) return e;
@@ -1215,7 +1219,7 @@ int fpic_device_buffer(fpic_handle* h, int which, void** dptr, size_t* bytes)
     if (h->es) return fes::device_buffer(h, which, dptr, bytes);
     if (which != FPIC_BUF_CELL_SUMS) return fail(h, FPIC_ERR_INVALID_ARG, ".which <- unknown buffer %d", which);
     if (dptr) *dptr = h->cell_sums;
-    if (bytes) *bytes = (static_cast<size_t>(h->nr) + 1) * (static_cast<size_t>(h->nz) + 1) * 4 * h->esize;
+    if (bytes) *bytes = sums_cells(h->nr, h->nz) * 4 * h->esize;
     return FPIC_OK;
 }
 
@@ -1379,6 +1383,18 @@ int fpic_get_cells_of(fpic_handle* h, int species, int32_t* cells)
     CHECK_HANDLE(h);
     BOX_ONLY(h, "fpic_get_cells_of");
     return fes::get_cells(h, species, cells);
+}
+int fpic_get_particles_range(fpic_handle* h, int species, uint64_t first, uint64_t n, uint64_t stride, void* pos_aos, void* vel_aos, int dtype)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_get_particles_range");
+    return fes::get_particles(h, species, pos_aos, vel_aos, dtype, first, n, stride);
+}
+int fpic_get_cells_range(fpic_handle* h, int species, uint64_t first, uint64_t n, uint64_t stride, int32_t* cells)
+{
+    CHECK_HANDLE(h);
+    BOX_ONLY(h, "fpic_get_cells_range");
+    return fes::get_cells(h, species, cells, first, n, stride);
 }
 int fpic_add_b(fpic_handle* h, double bx, double by, double bz)
 {

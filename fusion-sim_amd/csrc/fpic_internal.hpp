@@ -23,6 +23,16 @@ constexpr int kTileLds = kTileSide + 2 * kTileHalo;
 constexpr int kDepositChunk = 16384;         // particles per workgroup and chunk (sweep: profiles/r01_rebin_ablation.txt)
 constexpr int kMaxTiles = 16384;             // LDS histogram limit of the binning pass
 
+// The per-cell sums of density()'s point sprites live on the cells a sprite's CENTRE can have: columns 0..nr (r = 1
+// lands on column nr) under the ideal convention, and up to 5 cells outside the grid when the sprites are drawn as a
+// rasteriser draws them (spec.raster_subpixel_bits: a point whose centre has left the target is cropped, not dropped).
+// Grid of (nr + 1 + 2*kSumsApron) x (nz + 1 + 2*kSumsApron) cells, cell (ic, jc) at sums_index(ic, jc, nr).
+constexpr int kSumsApron = 5;
+constexpr size_t sums_width(int nr) { return static_cast<size_t>(nr) + 1 + 2 * kSumsApron; }
+constexpr size_t sums_cells(int nr, int nz) { return sums_width(nr) * sums_width(nz); }
+constexpr size_t sums_index(int ic, int jc, int nr) { return static_cast<size_t>(ic + kSumsApron) + sums_width(nr) * static_cast<size_t>(jc + kSumsApron); }
+constexpr bool sums_holds(int ic, int jc, int nr, int nz) { return ic >= -kSumsApron && ic <= nr + kSumsApron && jc >= -kSumsApron && jc <= nz + kSumsApron; }
+
 struct Constants {
     double h, factor_r, factor_z, step_factor, f_rz, f_zr;
 };

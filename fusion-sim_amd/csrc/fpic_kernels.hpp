@@ -15,8 +15,8 @@
 //   sink_alive: 1 byte per cell (sink.r > 0.5 evaluated once at set()).
 //   inv_cdf_xy: 2 T per texel of the 512x512 injection table.
 //   entropy   : 4 T per texel of the 1024x1024 table.
-//   cell_sums : 4 T per cell of an (nr+1) x (nz+1) grid: sums of 0.001*(vr,vtheta,vz,1)
-//               over the particles whose nearest cell it is.
+//   cell_sums : 4 T per cell of an (nr+1) x (nz+1) grid plus an apron of kSumsApron cells (fpic_internal.hpp):
+//               sums of 0.001*(vr,vtheta,vz,1) over the particles whose sprite is centred on the cell.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -123,6 +123,41 @@ __device__ __forceinline__ bool deposit_cell(T x, T y, T z, int nr, int nz, T& r
     return true;
 }
 
+// The same under the rasterised convention (spec.raster_subpixel_bits = b > 0; the CPU restatement is deposit_raster,
+// pinned by tests/golden/webgl_*): what a rasteriser with b sub-pixel bits makes of the
+// point.  Clip coordinate 2u-1, viewport transform to a fixed-point window position in pixel-centre coordinates with
+// y running downwards, X = rint(X0 + ndc*Wb), one rounding per operation; the sprite is the square X +- 11*2^(b-1),
+// left/top edges inclusive; its first column (row from the top) is ceil((X - 11*2^(b-1)) / 2^b).  Returns the
+// first column (y_down = false) or the first row counted from the bottom (y_down = true), i.e. centre - 5; false
+// for a NaN / infinite / absurd coordinate.  The footprint may leave the grid: it is cropped, not dropped.
+template <typename T>
+__device__ __forceinline__ bool raster_first(T u, int W, int bits, bool y_down, int& first)
+{
+    const T ndc = static_cast<T>(2) * u - static_cast<T>(1);
+    const T wb = static_cast<T>(W) * static_cast<T>(0.5) * static_cast<T>(1 << bits);
+    const T x0 = wb - static_cast<T>(1 << bits) * static_cast<T>(0.5);
+    const T t = ndc * (y_down ? -wb : wb);
+    const T s = x0 + t;
+    if (!(s > static_cast<T>(-1073741824.0) && s < static_cast<T>(1073741824.0))) return false;
+    int X;
+    if constexpr (sizeof(T) == 4) X = __float2int_rn(s); else X = __double2int_rn(s);   // round half to even
+    const int a = X - 11 * (1 << bits) / 2;
+    const int p0 = (a + (1 << bits) - 1) >> bits;                                        // ceil(a / 2^b)
+    first = y_down ? W - 1 - (p0 + 10) : p0;
+    return true;
+}
+
+// Centre cell of the rasterised sprite of (r, z); false when nothing of it can reach the grid.
+template <typename T>
+__device__ __forceinline__ bool raster_cell(T r, T z, int nr, int nz, int bits, int& ic, int& jc)
+{
+    int i0, j0;
+    if (!raster_first(r, nr, bits, false, i0) || !raster_first(z, nz, bits, true, j0)) return false;
+    if (i0 >= nr || i0 + 10 < 0 || j0 >= nz || j0 + 10 < 0) return false;
+    ic = i0 + 5; jc = j0 + 5;
+    return true;
+}
+
 // One workgroup sums one chunk of the particles binned to one tile.  The tile and an
 // 8-cell halo live in LDS as DOUBLE accumulators: on gfx950 ds_add_f32 sustains only
 // ~0.4 lanes/clk/CU while ds_add_f64 is 3.7x and ds_add_u32 9x faster (measured,
@@ -138,7 +173,8 @@ template <typename T>
 __global__ __launch_bounds__(kSumsThreads) void cell_sums_kernel(ParticleArrays<T> p, int nr, int nz, int ntx,
                                                                  const BlockWork* __restrict__ work,
                                                                  const uint32_t* __restrict__ nwork,
-                                                                 T* __restrict__ cell_sums, unsigned long long* spilled)
+                                                                 T* __restrict__ cell_sums, unsigned long long* spilled,
+                                                                 int raster_bits)
 {
     constexpr int PPT = Vec16<T>::N;
     constexpr int LW = kTileLds;
@@ -151,7 +187,6 @@ __global__ __launch_bounds__(kSumsThreads) void cell_sums_kernel(ParticleArrays<
     for (int k = threadIdx.x; k < LW * LW * 4; k += BS) tile[k] = 0.0;
     __syncthreads();
 
-    const size_t gw = static_cast<size_t>(nr) + 1;
     unsigned int my_spill = 0;
     const size_t first = (static_cast<size_t>(w.begin) / PPT) * PPT;
     for (size_t base = first + static_cast<size_t>(threadIdx.x) * PPT; base < w.end; base += BS * PPT) {
@@ -168,7 +203,8 @@ __global__ __launch_bounds__(kSumsThreads) void cell_sums_kernel(ParticleArrays<
             if (i < w.begin || i >= w.end) continue;
             T r;
             int ic, jc;
-            if (!deposit_cell(x[k], y[k], z[k], nr, nz, r, ic, jc)) continue;
+            const bool inside = deposit_cell(x[k], y[k], z[k], nr, nz, r, ic, jc);
+            if (raster_bits ? !raster_cell(r, z[k], nr, nz, raster_bits, ic, jc) : !inside) continue;
             const T dx = x[k] / r, dy = y[k] / r;
             const T vr = vx[k] * dx + vy[k] * dy;
             const T va = vy[k] * dx - vx[k] * dy;
@@ -185,12 +221,12 @@ __global__ __launch_bounds__(kSumsThreads) void cell_sums_kernel(ParticleArrays<
                 atomicAdd(t + 2, static_cast<double>(c2));
                 atomicAdd(t + 3, static_cast<double>(c3));
             } else {
-                T* g = cell_sums + 4 * (static_cast<size_t>(ic) + gw * jc);
+                T* g = cell_sums + 4 * sums_index(ic, jc, nr);
                 atomicAdd(g, c0);
                 atomicAdd(g + 1, c1);
                 atomicAdd(g + 2, c2);
                 atomicAdd(g + 3, c3);
-                ++my_spill;
+                if (inside) ++my_spill;     // a point outside the unit square is not a sign of stale bins
             }
         }
     }
@@ -203,8 +239,8 @@ __global__ __launch_bounds__(kSumsThreads) void cell_sums_kernel(ParticleArrays<
         const int lj = k / (LW * 4);
         const int rem = k - lj * (LW * 4);
         const int gi = i0 + (rem >> 2), gj = j0 + lj;
-        if (gi < 0 || gi > nr || gj < 0 || gj > nz) continue;
-        atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(v));
+        if (!sums_holds(gi, gj, nr, nz)) continue;
+        atomicAdd(cell_sums + 4 * sums_index(gi, gj, nr) + (rem & 3), static_cast<T>(v));
     }
     if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
 }
@@ -229,7 +265,6 @@ __global__ __launch_bounds__(kSumsThreads) void cic_sums_kernel(ParticleArrays<T
     const int j0 = static_cast<int>(w.tile / ntx) * kTileSide - kTileHalo;
     for (int k = threadIdx.x; k < LW * LW * 4; k += BS) tile[k] = 0.0;
     __syncthreads();
-    const size_t gw = static_cast<size_t>(nr) + 1;
     unsigned int my_spill = 0;
     const size_t first = (static_cast<size_t>(w.begin) / PPT) * PPT;
     for (size_t base = first + static_cast<size_t>(threadIdx.x) * PPT; base < w.end; base += BS * PPT) {
@@ -272,7 +307,7 @@ __global__ __launch_bounds__(kSumsThreads) void cic_sums_kernel(ParticleArrays<T
 #pragma unroll
                         for (int c = 0; c < 4; ++c) atomicAdd(t + c, static_cast<double>(col[c] * wgt));
                     } else {
-                        T* g = cell_sums + 4 * (static_cast<size_t>(ii) + gw * j);
+                        T* g = cell_sums + 4 * sums_index(ii, j, nr);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) atomicAdd(g + c, col[c] * wgt);
                         spilled_here = true;
@@ -289,8 +324,8 @@ __global__ __launch_bounds__(kSumsThreads) void cic_sums_kernel(ParticleArrays<T
         const int lj = k / (LW * 4);
         const int rem = k - lj * (LW * 4);
         const int gi = i0 + (rem >> 2), gj = j0 + lj;
-        if (gi < 0 || gi > nr || gj < 0 || gj > nz) continue;
-        atomicAdd(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(v));
+        if (!sums_holds(gi, gj, nr, nz)) continue;
+        atomicAdd(cell_sums + 4 * sums_index(gi, gj, nr) + (rem & 3), static_cast<T>(v));
     }
     if (my_spill) atomicAdd(spilled, static_cast<unsigned long long>(my_spill));
 }
@@ -313,13 +348,12 @@ __global__ __launch_bounds__(256) void stamp_finish_kernel(const T* __restrict__
     __shared__ T g[LW * LW * 4];
     __shared__ float w[kStampCells];
     const int i0 = blockIdx.x * OT, j0 = blockIdx.y * OT;
-    const size_t gw = static_cast<size_t>(nr) + 1;
     for (int k = threadIdx.x; k < kStampCells; k += 256) w[k] = stamp[k];
     for (int k = threadIdx.x; k < LW * LW; k += 256) {
         const int lj = k / LW, li = k - lj * LW;
         const int gi = i0 - kStampReach + li, gj = j0 - kStampReach + lj;
         T v[4] = { 0, 0, 0, 0 };
-        if (gi >= 0 && gi <= nr && gj >= 0 && gj <= nz) load4(cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj), v);
+        if (sums_holds(gi, gj, nr, nz)) load4(cell_sums + 4 * sums_index(gi, gj, nr), v);
         g[4 * k] = v[0]; g[4 * k + 1] = v[1]; g[4 * k + 2] = v[2]; g[4 * k + 3] = v[3];
     }
     __syncthreads();
@@ -538,11 +572,16 @@ __global__ __launch_bounds__(256) void set_rand_kernel(const float* __restrict__
 template <typename T, typename Out>
 __global__ __launch_bounds__(256) void get_vec3_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                        const T* __restrict__ c, const uint32_t* __restrict__ id,
-                                                       size_t n, size_t chunk_begin, size_t chunk_n, Out* __restrict__ aos)
+                                                       size_t n, size_t chunk_begin, size_t chunk_n, Out* __restrict__ aos,
+                                                       size_t first = 0, size_t stride = 1)
 {
+    // slot k of the output = the caller's particle first + k * stride (a ranged or sampled read-back); this launch
+    // fills slots [chunk_begin, chunk_begin + chunk_n)
     const size_t s = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    const size_t i = id[s];
+    size_t i = id[s];
+    if (i < first || (i - first) % stride) return;
+    i = (i - first) / stride;
     if (i < chunk_begin || i >= chunk_begin + chunk_n) return;
     Out* o = aos + 3 * (i - chunk_begin);
     o[0] = static_cast<Out>(a[s]); o[1] = static_cast<Out>(b[s]); o[2] = static_cast<Out>(c[s]);

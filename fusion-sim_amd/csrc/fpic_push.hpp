@@ -39,11 +39,12 @@ struct PushArgs {
     int nr, nz;
     T step_factor;
     unsigned long long n;
-    int nsub;              // even: two sub-steps per step() call
+    int nsub;              // two sub-steps per step() call; fpic_substeps() may pass any count
     // counter-based RNG extension (CTR kernels): nothing random is stored per particle
     const uint32_t* id;    // the caller's particle index = the generator's stream
     uint32_t seed_lo, seed_hi;
     unsigned long long t0; // global index of this launch's first sub-step
+    int raster_bits;       // spec.raster_subpixel_bits: 0 = ideal point sprites, b = drawn as a rasteriser with b sub-pixel bits does
 };
 
 // Philox4x32-10 (Salmon et al., SC'11; Random123 constants).  Extension mode only:
@@ -76,7 +77,7 @@ struct TileArgs {
     uint32_t ntiles;                   // real tiles + 1 bin for clipped particles
     const BlockWork* work;             // chunks of the CURRENT particle order
     const uint32_t* nwork;
-    T* cell_sums;                      // FUSE: (nr+1) x (nz+1) x 4, zeroed by the host
+    T* cell_sums;                      // FUSE: sums_cells(nr, nz) x 4 (fpic_internal.hpp), zeroed by the host
     unsigned long long* spilled;       // FUSE: particles summed outside their LDS window
     uint32_t* tile_count;              // FUSE: census of final states per tile, zeroed by the host
     // SCATTER (re-binning launch): the other particle set and its bin table
@@ -292,14 +293,15 @@ struct WindowSums {
     FPIC_LDS uint32_t* lcensus;  // [kNbrSlots]
     int i0, j0;                  // window origin (tile origin - kTileHalo)
     TileNeighbourhood nb;
-    T* cell_sums;                // global (nr+1) x (nz+1) x 4
+    T* cell_sums;                // global sums_cells(nr, nz) x 4
     uint32_t* tile_count;        // global census
     unsigned* spilled;           // lane-local count of particles outside the window
     unsigned* own_census;        // lane-local count of final states in the workgroup's own tile
+    int raster_bits;             // 0: ideal sprites; b: the sprite's cell as a rasteriser with b sub-pixel bits places it
     __device__ __forceinline__ void add(const Particle<T>& q, int nr, int nz) const
     {
         int ic = 0, jc = 0;
-        const bool visible = sprite_cell(q, nr, nz, ic, jc);
+        bool visible = sprite_cell(q, nr, nz, ic, jc);   // the bins always follow the ideal cell
         uint32_t key;
         const int s = nb.slot(visible, ic, jc, key);
         // nearly every particle is still in the workgroup's own tile: those are counted in a register (64 lanes
@@ -307,7 +309,10 @@ struct WindowSums {
         if (s == kOwnSlot) ++*own_census;
         else if (s >= 0) __hip_atomic_fetch_add(lcensus + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAdd(tile_count + key, 1u);
-        if (!SUMS || !visible) return;
+        if (!SUMS) return;
+        const bool inside = visible;
+        if (raster_bits) visible = raster_cell(q.r, q.z, nr, nz, raster_bits, ic, jc);   // uniform branch
+        if (!visible) return;
         const T dx = q.x / q.r, dy = q.y / q.r;
         const T c0 = static_cast<T>(0.001) * (q.vx * dx + q.vy * dy);
         const T c1 = static_cast<T>(0.001) * (q.vy * dx - q.vx * dy);
@@ -322,12 +327,12 @@ struct WindowSums {
             // LDS atomic); the flush turns n into n * 0.001 once
             __hip_atomic_fetch_add((FPIC_LDS uint32_t*)(t + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            T* g = cell_sums + 4 * (static_cast<size_t>(ic) + (static_cast<size_t>(nr) + 1) * jc);
+            T* g = cell_sums + 4 * sums_index(ic, jc, nr);
             atomicAdd(g, c0);
             atomicAdd(g + 1, c1);
             atomicAdd(g + 2, c2);
             atomicAdd(g + 3, static_cast<T>(0.001) * static_cast<T>(1));
-            ++*spilled;
+            if (inside) ++*spilled;     // a point outside the unit square says nothing about the bins' age
         }
     }
 };
@@ -375,8 +380,10 @@ __device__ __forceinline__ void advance_state(const PushArgs<T>& a, const Tables
     for (int s = 0; s < a.nsub; s += 2) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) substep<T, CTR>(q[k], a, tab, a.t0 + s);
+        if (s + 1 < a.nsub) { // fpic_substeps() may ask for an odd number of sub-steps
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) substep<T, CTR>(q[k], a, tab, a.t0 + s + 1);
+            for (int k = 0; k < PPT; ++k) substep<T, CTR>(q[k], a, tab, a.t0 + s + 1);
+        }
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
             Particle<T> q[PPT];
             load_state<T, CTR>(a, base, cnt, q);
             if constexpr (FUSE)
-                advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill, &my_own }, cnt, q);
+                advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill, &my_own, a.raster_bits }, cnt, q);
             else
                 advance_state<T, CTR>(a, tab, NoSums{}, cnt, q);
             store_state<T, CTR>(a, base, cnt, q);
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
                     if (own) dest[k] = lrange[kOwnSlot] + wave_base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
                 }
             }
-            advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill, &my_own }, cnt, q);
+            advance_state<T, CTR>(a, tab, WindowSums<T, SUMS>{ lsums, lcensus, ti0 - kTileHalo, tj0 - kTileHalo, nb, t.cell_sums, t.tile_count, &my_spill, &my_own, a.raster_bits }, cnt, q);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 if (k < cnt) {
@@ -633,7 +640,6 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
         __syncthreads();
         // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
         // global addresses, so a wave's atomic is one 256-byte piece
-        const size_t gw = static_cast<size_t>(a.nr) + 1;
         for (int k = threadIdx.x; SUMS && k < SW * SW * 4; k += kPushThreads) {
             const int lj = k / (SW * 4);
             const int rem = k - lj * (SW * 4);
@@ -642,8 +648,8 @@ __global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a,
                 val = static_cast<double>(*(FPIC_LDS uint32_t*)(lsums + k)) * static_cast<double>(static_cast<T>(0.001) * static_cast<T>(1));
             if (val == 0.0) continue;
             const int gi = ti0 - kTileHalo + (rem >> 2), gj = tj0 - kTileHalo + lj;
-            if (gi < 0 || gi > a.nr || gj < 0 || gj > a.nz) continue;
-            atomicAdd(t.cell_sums + 4 * (static_cast<size_t>(gi) + gw * gj) + (rem & 3), static_cast<T>(val));
+            if (!sums_holds(gi, gj, a.nr, a.nz)) continue;
+            atomicAdd(t.cell_sums + 4 * sums_index(gi, gj, a.nr) + (rem & 3), static_cast<T>(val));
         }
         if (threadIdx.x < kNbrSlots) {
             const uint32_t c = lcensus[threadIdx.x];

@@ -39,7 +39,7 @@ ABI_FUNCTIONS = [
     "fpic_get_stream", "fpic_sort", "fpic_sync", "fpic_profile", "fpic_get_stats", "fpic_reset_stats",
     "fpic_get_substep_counter", "fpic_set_substep_counter", "fpic_save_checkpoint", "fpic_load_checkpoint",
     "fpic_add_species", "fpic_set_particles_of", "fpic_get_particles_of", "fpic_get_cells_of", "fpic_add_b",
-    "fpic_set_field3", "fpic_read_field3", "fpic_set_particles_range",
+    "fpic_set_field3", "fpic_read_field3", "fpic_set_particles_range", "fpic_get_particles_range", "fpic_get_cells_range",
     "fpic_comm_unique_id", "fpic_comm_init", "fpic_comm_destroy", "fpic_comm_info", "fpic_comm_set_overlap",
     "fpic_domain_init", "fpic_domain_set_particles", "fpic_domain_get_particles", "fpic_domain_stats",
     "fpic_group_precalc", "fpic_group_step", "fpic_group_density",
@@ -61,7 +61,7 @@ class Spec(ctypes.Structure):
         ("unfused_deposit", ctypes.c_int32), ("rng_mode", ctypes.c_int32), ("rng_seed_lo", ctypes.c_uint32),
         ("rng_seed_hi", ctypes.c_uint32), ("geometry", ctypes.c_int32), ("solver", ctypes.c_int32), ("ny", ctypes.c_int32),
         ("shape", ctypes.c_int32), ("length_y", ctypes.c_double), ("macro_weight", ctypes.c_double),
-        ("reserved", ctypes.c_double * 6),
+        ("raster_subpixel_bits", ctypes.c_int32), ("reserved_i32", ctypes.c_int32), ("reserved", ctypes.c_double * 5),
     ]
 
 
@@ -147,6 +147,8 @@ def load_library(path=None):
     lib.fpic_get_particles_of.argtypes = [vp, ci, vp, vp, ci]
     lib.fpic_set_particles_range.argtypes = [vp, ci, ctypes.c_uint64, ctypes.c_uint64, vp, vp, ci]
     lib.fpic_get_cells_of.argtypes = [vp, ci, vp]
+    lib.fpic_get_particles_range.argtypes = [vp, ci, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp, vp, ci]
+    lib.fpic_get_cells_range.argtypes = [vp, ci, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp]
     lib.fpic_add_b.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     lib.fpic_set_field3.argtypes = [vp, ci, vp, ci, ci, ci, ci]
     lib.fpic_read_field3.argtypes = [vp, ci, vp, ci]
@@ -204,7 +206,7 @@ class CylindricalParticlePusher:
     """Object returned by makeCylindricalParticlePusher (empic.js:1528)."""
 
     def __init__(self, spec, precision="fp32", device=0, count=0, compat=True, sort_interval=0, fuse_deposit=True,
-                 rng="reference", seed=0, library=None, shape="ref11"):
+                 rng="reference", seed=0, library=None, shape="ref11", raster_subpixel_bits=0):
         _validate_spec(spec)
         self._lib = library or load_library()
         self.spec = dict(spec)
@@ -221,6 +223,8 @@ class CylindricalParticlePusher:
         s.unfused_deposit = 2 if fuse_deposit == "census" else (0 if fuse_deposit else 1)
         s.rng_mode = {"reference": 0, "counter": 1}[rng]
         s.shape = {"ref11": 0, "cic": 1}[spec.get("shape", shape)]   # SURVEY 8(b) extension key
+        # density()'s point sprites as a rasteriser with that many sub-pixel bits draws them (0 / absent: ideal sprites)
+        s.raster_subpixel_bits = int(spec.get("raster_subpixel_bits", raster_subpixel_bits))
         s.rng_seed_lo, s.rng_seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
         self.precision = s.precision
         self.nr, self.nz = int(spec["nr"]), int(spec["nz"])
@@ -561,6 +565,18 @@ class ElectrostaticBoxPusher:
     def getCells(self, species=0):
         out = np.empty(self.counts[species], dtype=np.int32)
         self._check(self._lib.fpic_get_cells_of(self._h, species, out.ctypes.data))
+        return out
+
+    def getRange(self, first, count, stride=1, dtype=None, species=0, cells=False):
+        """The caller's particles first, first + stride, ... (`count` of them): the mirror of setRange and a sampled
+        read-back (fpic_get_particles_range); cells=True adds their node cells."""
+        code = self.precision if dtype is None else (F32 if np.dtype(dtype) == np.float32 else F64)
+        out = {"position": np.empty((count, 3), dtype=_np_dtype(code)), "velocity": np.empty((count, 3), dtype=_np_dtype(code))}
+        self._check(self._lib.fpic_get_particles_range(self._h, species, int(first), int(count), int(stride),
+                                                       out["position"].ctypes.data, out["velocity"].ctypes.data, code))
+        if cells:
+            out["cells"] = np.empty(count, dtype=np.int32)
+            self._check(self._lib.fpic_get_cells_range(self._h, species, int(first), int(count), int(stride), out["cells"].ctypes.data))
         return out
 
     def readField(self, which, dtype=None):

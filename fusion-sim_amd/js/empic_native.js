@@ -27,6 +27,9 @@
  * and sub-step instead of the reference's entropy-table generator; not the reference's
  * random stream).
  * shape 'cic' replaces density()'s 11x11 sprite by a bilinear deposit on the four nearest cell centres (extension).
+ * raster_subpixel_bits b (1..8) draws density()'s point sprites as a rasteriser with b sub-pixel bits does (snapped window
+ * positions, cropped instead of discarded outside the target); 4 reproduces the reference under Chromium's SwiftShader bit
+ * for bit, absent / 0 = ideal sprites (include/fusionpic.h).
  * geometry 'cart3d' (+ ny, length_y, solver 'poisson_fft'|'none', macro_weight) selects the self-consistent
  * electrostatic box — an extension with no reference counterpart (include/fusionpic.h): radius, height are
  * then the box lengths along x and z, nr, nz the node counts; same method names, plus addSpecies, addB,
@@ -150,7 +153,7 @@ function makeBox(spec, lib) {
     const n0 = spec.count ? spec.count : spec.nparticles * spec.nparticles;
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass, spec.particle_charge,
         spec.count || 0, fp64 ? 1 : 0, spec.device || 0, 0, spec.sort_interval || 0, 0, 0, 0, 0,
-        1, spec.solver === 'none' ? 0 : (spec.solver === 'yee' ? 2 : 1), spec.ny, spec.length_y, spec.macro_weight === undefined ? 1 : spec.macro_weight, 0);
+        1, spec.solver === 'none' ? 0 : (spec.solver === 'yee' ? 2 : 1), spec.ny, spec.length_y, spec.macro_weight === undefined ? 1 : spec.macro_weight, 0, 0);
     const nx = spec.nr, ny = spec.ny, nz = spec.nz, nodes = nx * ny * nz;
     const counts = [n0];
     const Real = fp64 ? Float64Array : Float32Array;
@@ -191,8 +194,17 @@ function makeBox(spec, lib) {
         return r;
     };
     out.getCells = function (buf, species) { const n = counts[species || 0]; return lib.getCellsOf(h, species || 0, checkLength(buf, n, 'cells') || new Int32Array(n)); };
+    // the mirror of setRange, and a sampled read-back: the caller's particles first, first + stride, ... (count of them;
+    // stride 1 = the range [first, first + count)); 2e9 particles do not fit one typed array
+    out.getRange = function (first, count, into, species, stride) {
+        const r = into || { position: new Real(3 * count), velocity: new Real(3 * count) };
+        checkLength(r.position, 3 * count, 'position'); checkLength(r.velocity, 3 * count, 'velocity');
+        lib.getParticlesRange(h, species || 0, first, stride === undefined ? 1 : stride, r.position || null, r.velocity || null);
+        return r;
+    };
     out.commInit = function (id, rank, world, overlap) { lib.commInit(h, id, rank, world, overlap === false ? 0 : 1); };
     out.commDestroy = function () { lib.commDestroy(h); };
+    out.commInfo = function () { return lib.commInfo(h); };                  // { rank, world } as the library sees them
     // z-slab decomposition (this process = rank `rank` of `world`, after commInit with the same numbers): the rank's
     // particles arrive through domainSet with their global indices; step() then exchanges ghost planes, halos and
     // migrating particles with the neighbours inside the library
@@ -231,7 +243,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
         radius: 'number', height: 'number', nr: 'number', nz: 'number', dt: 'number',
         nparticles: 'number', particle_mass: 'number', particle_charge: 'number',
         precision: [, 'string'], device: [, 'number'], count: [, 'number'], compat: [, 'boolean'],
-        sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'], geometry: [, 'string'], shape: [, 'string'],
+        sort_interval: [, 'number'], rng: [, 'string'], seed: [, 'number'], geometry: [, 'string'], shape: [, 'string'], raster_subpixel_bits: [, 'number'],
     });
     if (spec.devices !== undefined) {   // SURVEY 8(b) extension key: one process drives one GPU here; N GPUs are N processes (commInit)
         if (!Array.isArray(spec.devices) || spec.devices.length !== 1 || typeof spec.devices[0] !== 'number') {
@@ -259,7 +271,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
     let h = lib.create(spec.radius, spec.height, spec.nr, spec.nz, spec.dt, spec.nparticles, spec.particle_mass,
         spec.particle_charge, spec.count || 0, fp64 ? 1 : 0, spec.device || 0, spec.compat === false ? 1 : 0,
         spec.sort_interval || 0, spec.fuse_deposit === 'census' ? 2 : (spec.fuse_deposit === false ? 1 : 0), spec.rng === 'counter' ? 1 : 0,
-        seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296, 0, 0, 0, 0, 0, spec.shape === 'cic' ? 1 : 0);
+        seed % 4294967296, Math.floor(seed / 4294967296) % 4294967296, 0, 0, 0, 0, 0, spec.shape === 'cic' ? 1 : 0, spec.raster_subpixel_bits || 0);
     const nr = spec.nr, nz = spec.nz;
     const Real = fp64 ? Float64Array : Float32Array;
     const out = {};
@@ -309,6 +321,7 @@ exports.makeCylindricalParticlePusher = function (spec) {
     };
     out.commInit = function (id, rank, world, overlap) { lib.commInit(h, id, rank, world, overlap === false ? 0 : 1); };
     out.commDestroy = function () { lib.commDestroy(h); };
+    out.commInfo = function () { return lib.commInfo(h); };                  // { rank, world } as the library sees them
     out.saveCheckpoint = function (path) { lib.saveCheckpoint(h, String(path)); };
     out.loadCheckpoint = function (path) { lib.loadCheckpoint(h, String(path)); };
     out.sort = function () { lib.sort(h); };

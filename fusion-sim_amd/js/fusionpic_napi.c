@@ -136,13 +136,14 @@ static napi_value undefined(napi_env env)
 }
 
 /* create(radius, height, nr, nz, dt, nparticles, mass, charge, count, precision, device, physical_a,
- *        sort_interval, unfused_deposit, rng_mode, seed_lo, seed_hi, geometry, solver, ny, length_y, macro_weight, shape) */
+ *        sort_interval, unfused_deposit, rng_mode, seed_lo, seed_hi, geometry, solver, ny, length_y, macro_weight, shape,
+ *        raster_subpixel_bits) */
 static napi_value n_create(napi_env env, napi_callback_info info)
 {
-    napi_value argv[23];
-    if (!get_args(env, info, 23, argv, NULL)) return NULL;
-    double d[23];
-    for (int i = 0; i < 23; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
+    napi_value argv[24];
+    if (!get_args(env, info, 24, argv, NULL)) return NULL;
+    double d[24];
+    for (int i = 0; i < 24; ++i) if (!get_double(env, argv[i], &d[i])) return NULL;
     fpic_spec s;
     memset(&s, 0, sizeof s);
     s.radius = d[0]; s.height = d[1]; s.nr = (int32_t)d[2]; s.nz = (int32_t)d[3]; s.dt = d[4];
@@ -151,6 +152,7 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     s.physical_a = (int32_t)d[11]; s.sort_interval = (int32_t)d[12]; s.unfused_deposit = (int32_t)d[13];
     s.rng_mode = (int32_t)d[14]; s.rng_seed_lo = (uint32_t)d[15]; s.rng_seed_hi = (uint32_t)d[16];
     s.geometry = (int32_t)d[17]; s.solver = (int32_t)d[18]; s.ny = (int32_t)d[19]; s.length_y = d[20]; s.macro_weight = d[21]; s.shape = (int32_t)d[22];
+    s.raster_subpixel_bits = (int32_t)d[23];
     fpic_handle* h = NULL;
     if (fpic_create(&s, &h) != FPIC_OK) return throw_fpic(env, NULL);
     box_t* b = (box_t*)malloc(sizeof *b);
@@ -523,6 +525,48 @@ static napi_value n_get_particles_of(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+/* getParticlesRange(h, species, first, stride, position|null, velocity|null): the caller's particles first, first + stride, ...
+ * — as many as the arrays hold (len / 3) */
+static napi_value n_get_particles_range(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6]; fpic_handle* h; int sp; double first, stride;
+    if (!get_args(env, info, 6, argv, &h)) return NULL;
+    if (!get_species(env, argv[1], &sp) || !get_double(env, argv[2], &first) || !get_double(env, argv[3], &stride)) return NULL;
+    napi_typedarray_type t[2]; void* p[2]; size_t len[2] = { 0, 0 }; int dtype = -1;
+    for (int k = 0; k < 2; ++k) {
+        if (!get_typed(env, argv[4 + k], &t[k], &p[k], &len[k])) return NULL;
+        if (!p[k]) continue;
+        int d2;
+        if (!float_dtype(env, t[k], &d2)) return NULL;
+        if (dtype >= 0 && d2 != dtype) { napi_throw_type_error(env, NULL, "position and velocity must have the same element type"); return NULL; }
+        dtype = d2;
+        if (len[k] % 3) { napi_throw_range_error(env, NULL, ".position <- length must be a multiple of 3"); return NULL; }
+    }
+    if (dtype < 0) return undefined(env);
+    if (p[0] && p[1] && len[0] != len[1]) { napi_throw_range_error(env, NULL, ".velocity <- must be as long as .position"); return NULL; }
+    const size_t m = (p[0] ? len[0] : len[1]) / 3, have = g_box->count[sp];
+    if (first < 0 || stride < 1 || (m && ((size_t)first >= have || (m - 1) > (have - 1 - (size_t)first) / (size_t)stride))) {
+        napi_throw_range_error(env, NULL, ".position <- range lies outside the species");
+        return NULL;
+    }
+    if (fpic_get_particles_range(h, sp, (uint64_t)first, m, (uint64_t)stride, p[0], p[1], dtype) != FPIC_OK) return throw_fpic(env, h);
+    return undefined(env);
+}
+
+/* commInfo(h) -> { rank, world } of the communicator the handle has joined ({0, 1} without one) */
+static napi_value n_comm_info(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1]; fpic_handle* h;
+    if (!get_args(env, info, 1, argv, &h)) return NULL;
+    int rank = 0, world = 1;
+    if (fpic_comm_info(h, &rank, &world) != FPIC_OK) return throw_fpic(env, h);
+    napi_value out, v;
+    napi_create_object(env, &out);
+    napi_create_int32(env, rank, &v); napi_set_named_property(env, out, "rank", v);
+    napi_create_int32(env, world, &v); napi_set_named_property(env, out, "world", v);
+    return out;
+}
+
 static napi_value n_get_cells_of(napi_env env, napi_callback_info info)
 {
     napi_value argv[3]; fpic_handle* h; int sp;
@@ -697,7 +741,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "getCells", n_get_cells }, { "sort", n_sort }, { "sync", n_sync }, { "profile", n_profile },
         { "getStats", n_get_stats }, { "saveCheckpoint", n_save_checkpoint }, { "loadCheckpoint", n_load_checkpoint }, { "resetStats", n_reset_stats }, { "buildArch", n_build_arch },
         { "addSpecies", n_add_species }, { "setParticlesRange", n_set_particles_range }, { "getParticlesOf", n_get_particles_of },
-        { "getCellsOf", n_get_cells_of }, { "addB", n_add_b }, { "setField3", n_set_field3 }, { "readField3", n_read_field3 },
+        { "getCellsOf", n_get_cells_of }, { "getParticlesRange", n_get_particles_range }, { "commInfo", n_comm_info }, { "addB", n_add_b }, { "setField3", n_set_field3 }, { "readField3", n_read_field3 },
         { "commUniqueId", n_comm_unique_id }, { "commInit", n_comm_init }, { "commDestroy", n_comm_destroy },
         { "domainInit", n_domain_init }, { "domainSetParticles", n_domain_set_particles }, { "domainGetParticles", n_domain_get_particles },
         { "domainStats", n_domain_stats },

@@ -129,7 +129,8 @@ typedef enum fpic_field3 {
 
 /* Device buffers whose address can be handed to a collective (see fpic_device_buffer). */
 typedef enum fpic_buffer {
-    FPIC_BUF_CELL_SUMS = 0, /* per-cell sums 0.001*(vr,vtheta,vz,1), (nr+1)*(nz+1)*4 scalars */
+    FPIC_BUF_CELL_SUMS = 0, /* per-cell sums 0.001*(vr,vtheta,vz,1), (nr+11)*(nz+11)*4 scalars: sprite-centre cell (ic, jc),
+                               ic in -5..nr+5, at 4*((ic+5) + (nr+11)*(jc+5)); opaque to a host that only sums it over ranks */
     FPIC_BUF_RHO_FIXED = 1  /* CART3D: int64 charge accumulators, nr*ny*nz */
 } fpic_buffer;
 
@@ -172,7 +173,18 @@ typedef struct fpic_spec {
     int32_t shape;          /* fpic_shape of density() on the (r,z) grid; CART3D always deposits CIC */
     double length_y;        /* CART3D: box is radius (x) x length_y x height (z) metres */
     double macro_weight;    /* CART3D: real particles per macro-particle (charge density scale); 0 = 1 */
-    double reserved[6];
+    int32_t raster_subpixel_bits; /* density()'s point sprites (empic.js:980-1035, :1473-1478) on the (r,z) grid.
+                               0: ideal sprites — window coordinates of infinite precision, a point whose centre lies
+                               outside the clip volume is discarded whole (the GL ES 2.0 text).
+                               b = 1..8: as a rasteriser with b sub-pixel bits draws them — window position snapped to
+                               2^-b pixel (round half to even, y running downwards), left/top edges inclusive, a point whose
+                               centre has left the target cropped instead of discarded.  b = 4 reproduces the reference
+                               run under Chromium's ANGLE/SwiftShader bit for bit (tests/golden/webgl_*); desktop GPUs
+                               usually have 8.  Only the cell a particle's 11x11 stamp is centred on changes (one cell
+                               lower for a coordinate within 2^-(b+1) pixel above a pixel edge).  Carved out of the
+                               former reserved[6]: same size and offsets, ABI unchanged */
+    int32_t reserved_i32;
+    double reserved[5];
 } fpic_spec;
 
 typedef struct fpic_handle fpic_handle;
@@ -292,6 +304,13 @@ int fpic_set_particles_of(fpic_handle* h, int species, const void* pos_aos, cons
 int fpic_set_particles_range(fpic_handle* h, int species, uint64_t first, uint64_t n, const void* pos_aos, const void* vel_aos, int dtype);
 int fpic_get_particles_of(fpic_handle* h, int species, void* pos_aos, void* vel_aos, int dtype);
 int fpic_get_cells_of(fpic_handle* h, int species, int32_t* cells);
+/* The mirror of fpic_set_particles_range, and a sampled read-back: the caller's particles first, first + stride,
+ * first + 2 stride, ... — n of them (stride >= 1; stride 1 = the contiguous range [first, first + n)) — in the caller's
+ * order, pos_aos / vel_aos [n][3] of dtype (either may be NULL).  The reference can only display its particles
+ * (fusionsim.js:174-178; utilities.js:701-711 has readPixels, unused): 2e9 particles are 48 / 96 GB of host arrays, so a
+ * host reads them piecewise or samples them (every 20 000th particle of BASELINE configs[4] for the oracle comparison). */
+int fpic_get_particles_range(fpic_handle* h, int species, uint64_t first, uint64_t n, uint64_t stride, void* pos_aos, void* vel_aos, int dtype);
+int fpic_get_cells_range(fpic_handle* h, int species, uint64_t first, uint64_t n, uint64_t stride, int32_t* cells);
 /* uniform external B (T), additive like the reference's painters (empic.js:1391-1400) */
 int fpic_add_b(fpic_handle* h, double bx, double by, double bz);
 /* which = FPIC_F3_E only: value[i][j][k][3] flattened, dims must equal the handle's */

@@ -318,7 +318,7 @@ def scene_demo(br, ref, out_dir, frames=3, stride=61):
                 blob.put(key + "@window", img[b0:b1, a0:a1])
             elif key.startswith("precalc") or key.startswith("painted"):
                 blob.put(key + "@rows", a.reshape(nz, nr, 4)[::53])     # every 53rd z row of the whole texture
-                if key.startswith("precalc"):
+                if key.startswith("precalc") or key == "painted/B":
                     blob.put(key + "@window", a.reshape(nz, nr, 4)[j0:j1, i0:i1])
         meta["sha256"] = digests
         meta["sha256_rule"] = "SHA-256 of the little-endian float32 bytes with every NaN replaced by 0x7FC00000"

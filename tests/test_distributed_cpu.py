@@ -1,8 +1,8 @@
 """N > 1 host logic on CPU: two gloo ranks each own a shard of the particles, scatter
 their shard, all-reduce the per-cell sums, and finish; the result must equal the
 single-rank result.  The oracle stands in for the per-rank push; the deposit runs in the
-library's two stages and the exchanged buffer has the library's shape ((nr+1)(nz+1)*4 per-cell
-sums, then the stamp) — the sharding + exchange logic of fusionpic.multi and of fpic_density()
+library's two stages and the exchanged buffer has the library's shape ((nr+11)(nz+11)*4 per-cell
+sums: the (nr+1) x (nz+1) sprite-centre cells and the 5-cell apron of csrc/fpic_internal.hpp, then the stamp) — the sharding + exchange logic of fusionpic.multi and of fpic_density()
 under a communicator."""
 import os
 import socket
@@ -37,7 +37,7 @@ def test_shard_bounds_cover_everything():
 class OracleRank:
     """Per-rank pusher for the CPU test: oracle compute for the push, and the deposit in the TWO STAGES the
     HIP path uses: stage 1 forms the per-cell sums of the vertex colour 0.001*(vr,vtheta,vz,1)
-    on the (nr+1) x (nz+1) grid — the buffer a multi-GPU run all-reduces (FPIC_BUF_CELL_SUMS, same shape and
+    on the (nr+1) x (nz+1) grid inside its 5-cell apron — the buffer a multi-GPU run all-reduces (FPIC_BUF_CELL_SUMS, same shape and
     layout) — stage 2 applies the 11x11 stamp and the normalise / EMA passes.  `sums` is the exchanged tensor."""
 
     def __init__(self, po, begin, end, scene):
@@ -46,9 +46,9 @@ class OracleRank:
         self.sim.set(B=B, position=pos[begin:end], velocity=vel[begin:end], sink_mask=sink, source_pdf=sink)
         self.sim.set_random_state(entropy, rand[begin:end])
         self.nr, self.nz = SPEC["nr"], SPEC["nz"]
-        self.cell_sums = np.zeros((self.nz + 1, self.nr + 1, 4))          # index 4*(i + (nr+1)*j) + c, as the library's buffer
+        self.cell_sums = np.zeros((self.nz + 11, self.nr + 11, 4))        # index 4*((i+5) + (nr+11)*(j+5)) + c, as the library's buffer
         self.sums = torch.from_numpy(self.cell_sums.reshape(-1))           # aliases it: what the all-reduce sees
-        assert self.sums.numel() == (self.nr + 1) * (self.nz + 1) * 4
+        assert self.sums.numel() == (self.nr + 11) * (self.nz + 11) * 4
 
     def precalc(self): self.sim.precalc()
     def step(self, n=1): self.sim.step(n)
@@ -63,13 +63,13 @@ class OracleRank:
         colour = 0.001 * np.stack([v[:, 0] * dx + v[:, 1] * dy, v[:, 1] * dx - v[:, 0] * dy, v[:, 2], np.ones_like(r)], axis=1)
         flat = self.cell_sums.reshape(-1, 4)
         flat[:] = 0
-        np.add.at(flat, cells[keep], colour[keep])
+        ic, jc = cells[keep] % (self.nr + 1), cells[keep] // (self.nr + 1)
+        np.add.at(flat, (ic + 5) + (self.nr + 11) * (jc + 5), colour[keep])
 
     def densityFinish(self):
         """stage 2: moments01 = stamp (*) cell sums cropped to the grid (empic.js:1473-1478), then K5/K6/K7"""
         w = self.sim.stamp.reshape(11, 11).astype(np.float64)              # index [b][a] = a + 11*b
-        padded = np.zeros((self.nz + 1 + 10, self.nr + 1 + 10, 4))
-        padded[5:-5, 5:-5] = self.cell_sums
+        padded = self.cell_sums                                            # the apron is the stamp's reach
         out = np.zeros((self.nz, self.nr, 4))
         for b in range(11):
             for a in range(11):

@@ -202,20 +202,38 @@ def test_configs3_at_full_size(fp, eo, bench):
     torch.cuda.empty_cache()
 
 
+def oracle_em_substep_on_a_sample(eo, spec, before, edge_e, face_b):
+    """one full-EM sub-step's push (em_nodes + em_push of oracle/es3d_oracle_impl.h) of the sampled particles `before`
+    (normalised positions, velocities as the library returned them) in the lattice fields read back beforehand"""
+    count = before["position"].shape[0]
+    ora = eo.OracleES3D(dict(spec, count=count), np.float64)
+    sp = ora.species[0]
+    for k, name in enumerate(("x", "y", "z")):
+        getattr(sp, name)[:] = before["position"][:, k]
+    for k, name in enumerate(("vx", "vy", "vz")):
+        getattr(sp, name)[:] = before["velocity"][:, k]
+    ora.Ey[:] = edge_e.ravel()
+    ora.By[:] = face_b.ravel()
+    ora.em_substep()      # nodes, push, current, field update: the particles are what is compared
+    return ora.positions(0), ora.velocities(0), ora.cells(0)
+
+
 def test_configs4_at_full_size(fp, eo, bench):
-    """BASELINE configs[4]'s lattice on one GPU: 512^3 Yee lattice, fp64, 1e9 electrons (the largest population that keeps
-    this test inside its time budget; 2e9 fits the card — DESIGN.md 4.5 — but doubles every pass).  Over one sub-step the
-    integer continuity equation holds at EVERY node: 96 (rho_fixed(n+1) - rho_fixed(n)) + div J_fixed = 0; Gauss's law
-    on the lattice stays at rounding level from precalc() through the steps."""
+    """BASELINE configs[4] AS STATED on one GPU: 512^3 Yee lattice, fp64, 2e9 electrons (233 GB of the card's 288).  Over
+    one sub-step the integer continuity equation holds at EVERY node: 96 (rho_fixed(n+1) - rho_fixed(n)) + div J_fixed = 0;
+    Gauss's law on the lattice stays at rounding level from precalc() through the steps; and the oracle itself on a
+    sample: the lattice fields are read back, every 20 000th particle is read with the ranged read-back
+    (fpic_get_particles_range: 2e9 fp64 particles would be 96 GB of host arrays), fpic_substeps(1) advances one sub-step,
+    and oracle/es3d_oracle's em_push moves the sample in that very field: positions, velocities, cells bit for bit."""
     import torch
-    n, grid = 1_000_000_000, 512
+    n, grid = 2_000_000_000, 512
     c, eps0, me, qe, vth, wp = 2.998e8, 8.8541878128e-12, 9.109e-31, -1.602e-19, 1e-3, 1e10
     dx = vth * c / wp
     L = grid * dx
     spec = dict(radius=L, length_y=L, height=L, nr=grid, ny=grid, nz=grid, dt=0.5 * dx / (c * 3 ** 0.5), nparticles=0, count=n, particle_mass=me,
                 particle_charge=qe, geometry="cart3d", solver="yee", macro_weight=wp ** 2 * eps0 * me / qe ** 2 * L ** 3 / n, precision="fp64")
     sim = fp.makeCylindricalParticlePusher(spec)
-    upload_generated(bench, sim, n, 16, L, vth)
+    upload_generated(bench, sim, n, 32, L, vth)
     sim.precalc()
     shape = (grid, grid, grid)
     dv = (L / grid) ** 3
@@ -239,7 +257,14 @@ def test_configs4_at_full_size(fp, eo, bench):
     sim.density()
     r0 = sim.readField(fp.F3_RHO_FIXED).copy()
     assert exact_sum(r0) == n * eo.FIXED_ONE
+    # the sample and the fields it is about to be pushed in
+    stride = 20000
+    count = n // stride
+    before = sim.getRange(0, count, stride)
+    assert float(before["position"].min()) >= 0.0 and float(before["position"].max()) < 1.0
+    edge_e, face_b = sim.readField(fp.F3_EDGE_E), sim.readField(fp.F3_FACE_B)
     sim.substeps(1)
+    after = sim.getRange(0, count, stride, cells=True)
     J = sim.readField(fp.F3_J_FIXED).reshape(grid, grid, grid, 3)
     sim.density()
     r1 = sim.readField(fp.F3_RHO_FIXED)
@@ -259,3 +284,151 @@ def test_configs4_at_full_size(fp, eo, bench):
     assert st["particle_updates"] == 5 * n
     sim.destroy()
     torch.cuda.empty_cache()
+    want_p, want_v, want_c = oracle_em_substep_on_a_sample(eo, spec, before, edge_e, face_b)
+    assert same_bits(after["position"], want_p)
+    assert same_bits(after["velocity"], want_v)
+    assert np.array_equal(after["cells"], want_c)
+    assert not same_bits(after["position"], before["position"])
+
+
+def test_configs4_decomposition_at_its_lattice(fp, eo, bench):
+    """The full-EM decomposition at configs[4]'s lattice (until now asserted at 64 x 64 x 128): 512^3
+    Yee lattice, fp64, 8 in-process ranks of 64 planes against ONE handle on a population that can sit beside it (2e8
+    electrons): after 3 frames (6 sub-steps, one migration) the integer current grid and both lattice fields on every
+    rank's planes and every particle are bit-identical to the one handle's, none lost."""
+    import torch
+    n, grid, world = 200_000_000, 512, 8
+    c, eps0, me, qe, vth, wp = 2.998e8, 8.8541878128e-12, 9.109e-31, -1.602e-19, 1e-3, 1e10
+    dx = vth * c / wp
+    L = grid * dx
+    spec = dict(radius=L, length_y=L, height=L, nr=grid, ny=grid, nz=grid, dt=0.5 * dx / (c * 3 ** 0.5), nparticles=0, count=n, particle_mass=me,
+                particle_charge=qe, geometry="cart3d", solver="yee", macro_weight=wp ** 2 * eps0 * me / qe ** 2 * L ** 3 / n, precision="fp64")
+    share = n // world
+    one = fp.makeCylindricalParticlePusher(spec)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(dict(spec, count=int(share * 1.25)))
+        s.domainInit(r, world, ghost_planes=2, migrate_every=4)
+        ranks.append(s)
+    for r in range(world):
+        p, v = bench.c4_rank_particles(r, world, 0, share, L, vth, 1.0, 0)
+        one.setRange(r * share, position=p, velocity=v)
+        ranks[r].domainSet(p, v, first_id=r * share)
+        del p, v
+    torch.cuda.empty_cache()
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+    one.step(3); group.step(3)
+    nzl = grid // world
+    for which in (fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B):
+        ref = one.readField(which).reshape(grid, -1)
+        for r, s in enumerate(ranks):
+            got = s.readField(which).reshape(grid, -1)[r * nzl:(r + 1) * nzl]
+            assert (np.array_equal if which == fp.F3_J_FIXED else same_bits)(got, ref[r * nzl:(r + 1) * nzl]), (which, r)
+            del got
+        del ref
+    ref = one.getParticles()
+    parts = [s.domainGet() for s in ranks]
+    ids = np.concatenate([p["ids"] for p in parts])
+    order = np.argsort(ids)
+    assert len(ids) == n and np.array_equal(ids[order], np.arange(n, dtype=np.uint32))
+    assert same_bits(np.concatenate([p["position"] for p in parts])[order], ref["position"])
+    assert same_bits(np.concatenate([p["velocity"] for p in parts])[order], ref["velocity"])
+    stats = [s.domainStats() for s in ranks]
+    assert sum(s["migrated"] for s in stats) > 0 and all(s["lost"] == 0 for s in stats), stats
+    for s in ranks + [one]:
+        s.destroy()
+    torch.cuda.empty_cache()
+
+
+def test_ranged_and_sampled_read_back(fp):
+    """fpic_get_particles_range / fpic_get_cells_range: every range and stride of a binned, stepped box equals the same
+    slice of the whole read-back (the caller's order, whatever the bins did); out-of-range requests are refused."""
+    rng = np.random.default_rng(3)
+    n, shape, L = 100_003, (32, 32, 16), (0.02, 0.02, 0.01)
+    spec = dict(radius=L[0], length_y=L[1], height=L[2], nr=shape[0], ny=shape[1], nz=shape[2], dt=2e-11, nparticles=0, count=n,
+                particle_mass=9.109e-31, particle_charge=-1.602e-19, geometry="cart3d", solver="poisson_fft", macro_weight=1e4)
+    for precision in ("fp32", "fp64"):
+        sim = fp.makeCylindricalParticlePusher(spec, precision=precision)
+        sim.set(position=rng.random((n, 3)) * L, velocity=rng.normal(0, 0.05, (n, 3)))
+        sim.precalc()
+        sim.step(2)
+        whole, cells = sim.getParticles(), sim.getCells()
+        for first, count, stride in ((0, n, 1), (5, 1000, 1), (17, 3000, 31), (n - 1, 1, 1), (0, (n + 19999) // 20000, 20000), (99_000, 0, 1)):
+            got = sim.getRange(first, count, stride, cells=True)
+            idx = first + stride * np.arange(count)
+            assert same_bits(got["position"], whole["position"][idx]) and same_bits(got["velocity"], whole["velocity"][idx])
+            assert np.array_equal(got["cells"], cells[idx])
+        other = np.float32 if precision == "fp64" else np.float64
+        got = sim.getRange(10, 50, 7, dtype=other)
+        assert np.array_equal(got["position"], whole["position"][10 + 7 * np.arange(50)].astype(other))
+        for bad in ((n, 1, 1), (0, n + 1, 1), (0, 2, n), (0, 1, 0)):
+            with pytest.raises(fp.FusionPicError):
+                sim.getRange(*bad)
+        sim.destroy()
+
+
+# ------------------------------------------------------------------------------------------- the solve where it runs
+
+EPS0 = 8.8541878128e-12
+
+
+def numpy_poisson(rho, L):
+    """phi of the 3-point-Laplacian Poisson problem in double with numpy's FFT: phi_hat = rho_hat / (eps0 K^2),
+    K^2 = sum_axis (2/d sin(pi m/n))^2, mean mode 0 (the definition in oracle/es3d_oracle_impl.h, not its code)."""
+    nz, ny, nx = rho.shape
+    hat = np.fft.rfftn(rho)
+    k2 = 0.0
+    for axis, (n, length, half) in enumerate(((nz, L[2], False), (ny, L[1], False), (nx, L[0], True))):
+        m = np.arange(n // 2 + 1) if half else np.arange(n)
+        term = (2.0 * n / length * np.sin(np.pi * m / n)) ** 2
+        shape = [1, 1, 1]
+        shape[axis] = term.size
+        k2 = k2 + term.reshape(shape)
+    k2[0, 0, 0] = 1.0
+    hat /= EPS0 * k2
+    hat[0, 0, 0] = 0.0
+    return np.fft.irfftn(hat, s=rho.shape)
+
+
+@pytest.mark.parametrize("n,precision", [(256, "fp32"), (256, "fp64"), (512, "fp32")])
+def test_poisson_solve_against_numpy_at_the_sizes_it_runs_at(fp, n, precision):
+    """the library's own FFT passes (csrc/fes_fft.hpp: 256- and 512-point Stockham sweeps, whose
+    launch shapes differ from the <= 64-point cases the oracle comparison reaches) asserted DIRECTLY at the grid sizes of
+    BASELINE configs[2] (256^3) and configs[3] / [4] (512^3), against an independent solve: numpy.fft.rfftn in double of
+    the library's own charge density, divided by the eigenvalues of the 3-point Laplacian.  phi within 2e-5 (fp32) /
+    1e-10 (fp64) of the largest potential; E = -grad phi by central differences of the library's own phi."""
+    rng = np.random.default_rng(n)
+    count = 100000
+    L = (0.7, 1.3, 0.9)
+    spec = dict(radius=L[0], length_y=L[1], height=L[2], nr=n, ny=n, nz=n, dt=1e-10, nparticles=0, count=count,
+                particle_mass=9.109e-31, particle_charge=-1.602e-19, geometry="cart3d", solver="poisson_fft", macro_weight=1e9)
+    sim = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    # a lumpy cloud: every wavelength from the box down to a few cells carries charge
+    centres = rng.random((40, 3))
+    pos = (centres[rng.integers(0, 40, count)] + rng.normal(0, 0.03, (count, 3)) * rng.random((count, 1))) % 1.0 * L
+    sim.set(position=pos, velocity=np.zeros((count, 3)))
+    sim.precalc()
+    rho = sim.readField(fp.F3_RHO, np.float64).reshape(n, n, n)          # [k][j][i]
+    fixed = sim.readField(fp.F3_RHO_FIXED)
+    assert exact_sum(fixed) == count * (1 << 42)
+    want = numpy_poisson(rho, L)
+    del fixed
+    phi = sim.readField(fp.F3_PHI, np.float64).reshape(n, n, n)
+    tol = 2e-5 if precision == "fp32" else 1e-10
+    top = np.abs(want).max()
+    assert top > 0
+    assert np.abs(phi - want).max() <= tol * top, np.abs(phi - want).max() / top
+    del want, rho
+    e4 = sim.readField(fp.F3_E, np.float64).reshape(n, n, n, 4)
+    assert same_bits(e4[..., 3], phi)
+    worst, scale = 0.0, 0.0
+    for comp, (axis, length) in enumerate(((2, L[0]), (1, L[1]), (0, L[2]))):
+        grad = -(np.roll(phi, -1, axis=axis) - np.roll(phi, 1, axis=axis)) * (n / (2.0 * length))
+        worst = max(worst, float(np.abs(e4[..., comp] - grad).max()))
+        scale = max(scale, float(np.abs(grad).max()))
+        del grad
+    # the gradient is formed in T from phi in T: its rounding is eps(T) * |phi| * n / (2 L) per node
+    eps = np.finfo(np.float32 if precision == "fp32" else np.float64).eps
+    assert worst <= 4 * eps * top * n / (2 * min(L)) + 1e-6 * scale, (worst, scale)
+    sim.destroy()

@@ -1,6 +1,6 @@
 """GPU parity tests of the dense iterative solver, through the C ABI
-(include/fusionsor.h): against tests/golden/swgl_sor.* (the reference's own makeSORIterative
-evaluated in software) directly, against the CPU restatement (oracle/sor_oracle.c) at sizes the
+(include/fusionsor.h): against tests/golden/webgl_sor.* (the reference's own makeSORIterative run by
+Chromium's WebGL, oracle/make_golden_webgl.py) and tests/golden/swgl_sor.* (the same evaluated in software) directly, against the CPU restatement (oracle/sor_oracle.c) at sizes the
 fixture does not hold, and through size-independent properties at a size the oracle cannot reach.
 All outputs are float32 produced by the same operation tree, so the bar is bit-exact."""
 import numpy as np
@@ -42,9 +42,17 @@ def dominant_system(L, seed, coupling=0.5, dominance=1.5):
     return A, b, x0
 
 
+WEBGL_META = load_json("webgl_sor.json")
+WEBGL_BLOB = load_f32gz(WEBGL_META["file"])
+
+
+@pytest.mark.parametrize("fixture", ["swgl", "webgl"])
 @pytest.mark.parametrize("name", sorted(META["cases"]))
-def test_against_reference_solver_evaluated_in_software(sor, name):
-    case = META["cases"][name]
+def test_against_reference_solver_evaluated_in_software(sor, name, fixture):
+    """fixture 'webgl': the reference's solver executed by a real WebGL; 'swgl': its shader text under our evaluator."""
+    meta, blob = (META, BLOB) if fixture == "swgl" else (WEBGL_META, WEBGL_BLOB)
+    arr = lambda at: blob[at[0]: at[0] + at[1]]
+    case = meta["cases"][name]
     L = case["vec_length"]
     spec = {"n_power": case["n_power"]}
     if case["relaxation"] is not None:
