@@ -385,6 +385,8 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     import torch
     spec, L, vth, mi, qi = c4_scene(total, grid, world)
     em = solver == "yee"
+    solve_mode = os.environ.get("FPIC_BENCH_SOLVE", "interface")   # "interface": fes_tri.hpp (no transposition); "1": the transposed spectrum
+    solve_mode = "interface" if solve_mode == "interface" and not em else True
     nspecies = 1 if em else 2          # configs[4] names no second species: electrons against a neutralising background
     share = total // nspecies // world
     migrate_every = 2 * ghost
@@ -441,7 +443,7 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
         s_ = fp.makeCylindricalParticlePusher(dict(spec, count=cap), device=device, precision=precision)
         if nspecies == 2:
             s_.addSpecies(mi, qi, cap)
-        s_.domainInit(r, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=True)
+        s_.domainInit(r, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=solve_mode)
         for sp in range(nspecies):
             p, v = particles(r, sp)
             s_.domainSet(p, v, first_id=r * share, species=sp)
@@ -477,8 +479,12 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
             {"current_ghost_planes_int64_reduce": 2 * (ghost + 2) * plane * 3 * 8, "lattice_halo_copies_E_and_B": 2 * 2 * (ghost + 2) * plane * 4 * esz} if em else
             {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
              # (rows of the half spectrum are padded to whole 128-byte tiles in the library's own transform buffers)
-             "fft_transposes": 2 * 2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid * (grid // world) * 2 * esz * (world - 1) // world,
-             "field_ghost_planes": 2 * 3 * plane * 4 * esz},
+             # (one formula with box_workload; ADVICE r03: the two used different leading factors)
+             **({"interface_planes_all_gather": (2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid + grid // world) * 2 * esz * (world - 1)}
+                if solve_mode == "interface" else
+                {"fft_transposes_all_to_all": 2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid * (grid // world) * 2 * esz * (world - 1) // world}),
+             "potential_planes": (2 * ghost + 3) * plane * esz},
+        "decomposed_solve": "interface system along z (fes_tri.hpp)" if solve_mode == "interface" else "transposed spectrum",
     }
     for s_ in ranks:
         s_.destroy()
@@ -497,6 +503,8 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
     warmup = args.warmup if warmup is None else warmup
     total, grid, ghost = int(args.c4_particles), args.c4_grid, args.c4_ghost
     em = args.c4_solver == "yee"
+    solve_mode = os.environ.get("FPIC_BENCH_SOLVE", "interface")   # "interface": fes_tri.hpp (no transposition); "1": the transposed spectrum
+    solve_mode = "interface" if solve_mode == "interface" and not em and world <= 8 else True
     spec, L, vth, mi, qi = c4_scene(total, grid, world)
     nspecies = 1 if em else 2
     share = total // nspecies // world
@@ -524,7 +532,7 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
         comm = {"transport": "libfusionpic.so's own RCCL communicator (fpic_comm_init)", "rank": r_, "world": w_}
         if w_ != world:
             raise RuntimeError("fpic_comm_info reports a world of %d, the launcher has %d ranks" % (w_, world))
-    sim.domainInit(rank, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=world > 1)
+    sim.domainInit(rank, world, ghost_planes=ghost, migrate_every=migrate_every, distributed_solve=solve_mode if world > 1 else False)
     for sp in range(nspecies):
         p, v = c4_rank_particles(rank, world, sp, share, L, vth, 1.0 if sp == 0 else mi / spec["particle_mass"], local_rank)
         sim.domainSet(p, v, first_id=rank * share, species=sp)
@@ -568,7 +576,11 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
     else:
         exchanges = {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
                      # (rows of the half spectrum are padded to whole 128-byte tiles in the library's own transform buffers)
-                     "fft_transposes_all_to_all": 2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid * (grid // world) * 2 * esz * (world - 1) // world,
+                     # the decomposed direction of the solve: two transpositions of the rank's half spectrum (sent bytes), or — the
+                     # interface solve, csrc/fes_tri.hpp — one all-gather of two planes of it per rank (received bytes)
+                     **({"interface_planes_all_gather": (2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid + grid // world) * 2 * esz * (world - 1)}
+                        if solve_mode == "interface" else
+                        {"fft_transposes_all_to_all": 2 * (-(-(grid // 2 + 1) // (64 // esz)) * (64 // esz)) * grid * (grid // world) * 2 * esz * (world - 1) // world}),
                      "potential_planes": (2 * ghost + 3) * plane * esz,
                      "migration_records_32B": 32 * dom["migrated"] // max(1, sub)}
     out = {
@@ -579,7 +591,7 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
                                 "BASELINE configs[3]: %d^3 periodic grid, %.1e particles in total (electrons + protons), Poisson solve every sub-step")
                                % (grid, n_all) + "; EXTENSION, parity unpinned (no reference counterpart); one step = 2 sub-steps",
                    "parallelism": "z-slab decomposition x%d inside libfusionpic.so over RCCL (ghost planes %d, migration every %d sub-steps%s)"
-                                  % (world, ghost, migrate_every, "" if em or world == 1 else ", slab-decomposed FFT")},
+                                  % (world, ghost, migrate_every, "" if em or world == 1 else (", decomposed solve: interface system along z, one all-gather of two planes per rank" if solve_mode == "interface" else ", slab-decomposed FFT with two transpositions"))},
         "comm": comm,
         "roofline": {"bound": "hbm", "kernel": "em_push_tiles_kernel" if em else "push3_tiles_kernel", "achieved": algo / (push_ms * 1e-3) / 1e9 if push_ms else 0.0,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if push_ms else 0.0, "traffic": None,
@@ -983,10 +995,30 @@ def main():
         # N = 1, 2, 4, 8 of the driver's plain `bench.py --gpus N` trace the strong-scaling curve in this block, over the
         # library's own RCCL communicator (there is no other transport here: a failure to set it up ends the run).
         torch.cuda.empty_cache()
+        # A rank that fails inside this block leaves the others waiting in a collective of the library, rank 0 possibly
+        # among them: the headline measured above must not be lost with it.  A watchdog on every rank ends the wait: rank 0
+        # prints the line with the block marked as failed, every rank leaves.  
+        import threading
+        limit = float(os.environ.get("FPIC_BENCH_C4_LIMIT_S", "420"))
+
+        def give_up():
+            if rank == 0:
+                out["strong_c4"] = {"value": None, "error": "the strong_c4 block did not finish within %.0f s on rank 0 (a rank failed or an exchange "
+                                                            "never completed); the headline above was measured before it" % limit}
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("bench.py: rank %d gives up on the strong_c4 block after %.0f s\n" % (rank, limit))
+            sys.stderr.flush()
+            os._exit(0 if rank == 0 else 5)
+
+        watchdog = threading.Timer(limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             block = box_workload(args, rank, world, local_rank, dist if distributed else None, steps=max(2, args.steps // 5), warmup=1,
                                  cpu=not args.no_cpu_baseline)
-        except Exception as e:  # loud, but the headline measured above is not lost with it: the line, then a non-zero exit
+            watchdog.cancel()
+        except Exception as e:
+            watchdog.cancel()  # loud, but the headline measured above is not lost with it: the line, then a non-zero exit
             if rank == 0:
                 out["strong_c4"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
                 print(json.dumps(out), flush=True)

@@ -12,6 +12,7 @@
 #include "fes_api.hpp"
 #include "fes_kernels.hpp"
 #include "fes_fft.hpp"
+#include "fes_tri.hpp"
 #include "fpic_comm.hpp"
 #include "fpic_dyn.hpp"
 
@@ -139,6 +140,12 @@ struct Domain {
     rocfft_execution_info i2f = nullptr, i2i = nullptr, izf = nullptr, izi = nullptr;
     void* fft_work[4] = {};
     void* hatZ = nullptr;               // hatB turned to [nyl * nxh][nz]: the z pass is contiguous there
+    // distributed_solve = 2 (fes_tri.hpp): no transposition — the decomposed direction is a periodic tridiagonal system per
+    // (kx, ky) mode, reduced per rank to two interface planes; tri = [world][2 planes of the half spectrum + nzl values of
+    // the (0, 0) mode's line] (complex T), all-gathered in place; tri_block = complex values per rank
+    bool interface_solve = false;
+    void* tri = nullptr;
+    size_t tri_block = 0;
 };
 
 namespace {
@@ -1242,7 +1249,7 @@ void release(fpic_handle* h)
         if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
         if (d->ev_boundary) (void)hipEventDestroy(d->ev_boundary);
         if (d->ev_ghost) (void)hipEventDestroy(d->ev_ghost);
-        for (void* p : { d->hatA, d->hatB, d->xbuf, d->hatZ, d->fft_work[0], d->fft_work[1], d->fft_work[2], d->fft_work[3] })
+        for (void* p : { d->hatA, d->hatB, d->xbuf, d->hatZ, d->tri, d->fft_work[0], d->fft_work[1], d->fft_work[2], d->fft_work[3] })
             if (p) (void)hipFree(p);
         const fdyn::RocFFT& ffd = fdyn::rocfft();
         if (ffd.ok) {
@@ -1938,6 +1945,27 @@ int allgather_rho(Ranks& rk)
     return FPIC_OK;
 }
 
+// every rank ends up with every rank's interface planes (and its piece of the (0, 0) mode's line): fes_tri.hpp, step 2
+template <typename T>
+int allgather_tri(Ranks& rk)
+{
+    if (rk.rccl) {
+        fpic_handle* h = rk.hs[0];
+        const Domain& d = *h->es->dom;
+        T* buf = static_cast<T*>(d.tri);
+        const size_t count = 2 * d.tri_block; // scalars per rank
+        return fcomm::check(h, fdyn::rccl().AllGather(buf + d.rank * count, buf, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, h->comm->nccl, h->stream), "ncclAllGather");
+    }
+    for (fpic_handle* dst : rk.hs)
+        for (fpic_handle* src : rk.hs) {
+            if (src == dst) continue;
+            const Domain& sd = *src->es->dom;
+            const size_t count = 2 * sd.tri_block, off = sd.rank * count;
+            HIP_TRY(dst, hipMemcpyAsync(static_cast<T*>(dst->es->dom->tri) + off, static_cast<const T*>(sd.tri) + off, count * sizeof(T), hipMemcpyDeviceToDevice, rk.hs[0]->stream));
+        }
+    return FPIC_OK;
+}
+
 // One word agreed by every rank (maximum): an error that only one rank sees must stop them all at the same point of the
 // exchange sequence, or the others wait in the next send / receive for ever.
 int agree_max(Ranks& rk, unsigned mine_of_rank0, const std::vector<unsigned>& mine, unsigned& out)
@@ -2114,6 +2142,45 @@ int solve_distributed(Ranks& rk)
         return fft_status(h, ff.execute(plan, ib, ob, info), what);
     };
     const bool own = rk.hs[0]->es->own_fft;
+    if (rk.hs[0]->es->dom->interface_solve) {
+        // fes_tri.hpp: x and y transforms of the own planes in place, down sweep along z, all-gather of two planes per rank,
+        // up sweep, inverse y and x transforms — no transposition, 1/32 of its bytes on the links (nzl = 64)
+        if (int e = each([&](fpic_handle* h) -> int {
+                State* st = h->es;
+                Domain& d = *st->dom;
+                const int pitch = static_cast<int>(row_pitch<T>(st));
+                const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+                timing_begin(h, KC_SOLVE);
+                const double dv = (st->lx / st->nx) * (st->ly / st->ny) * (st->lz / st->nz), dz = st->lz / st->nz;
+                const double scale = h->spec.particle_charge * st->W / (4398046511104.0 * dv);
+                T* hat = static_cast<T*>(d.hatA);
+                if (int e2 = fft_x_forward<T>(h, st->rho_fixed + lp(st, d.z0) * plane, nullptr, scale, static_cast<size_t>(d.nzl) * st->ny, hat)) return e2;
+                if (int e2 = fft_columns<T, 0>(h, hat, static_cast<size_t>(st->ny) * pitch, pitch, d.nzl, st->ny)) return e2;
+                const festri::Slab sl{ d.nzl, st->ny, st->nx / 2 + 1, pitch };
+                T* mine = static_cast<T*>(d.tri) + 2 * (static_cast<size_t>(d.rank) * d.tri_block);
+                festri::tri_down_kernel<T><<<blocks_for(static_cast<size_t>(st->ny) * pitch), 256, 0, h->stream>>>(
+                    hat, sl, st->k2[0], st->k2[1], dz * dz, dz * dz / (kEps0 * static_cast<double>(st->nx) * st->ny), mine, mine + 2 * (2 * static_cast<size_t>(st->ny) * pitch));
+                HIP_TRY(h, hipGetLastError());
+                return FPIC_OK;
+            })) return e;
+        if (int e = allgather_tri<T>(rk)) return e;
+        if (int e = each([&](fpic_handle* h) -> int {
+                State* st = h->es;
+                Domain& d = *st->dom;
+                const int pitch = static_cast<int>(row_pitch<T>(st));
+                const size_t plane = static_cast<size_t>(st->nx) * st->ny;
+                const double dz = st->lz / st->nz;
+                T* hat = static_cast<T*>(d.hatA);
+                const festri::Slab sl{ d.nzl, st->ny, st->nx / 2 + 1, pitch };
+                festri::tri_up_kernel<T><<<blocks_for(static_cast<size_t>(st->ny) * pitch), 256, 0, h->stream>>>(
+                    hat, sl, st->k2[0], st->k2[1], dz * dz, static_cast<const T*>(d.tri), d.tri_block, d.world, d.rank);
+                HIP_TRY(h, hipGetLastError());
+                festri::tri_zero_line_kernel<T><<<1, 1024, 0, h->stream>>>(hat, sl, static_cast<const T*>(d.tri), d.tri_block, d.world, d.rank);
+                HIP_TRY(h, hipGetLastError());
+                if (int e2 = fft_columns<T, 1>(h, hat, static_cast<size_t>(st->ny) * pitch, pitch, d.nzl, st->ny)) return e2;
+                return fft_x_inverse<T>(h, hat, static_cast<size_t>(d.nzl) * st->ny, static_cast<T*>(st->phi) + lp(st, d.z0) * plane);
+            })) return e;
+    } else {
     if (int e = each([&](fpic_handle* h) -> int {
             State* st = h->es;
             Domain& d = *st->dom;
@@ -2171,6 +2238,7 @@ int solve_distributed(Ranks& rk)
             HIP_TRY(h, hipGetLastError());
             return run_fft(h, d.p2i, d.i2i, d.hatA, static_cast<T*>(st->phi) + lp(st, d.z0) * plane, "rocfft_execute (2-D inverse)");
         })) return e;
+    }
     // The potential's ghost planes travel (RCCL: on the communicator's stream) while the gradient of the planes that need
     // none of them is formed: a plane's gradient reads its two neighbours, so the slab's inner nzl - 2 planes are free.
     bool split = rk.hs[0]->es->solver != FPIC_SOLVER_YEE;
@@ -2630,13 +2698,23 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     if (distributed_solve && world > 1 && (st->solver == FPIC_SOLVER_POISSON_FFT || yee_decomposed)) {
         d->phi_below = st->solver == FPIC_SOLVER_YEE ? d->H : ghost_planes + 1;
         d->phi_above = d->phi_below + 1;
-        if (st->ny % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d rows along y do not divide into %d shares for the decomposed solve", st->ny, world);
+        if (distributed_solve != 2 && st->ny % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d rows along y do not divide into %d shares for the decomposed solve", st->ny, world);
         if (ghost_planes + 2 > nzl) return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- the decomposed solve needs ghost_planes + 2 <= %d planes per slab", nzl);
         d->distributed = true;
         d->nyl = st->ny / world;
         const size_t nxh = st->nx / 2 + 1, esz = h->esize;
-        const size_t cbytes = (h->prec == FPIC_F32 ? row_pitch<float>(st) : row_pitch<double>(st)) * st->ny * nzl * 2 * esz;
-        if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc))) return rc;
+        const size_t pitch = h->prec == FPIC_F32 ? row_pitch<float>(st) : row_pitch<double>(st);
+        const size_t cbytes = pitch * st->ny * nzl * 2 * esz;
+        if (distributed_solve == 2) { // the interface solve of fes_tri.hpp: the spectrum of the own planes stays where it is
+            if (!st->own_fft) return fail(h, FPIC_ERR_INVALID_ARG, ".distributed_solve <- 2 (interface solve along z) runs on the library's own transforms: power-of-two grids");
+            if (world > festri::kMaxRanks) return fail(h, FPIC_ERR_INVALID_ARG, ".distributed_solve <- 2 supports up to %d ranks (%d asked)", festri::kMaxRanks, world);
+            if (st->nz > 1024) return fail(h, FPIC_ERR_INVALID_ARG, ".distributed_solve <- 2 holds the (0, 0) mode's line in one workgroup: nz <= 1024");
+            d->interface_solve = true;
+            d->tri_block = 2 * pitch * st->ny + nzl;
+            if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->tri, d->tri_block * world * 2 * esz, acc))) return rc;
+        } else if ((rc = dev_alloc(h, &d->hatA, cbytes, acc)) || (rc = dev_alloc(h, &d->hatB, cbytes, acc)) || (rc = dev_alloc(h, &d->xbuf, cbytes, acc))) {
+            return rc;
+        }
         if (st->own_fft) { // the library's own passes work in place on hatA / hatB: no plans, no z-major copy
             // nothing on this rank reads or writes a node outside its slab, the ghost planes of the deposit (G below, G + 1
             // above) and the planes of phi their gradient needs (one more on each side): keep those

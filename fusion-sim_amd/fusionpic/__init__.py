@@ -523,7 +523,9 @@ class ElectrostaticBoxPusher:
 
     # ---- spatial decomposition (z-slabs; include/fusionpic.h, fpic_domain_*)
     def domainInit(self, rank, world, ghost_planes=2, migrate_every=4, distributed_solve=False):
-        self._check(self._lib.fpic_domain_init(self._h, int(rank), int(world), int(ghost_planes), int(migrate_every), 1 if distributed_solve else 0))
+        # distributed_solve: False / 0 replicated, True / 1 transposed spectrum, "interface" / 2 tridiagonal interface solve along z
+        mode = 2 if (distributed_solve == "interface" or (distributed_solve == 2 and distributed_solve is not True)) else (1 if distributed_solve else 0)
+        self._check(self._lib.fpic_domain_init(self._h, int(rank), int(world), int(ghost_planes), int(migrate_every), mode))
 
     def domainSet(self, position, velocity, first_id, species=0):
         p, v = _device_or_host(position), _device_or_host(velocity)

@@ -211,7 +211,7 @@ function makeBox(spec, lib) {
     out.domainInit = function (rank, world, options) {
         const o = options || {};
         lib.domainInit(h, rank, world, o.ghost_planes === undefined ? 2 : o.ghost_planes, o.migrate_every === undefined ? 4 : o.migrate_every,
-                       o.distributed_solve ? 1 : 0);
+                       o.distributed_solve === 'interface' || o.distributed_solve === 2 ? 2 : (o.distributed_solve ? 1 : 0));
     };
     out.domainSet = function (value, firstId, species) {
         const sp = species || 0;

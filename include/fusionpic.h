@@ -353,7 +353,13 @@ int fpic_comm_set_overlap(fpic_handle* h, int enable);
  * take it for their initial field as well, and the rank then KEEPS ONLY ITS SLAB: nz/N + 2 (ghost_planes + 2) + 1 planes of
  * every node array instead of nz (FPIC_DOMAIN_COMPACT=0 keeps whole-grid arrays).  Call it on a fresh handle: node fields
  * uploaded before it are dropped (upload after).  fpic_read_field3 still fills a whole-grid-shaped array: the planes the
- * rank holds in their places, zero elsewhere; fpic_device_buffer(FPIC_BUF_RHO_FIXED) is then the held planes only. */
+ * rank holds in their places, zero elsewhere; fpic_device_buffer(FPIC_BUF_RHO_FIXED) is then the held planes only.
+ * 2: decomposed WITHOUT the transpositions (power-of-two grids, up to 8 ranks): K^2 = k2x + k2y + k2z with k2z the eigenvalues
+ * of the three-point second difference, so after the x and y transforms of its own planes every (kx, ky) mode is a periodic
+ * tridiagonal system along z; each rank eliminates its nz/N planes to a two-equation interface, ONE all-gather carries two
+ * planes of the half spectrum per rank (1/32 of the transpositions' bytes at nz/N = 64), every rank solves the 2N-unknown
+ * interface system of each mode redundantly and substitutes back (csrc/fes_tri.hpp).  Equal to the transform solve in exact
+ * arithmetic: fields agree with one GPU to rounding (2e-5 / 1e-10), not bit for bit.  Slab-only arrays as with 1. */
 int fpic_domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migrate_every, int distributed_solve);
 /* the rank's initial particles (positions anywhere in its slab +- ghost planes); their global indices are first_id, first_id+1, ... */
 int fpic_domain_set_particles(fpic_handle* h, int species, uint64_t n, const void* pos_aos, const void* vel_aos, uint32_t first_id, int dtype);

@@ -409,6 +409,86 @@ def test_slab_decomposition_reproduces_one_gpu_bit_for_bit(fp, eo, precision, wo
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("world,shape", [(2, (16, 16, 16)), (4, (32, 16, 32)), (8, (16, 32, 64)), (4, (32, 16, 64)), (8, (64, 32, 128)), (8, (8, 16, 32)),
+                                         (2, (32, 32, 256)), (8, (128, 64, 512))])
+def test_interface_solve_along_the_decomposed_direction(fp, eo, precision, world, shape):
+    """distributed_solve = 2 (csrc/fes_tri.hpp): no transposition — after the x and y transforms of its own planes every
+    rank reduces each (kx, ky) mode's periodic tridiagonal system along z to a two-equation interface, ONE all-gather
+    carries two planes per rank, and every rank solves the interface system and substitutes back.  On every rank's own
+    planes the potential agrees with ONE handle's three-dimensional transform within the solve's tolerance (2e-5 / 1e-10 of
+    the largest potential), the field on the slab and its ghost planes likewise; after four frames every particle agrees
+    to 1e-4 / 1e-9 of the box; none is lost.  4 to 128 planes per rank, and the longest column the library's transforms
+    support (512 planes).  (World sizes that are no power of two: the host test of the core, tests/test_tri_core.py.)"""
+    if shape[2] >= 256 and precision == "fp64" and world == 8:
+        pytest.skip("the 512-plane case runs once, in fp32")
+    rng = np.random.default_rng(300 + world)
+    n = 40000
+    L = (1e-3 * shape[0], 1.3e-3 * shape[1], 0.8e-3 * shape[2])         # cells that are no cubes: lam carries dz^2 / dx^2
+    spec = box_spec(shape, L, count=n, dt=5e-12, macro_weight=1e15 * np.prod(L) / n)
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.02, (n, 3))
+    nzl = shape[2] // world
+    own = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
+    order = np.argsort(own, kind="stable")
+    pos, vel, own = pos[order], vel[order], own[order]
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.set(position=pos, velocity=vel)
+    ranks, first = [], 0
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(spec, precision=precision)
+        s.domainInit(r, world, ghost_planes=min(2, nzl - 2), migrate_every=2, distributed_solve="interface")
+        m = int((own == r).sum())
+        s.domainSet(pos[first:first + m], vel[first:first + m], first_id=first)
+        first += m
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    one.precalc(); group.precalc()
+    tol = 2e-5 if precision == "fp32" else 1e-10
+    plane = shape[0] * shape[1]
+    G = min(2, nzl - 2)
+
+    def fields(tag, exact_rho):
+        f1 = one.readField(fp.F3_RHO_FIXED).reshape(shape[2], plane)
+        p1 = one.readField(fp.F3_PHI, np.float64).reshape(shape[2], plane)
+        e1 = one.readField(fp.F3_E, np.float64).reshape(shape[2], plane, 4)
+        for r, s in enumerate(ranks):
+            planes = np.arange(r * nzl, (r + 1) * nzl)
+            if exact_rho:
+                assert np.array_equal(s.readField(fp.F3_RHO_FIXED).reshape(shape[2], plane)[planes], f1[planes]), (tag, r)
+            pr = s.readField(fp.F3_PHI, np.float64).reshape(shape[2], plane)
+            assert np.abs(pr[planes] - p1[planes]).max() <= tol * np.abs(p1).max(), (tag, r, np.abs(pr[planes] - p1[planes]).max() / np.abs(p1).max())
+            wide = np.arange(r * nzl - G, (r + 1) * nzl + G + 1) % shape[2]           # the slab and its ghost planes
+            er = s.readField(fp.F3_E, np.float64).reshape(shape[2], plane, 4)
+            assert np.abs(er[wide][..., :3] - e1[wide][..., :3]).max() <= 20 * tol * np.abs(e1[..., :3]).max(), (tag, r)
+
+    fields("precalc", True)
+    for frame in range(4):
+        one.step(); group.step()
+    fields("after 4 frames", False)
+    parts = [s.domainGet(np.float64) for s in ranks]
+    ids = np.concatenate([p["ids"] for p in parts])
+    assert np.array_equal(np.sort(ids), np.arange(n))
+    got = np.concatenate([p["position"] for p in parts])[np.argsort(ids)]
+    d = np.abs(got - one.getParticles(np.float64)["position"]); d = np.minimum(d, 1 - d)
+    assert d.max() <= (1e-4 if precision == "fp32" else 1e-9)
+    stats = [s.domainStats() for s in ranks]
+    assert all(s["lost"] == 0 for s in stats)
+    for s in ranks + [one]:
+        s.destroy()
+
+
+def test_interface_solve_is_refused_where_it_cannot_run(fp):
+    """a grid that is no power of two (rocFFT path) and a world of more than eight ranks"""
+    s = fp.makeCylindricalParticlePusher(box_spec((24, 16, 48), (1.0, 1.0, 1.0), count=10))
+    with pytest.raises(fp.FusionPicError):
+        s.domainInit(0, 4, ghost_planes=2, migrate_every=2, distributed_solve="interface")
+    s.destroy()
+    s = fp.makeCylindricalParticlePusher(box_spec((16, 16, 64), (1.0, 1.0, 1.0), count=10))
+    with pytest.raises(fp.FusionPicError):
+        s.domainInit(0, 16, ghost_planes=1, migrate_every=2, distributed_solve="interface")
+    s.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
 @pytest.mark.parametrize("world,shape", [(2, (16, 16, 16)), (4, (24, 16, 32)), (8, (20, 32, 64)), (4, (32, 16, 64)), (8, (64, 32, 128))])
 def test_slab_decomposed_poisson_solve(fp, eo, precision, world, shape):
     """distributed_solve: no rank transforms the whole grid — 2-D transforms of the owned planes, all-to-all transposition,

@@ -63,7 +63,7 @@ for _ in range(frames):
 ref = one.getParticles()
 # (the library's own transforms on power-of-two grids: the decomposed solve is the one handle's, bit for bit)
 own_fft = all(s_ & (s_ - 1) == 0 and s_ >= 8 for s_ in shape)
-fields = [fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B] if em else [fp.F3_RHO_FIXED] + ([] if dist_solve and not own_fft else [fp.F3_E])
+fields = [fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B] if em else [fp.F3_RHO_FIXED] + ([] if (dist_solve and not own_fft) or dist_solve == 2 else [fp.F3_E])
 ref_f = {w: one.readField(w).reshape(shape[2], -1) for w in fields}
 
 uid = fp.commUniqueId()
@@ -148,6 +148,15 @@ def test_rccl_transport_slab_decomposed_solve(tmp_path, world, shape, ghost):
         # power-of-two grid: the library's own transforms, slab-only arrays, the potential's ghost planes travelling beside
         # the inner gradient — and every number the one handle's
         assert res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
+
+
+@pytest.mark.parametrize("world,shape,ghost", [(2, (16, 16, 16), 2), (4, (16, 32, 64), 2), (2, (32, 16, 64), 3)])
+def test_rccl_transport_interface_solve(tmp_path, world, shape, ghost):
+    """distributed_solve = 2 over the (stand-in) RCCL transport: ONE all-gather of two planes per rank instead of the two
+    transpositions; agreement with one handle to the solve's rounding (it is not the same arithmetic)"""
+    res = run_case(tmp_path, world=world, shape=shape, ghost=ghost, every=2, em=False, distributed_solve=2, precision="fp32", n=20000, seed=7)
+    assert res["ids_ok"] and res["pos_err"] <= 1e-4 and res["charge_total_same"] and res["charge_max_rel_diff"] <= 1e-3, res
+    assert res["migrated"] > 0 and res["lost"] == 0
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])

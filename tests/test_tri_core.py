@@ -1,0 +1,64 @@
+"""The arithmetic core of the interface solve (fusion-sim_amd/csrc/fes_tri.hpp: the decomposed direction of the
+slab-decomposed Poisson solve as a periodic tridiagonal system per (kx, ky) mode, solved by substructuring over the ranks
+instead of transposing the spectrum) built for the HOST with g++ and checked against numpy's FFT solve of the same
+system: 1..8 ranks, 2..512 planes per rank, modes from the longest wave of a 512^3 grid (lam = 1.5e-4: the
+ill-conditioned end) to the shortest (lam = 8), float and double storage.  No GPU involved; the kernels that wrap this
+core are held to one handle's transform solve in tests/test_gpu_es3d.py."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = tmp_path_factory.mktemp("tri") / "tri_core_test"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "tri_core_test.cpp"), "-o", str(out)])
+    return str(out)
+
+
+def modes():
+    k = (2 * np.sin(np.pi * np.arange(257) / 512)) ** 2
+    lam = np.add.outer(k[[0, 1, 2, 3, 7, 30, 100, 256]], k[[1, 2, 5, 64, 256]]).ravel()
+    return np.concatenate([lam, [1e-8, 1e-5, 3e-3, 8.0]])     # (1e-5: the longest wave of a 512-grid whose cells are 4 times flatter than wide)
+
+
+@pytest.mark.parametrize("P,m", [(1, 16), (2, 2), (2, 256), (3, 7), (4, 128), (5, 3), (6, 12), (8, 64), (8, 4), (7, 512)])
+@pytest.mark.parametrize("storage", ["float", "double"])
+def test_interface_solve_matches_the_transform(exe, tmp_path, P, m, storage):
+    rng = np.random.default_rng(P * 1000 + m)
+    lam = modes()
+    nz, nm = P * m, lam.size
+    f = rng.normal(size=(nz, nm)) + 1j * rng.normal(size=(nz, nm))
+    f[:, ::3] *= np.exp(-np.arange(nz) / 5.0)[:, None]          # some columns concentrated on the first planes
+    kz2 = (2 * np.sin(np.pi * np.arange(nz) / nz)) ** 2
+    want = np.fft.ifft(np.fft.fft(f, axis=0) / (lam[None, :] + kz2[:, None]), axis=0)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(src, "wb") as fh:
+        fh.write(lam.astype("<f8").tobytes())
+        fh.write(np.ascontiguousarray(f).view(np.float64).astype("<f8").tobytes())
+    subprocess.check_call([exe, str(P), str(m), str(nm), storage, str(src), str(dst)], timeout=120)
+    got = np.fromfile(dst, dtype="<f8").view(np.complex128).reshape(nz, nm)
+    err = np.abs(got - want).max(axis=0) / np.abs(want).max(axis=0)
+    # float storage: the exchanged planes and the stored g are float, the recurrences double
+    assert err.max() <= (1e-6 if storage == "float" else 2e-13), (err.max(), lam[np.argmax(err)])
+
+
+def test_singular_line(exe, tmp_path):
+    """the (0, 0) mode: -phi[z-1] + 2 phi[z] - phi[z+1] = f - mean(f), mean(phi) = 0, by two prefix sums"""
+    rng = np.random.default_rng(9)
+    for n in (8, 96, 512):
+        f = rng.normal(size=n) + 3.0
+        src, dst = tmp_path / "z.bin", tmp_path / "zo.bin"
+        f.astype("<f8").tofile(src)
+        subprocess.check_call([exe, "zero", str(n), str(src), str(dst)])
+        got = np.fromfile(dst, dtype="<f8")
+        kz2 = (2 * np.sin(np.pi * np.arange(n) / n)) ** 2
+        hat = np.fft.fft(f)
+        hat[0] = 0
+        kz2[0] = 1
+        want = np.fft.ifft(hat / kz2).real
+        assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
