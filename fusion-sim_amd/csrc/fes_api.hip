@@ -1135,7 +1135,7 @@ int create_state(fpic_handle* h)
             (rc = dev_alloc(h, reinterpret_cast<void**>(&st->Jfix), st->nodes * 3 * sizeof(long long), acc)))
             return rc;
     }
-    // power-of-two grids (8 .. 1024 nodes per axis): the library's own FFT passes; FPIC_POISSON_FFT=rocfft keeps rocFFT (a
+    // power-of-two grids (8 .. 512 nodes per axis): the library's own FFT passes; FPIC_POISSON_FFT=rocfft keeps rocFFT (a
     // development switch: the two agree within the solve's tolerance, tests/test_gpu_es3d.py)
     {
         const char* force = std::getenv("FPIC_POISSON_FFT");
@@ -1149,9 +1149,14 @@ int create_state(fpic_handle* h)
             HIP_TRY(h, hipGetLastError());
         }
         const size_t most = fft_lds_bytes<T>(1 << kFftMaxLog, fft_tile_columns<T>());
+        // (fft_columns() launches the half-width instantiation for 512-point float columns: every form it can launch gets
+        // its limit, whatever a later retune of the tile widths makes of their sizes)
+        constexpr int CH = fft_tile_columns<T>() / 2;
         if ((e = set_lds(fft_x_forward_kernel<T>, most)) != hipSuccess || (e = set_lds(fft_x_inverse_kernel<T>, most)) != hipSuccess ||
             (e = set_lds(fft_columns_kernel<T, 0>, most)) != hipSuccess || (e = set_lds(fft_columns_kernel<T, 1>, most)) != hipSuccess ||
-            (e = set_lds(fft_columns_kernel<T, 2>, most)) != hipSuccess)
+            (e = set_lds(fft_columns_kernel<T, 2>, most)) != hipSuccess ||
+            (e = set_lds(fft_columns_kernel<T, 0, CH>, most)) != hipSuccess || (e = set_lds(fft_columns_kernel<T, 1, CH>, most)) != hipSuccess ||
+            (e = set_lds(fft_columns_kernel<T, 2, CH>, most)) != hipSuccess)
             return fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
     if ((st->solver == FPIC_SOLVER_POISSON_FFT || st->solver == FPIC_SOLVER_YEE) && !st->own_fft) { // (YEE: the initial field is the Poisson field)
@@ -1559,7 +1564,7 @@ int load_rank_checkpoint(fpic_handle* h, const char* path)
     RankCheckpointHeader hd{};
     if (std::fread(&hd, 12, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICRNK1", 8) != 0)
         return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a rank of a decomposed box", path);
-    if (hd.version != kCheckpointVersion)
+    if (hd.version != kCheckpointVersion && hd.version != 1) // (version 1: the same layout, written before the number was raised)
         return fail(h, FPIC_ERR_INVALID_ARG, "%s is a rank checkpoint of format version %u; this library reads version %u (the header embeds fpic_spec of ABI %d)", path, hd.version,
                     kCheckpointVersion, FPIC_ABI_VERSION);
     if (std::fread(reinterpret_cast<char*>(&hd) + 12, sizeof hd - 12, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
@@ -1648,7 +1653,7 @@ int load_checkpoint(fpic_handle* h, const char* path)
     // (magic and version are the first twelve bytes whatever the rest of the header looked like when the file was written)
     if (std::fread(&hd, 12, 1, bf.f) != 1 || std::memcmp(hd.magic, "FPICBOX1", 8) != 0)
         return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a checkpoint of a box", path);
-    if (hd.version != kCheckpointVersion)
+    if (hd.version != kCheckpointVersion && hd.version != 1) // (version 1: the same layout, written before the number was raised)
         return fail(h, FPIC_ERR_INVALID_ARG, "%s is a box checkpoint of format version %u; this library reads version %u (the header embeds fpic_spec of ABI %d)", path, hd.version,
                     kCheckpointVersion, FPIC_ABI_VERSION);
     if (std::fread(reinterpret_cast<char*>(&hd) + 12, sizeof hd - 12, 1, bf.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");
@@ -2552,6 +2557,15 @@ int precalc(fpic_handle* h)
         if (rc == FPIC_OK) h->es->fields_ready = true;
         return rc;
     }
+    // A freshly uploaded population is in the caller's order: deposited as it is, every particle adds its eight weights with
+    // global atomics (369 ms at 2e9 particles, profiles/r03_bench_kernel_stats.csv: a third of that bench's GPU time).  Large
+    // populations are binned first — the staged two-level scatter of 4.7, which the first sub-step would run anyway — and take
+    // the tiled deposit; the charge grid is an integer grid, so the result is the same whatever the order.  Small ones keep
+    // the flat form (nothing to gain, and the tests keep covering it).
+    bool bin_first = false;
+    for (const Species& sp : h->es->sp) bin_first |= !sp.binned && sp.n >= h->two_level_min;
+    if (bin_first)
+        if (int e = h->prec == FPIC_F32 ? bin_all<float>(h, false) : bin_all<double>(h, false)) return e;
     int rc = h->prec == FPIC_F32 ? deposit_cycle<float, true>(h) : deposit_cycle<double, true>(h);
     if (rc) return rc;
     h->deposit_launches++;

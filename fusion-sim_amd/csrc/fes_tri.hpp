@@ -150,6 +150,8 @@ FESTRI_HD void down_sweep(const Mode& q, int m, T* col, size_t stride, double sc
 {
     double gr = 0, gi = 0, p = 1.0, rj = 1.0;
     double pk = exp2(2.0 * (m + 1) * q.log2r);               // r^(2k), k = m + 1 - j, walked downwards with j
+    double ej = one_minus(q, q.r2, 1);                       // 1 - r^(2j); each step's denominator is the next step's numerator
+    const double invD = 1.0 / q.D;
     y1r = y1i = 0;
 #if defined(__HIPCC__)
 #pragma unroll 8
@@ -158,10 +160,12 @@ FESTRI_HD void down_sweep(const Mode& q, int m, T* col, size_t stride, double sc
         T* at = col + 2 * (static_cast<size_t>(j - 1) * stride);
         const double fr = static_cast<double>(at[0]) * scale, fi = static_cast<double>(at[1]) * scale;
         p *= q.r2; rj *= q.r;                                // r^(2j), r^j
-        const double c = elim_c(q, p, j);
+        const double ej1 = one_minus(q, p * q.r2, j + 1);
+        const double c = q.r * ej / ej1;                     // c_j = r (1 - r^(2j)) / (1 - r^(2j+2))
+        ej = ej1;
         gr = (fr + gr) * c; gi = (fi + gi) * c;
         pk = pk > kTiny ? pk * q.rinv * q.rinv : exp2(2.0 * (m + 1 - j) * q.log2r);
-        const double v = rj * one_minus(q, pk, m + 1 - j) / q.D;      // (T^-1)_{1j} = r^j (1 - r^(2(m+1-j))) / D
+        const double v = rj * one_minus(q, pk, m + 1 - j) * invD;     // (T^-1)_{1j} = r^j (1 - r^(2(m+1-j))) / D
         y1r += v * fr; y1i += v * fi;
         at[0] = static_cast<T>(gr); at[1] = static_cast<T>(gi);
     }
@@ -174,6 +178,8 @@ FESTRI_HD void up_sweep(const Mode& q, int m, T* col, size_t stride, double ar, 
 {
     double yr = 0, yi = 0, rk = 1.0;                         // y_{j+1}; r^k with k = m + 1 - j
     double rj = exp2((m + 1) * q.log2r);                     // r^(j+1) to start with
+    double ej1 = q.D;                                        // 1 - r^(2(j+1))
+    const double invD = 1.0 / q.D;
 #if defined(__HIPCC__)
 #pragma unroll 8
 #endif
@@ -184,9 +190,10 @@ FESTRI_HD void up_sweep(const Mode& q, int m, T* col, size_t stride, double ar, 
         const double gr = static_cast<double>(at[0]), gi = static_cast<double>(at[1]);
         const double ej = one_minus(q, rj * rj, j);
         if (j == m) { yr = gr; yi = gi; }
-        else { const double c = q.r * ej / one_minus(q, rj * rj * q.r2, j + 1); yr = gr + c * yr; yi = gi + c * yi; }
-        const double v = rj * one_minus(q, rk * rk, m + 1 - j) / q.D;    // (T^-1)_{j1}
-        const double w = rk * ej / q.D;                                  // (T^-1)_{jm}
+        else { const double c = q.r * ej / ej1; yr = gr + c * yr; yi = gi + c * yi; }
+        ej1 = ej;
+        const double v = rj * one_minus(q, rk * rk, m + 1 - j) * invD;   // (T^-1)_{j1}
+        const double w = rk * ej * invD;                                 // (T^-1)_{jm}
         at[0] = static_cast<T>(yr + ar * v + br * w);
         at[1] = static_cast<T>(yi + ai * v + bi * w);
     }

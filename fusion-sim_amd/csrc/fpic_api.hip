@@ -1268,7 +1268,7 @@ int fpic_load_checkpoint(fpic_handle* h, const char* path)
     // (magic and version are the first twelve bytes whatever the rest of the header looked like when the file was written)
     if (std::fread(&hd, 12, 1, fc.f) != 1 || std::memcmp(hd.magic, "FPICCKP1", 8) != 0)
         return fail(h, FPIC_ERR_INVALID_ARG, "%s is not a fusionpic checkpoint", path);
-    if (hd.version != kRzCheckpointVersion)
+    if (hd.version != kRzCheckpointVersion && hd.version != 1) // (version 1: the same layout, written before the number was raised)
         return fail(h, FPIC_ERR_INVALID_ARG, "%s is a checkpoint of format version %u; this library reads version %u (the header embeds fpic_spec of ABI %d)", path, hd.version,
                     kRzCheckpointVersion, FPIC_ABI_VERSION);
     if (std::fread(reinterpret_cast<char*>(&hd) + 12, sizeof hd - 12, 1, fc.f) != 1) return fail(h, FPIC_ERR_STATE, "checkpoint is truncated");

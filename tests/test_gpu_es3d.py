@@ -852,9 +852,15 @@ def test_box_checkpoint_resume_is_bit_identical(fp, eo, tmp_path, precision, sol
     before = b.getParticles()
     with pytest.raises(fp.FusionPicError, match="truncated"):
         b.loadCheckpoint(tmp_path / "short.ckpt")
-    (tmp_path / "old.ckpt").write_bytes(data[:8] + (1).to_bytes(4, "little") + data[12:])
-    with pytest.raises(fp.FusionPicError, match="format version 1"):
-        b.loadCheckpoint(tmp_path / "old.ckpt")          # a file of an older library: refused by its version, not as "truncated"
+    (tmp_path / "old.ckpt").write_bytes(data[:8] + (0).to_bytes(4, "little") + data[12:])
+    with pytest.raises(fp.FusionPicError, match="format version 0"):
+        b.loadCheckpoint(tmp_path / "old.ckpt")          # a file of another format: refused by its version, not as "truncated"
+    (tmp_path / "v1.ckpt").write_bytes(data[:8] + (1).to_bytes(4, "little") + data[12:])
+    c1, c2 = build(), build()
+    c1.loadCheckpoint(tmp_path / "v1.ckpt")              # version 1 had the same layout (round 2's files): read
+    c2.loadCheckpoint(path)
+    assert same_bits(c1.getParticles()["position"], c2.getParticles()["position"])
+    c1.destroy(); c2.destroy()
     other = fp.makeCylindricalParticlePusher(dict(spec, nz=shape[2] + 8), precision=precision)
     with pytest.raises(fp.FusionPicError):
         other.loadCheckpoint(path)                       # one species, another grid
