@@ -7,21 +7,24 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as
  * the checker.  libfusionpic.so never links, loads or calls anything in oracle/.
  *
- * PARITY PINNING.  The reference ships no tests, golden vectors or fixtures
- *  and its shaders cannot be executed headless (no WebGL
- * context in the image).  What IS pinned, by importing the reference's own host
- * JavaScript under Node (oracle/make_golden.js -> tests/golden/ fixtures):
- *   the 11x11 stamp, the constants h / dt*c / factor_r / factor_z and the shader
- *   literals derived from them, the normalised particle upload, the E/B/sink
- *   texture packing, the 512x512 inverse-CDF table (NaN sites included), and the
- *   pass order and per-pass texture bindings of step() and density().
- * The per-fragment arithmetic (K1-K6, K8-K12) is pinned as a TRANSCRIPTION of the shader
- * text: tests/golden/swgl_scene.* hold every texture of a scene that the reference's own
- * host code and shader strings produced under a software evaluator (oracle/swgl.js,
- * oracle/glsl_eval.js; IEEE float32 per operation), and this restatement reproduces them
- * bit for bit (tests/test_oracle_swgl.py).  It remains "parity unpinned" with respect to a
- * real GPU: what a GLSL compiler does with that text (built-in precision, contraction,
- * rasteriser ties) is implementation-defined and cannot be observed in this image.
+ * PARITY PINNING.  The reference ships no tests, golden vectors or fixtures.  What pins this
+ * restatement, strongest first:
+ *   1. THE REFERENCE ITSELF RUN BY A REAL WebGL (round 4): oracle/make_golden_webgl.py executes the unmodified
+ *      utilities.js / spindle.js / empic.js / matrix_webgl.js in the headless Chromium of the `kaleido` package (WebGL 1 on
+ *      ANGLE/SwiftShader) and writes every frame buffer, read back with the reference's own readPixels, to
+ *      tests/golden/webgl_*.  This restatement reproduces them bit for bit — upload, inverse CDF, precalc, every particle
+ *      texel / random state / alive flag of every frame, the dense solver; the deposit under the rasterised convention
+ *      (deposit_raster) — and within stated tolerances where the GL implementation's cos() and division enter
+ *      (tests/test_oracle_webgl.py, tests/test_oracle_sor.py).
+ *   2. the reference's own host JavaScript imported under Node (oracle/make_golden.js -> tests/golden/): the 11x11 stamp,
+ *      the constants h / dt*c / factor_r / factor_z and the shader literals derived from them, the normalised particle
+ *      upload, the E/B/sink texture packing, the 512x512 inverse-CDF table (NaN sites included), and the pass order and
+ *      per-pass texture bindings of step() and density();
+ *   3. the reference's shader text under a software evaluator (oracle/swgl.js, oracle/glsl_eval.js; IEEE float32 per
+ *      operation): tests/golden/swgl_*, reproduced bit for bit (tests/test_oracle_swgl.py) — a transcription check, itself
+ *      checked against 1. since round 4.
+ * What stays implementation-defined in GLSL ES 1.00 and therefore differs between GL implementations: transcendental
+ * built-ins, division by a varying, and the rasteriser's sub-pixel grid.
  *
  * Two instantiations of every kernel: orc_f32_* (float, the reference's precision)
  * and orc_f64_* (double).  Arrays are RGBA textures, texel (i,j) at 4*(i + j*W).
