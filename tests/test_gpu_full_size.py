@@ -388,7 +388,7 @@ def numpy_poisson(rho, L):
     k2[0, 0, 0] = 1.0
     hat /= EPS0 * k2
     hat[0, 0, 0] = 0.0
-    return np.fft.irfftn(hat, s=rho.shape)
+    return np.fft.irfftn(hat, s=rho.shape, axes=(0, 1, 2))
 
 
 @pytest.mark.parametrize("n,precision", [(256, "fp32"), (256, "fp64"), (512, "fp32")])
