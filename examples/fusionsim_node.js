@@ -9,7 +9,10 @@
  * (fusionsim.js:170-178): step(), density(), show the picture.  Here the picture is written as a
  * binary PGM of the running-average density instead of being drawn on a canvas.
  *
- *   node examples/fusionsim_node.js [--frames 100] [--every 10] [--out DIR] [--seed 1]
+ *   node examples/fusionsim_node.js [--frames 100] [--every 10] [--out DIR] [--seed 1] [--raster 4]
+ *
+ * --raster b draws density()'s point sprites as a rasteriser with b sub-pixel bits does (4: Chromium's SwiftShader, whose
+ * run of the reference this reproduces bit for bit; 8: most desktop GPUs); without it: ideal sprites (INTEGRATION.md 4b).
  *
  * Only the import differs from the reference's controller: require('empic_native.js') in place of
  * the AMD module 'empic' (INTEGRATION.md section 2).
@@ -19,7 +22,7 @@ const fs = require('fs');
 const path = require('path');
 const empic = require(path.join(__dirname, '..', 'fusion-sim_amd', 'js', 'empic_native.js'));
 
-const args = { frames: 100, every: 10, out: null, seed: 1 };
+const args = { frames: 100, every: 10, out: null, seed: 1, raster: 0 };
 for (let i = 2; i < process.argv.length; i += 2) args[process.argv[i].replace(/^--/, '')] = process.argv[i + 1];
 const frames = Number(args.frames), every = Number(args.every);
 
@@ -30,6 +33,7 @@ function random() { state = (Math.imul(state, 1664525) + 1013904223) >>> 0; retu
 const nparticles = 160000;
 const spec = { radius: 1, height: 2, nr: 400, nz: 800, dt: 2e-9, nparticles: 400,
     particle_mass: 1.67e-27, particle_charge: 1.602e-19 };
+if (Number(args.raster)) spec.raster_subpixel_bits = Number(args.raster);
 const simulation = empic.makeCylindricalParticlePusher(spec);
 
 const sink = [], source = [], position = [], velocity = [];
@@ -84,5 +88,5 @@ const dens = simulation.readDensity();
 let total = 0;
 for (let k = 0; k < spec.nr * spec.nz; k++) if (dens[4 * k + 3] === dens[4 * k + 3]) total += dens[4 * k + 3];
 console.log(JSON.stringify({ frames: frames, seconds: seconds, fps: frames / seconds, particles: nparticles, alive: alive,
-    images: written, density_sum: total, arch: empic.buildArch() }));
+    images: written, density_sum: total, arch: empic.buildArch(), comm: simulation.commInfo() }));   // comm: { rank, world } as the library sees them
 simulation.destroy();

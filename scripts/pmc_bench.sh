@@ -5,7 +5,7 @@ set -e
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_$1
 mkdir -p $OUT
-CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extensions"
+CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extensions --no-strong-c4"   # (the 512^3 block has no place under the serialising PMC passes of the headline)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.json 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.json 2> $OUT/write.err
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/tcc -- $CMD > $OUT/tcc.json 2> $OUT/tcc.err

@@ -1003,6 +1003,49 @@ simulation.destroy();
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-3)
 
 
+def test_node_shim_draws_the_sprites_the_browser_drew(tmp_path):
+    """Node -> empic_native.js with spec.raster_subpixel_bits = 4 against tests/golden/webgl_probe.*: the 25 isolated sprites
+    the reference drew under Chromium's WebGL, through the shipped JavaScript host — and commInfo() of a handle without and
+    with a communicator."""
+    import base64
+    import json
+    import os
+    import shutil
+    import subprocess
+    from helpers import ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    meta, get = _webgl("webgl_probe")
+    (tmp_path / "in.json").write_text(json.dumps(dict(spec=dict(meta["spec"], raster_subpixel_bits=WEBGL_BITS), position=meta["position_in"],
+                                                      velocity=meta["velocity_in"], sink=meta["sink_in"], pdf=meta["pdf_in"], rand=meta["rand0"])))
+    script = r"""
+const fs = require('fs');
+const empic = require(process.argv[1]);
+const inp = JSON.parse(fs.readFileSync(process.argv[2]));
+const sim = empic.makeCylindricalParticlePusher(inp.spec);
+sim.set({position: inp.position, velocity: inp.velocity, sink_mask: inp.sink, source_pdf: inp.pdf});
+sim.setRandomState({rand: inp.rand});
+const alone = sim.commInfo();
+sim.commInit(empic.commUniqueId(), 0, 1);
+const joined = sim.commInfo();
+sim.precalc(); sim.step(); sim.density();
+let bad = 'none';
+try { empic.makeCylindricalParticlePusher(Object.assign({}, inp.spec, {raster_subpixel_bits: 9})); } catch (e) { bad = e.message; }
+const b64 = a => Buffer.from(a.buffer, a.byteOffset, a.byteLength).toString('base64');
+console.log(JSON.stringify({moments: b64(sim.readMoments()), alone: alone, joined: joined, bad: bad}));
+sim.destroy();
+"""
+    shim = os.path.join(ROOT, "fusion-sim_amd", "js", "empic_native.js")
+    raw = subprocess.check_output([node, "-e", script, shim, str(tmp_path / "in.json")])
+    out = json.loads(raw.decode().strip().splitlines()[-1])
+    got = np.frombuffer(base64.b64decode(out["moments"]), dtype=np.float32)
+    want = get("density1/moments01")
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    assert out["alone"] == {"rank": 0, "world": 1} and out["joined"] == {"rank": 0, "world": 1}
+    assert out["bad"].startswith(".raster_subpixel_bits <- ")
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_library_communicator_world_of_one(fp, po, overlap):
     """fpic_comm_*: the RCCL communicator inside the library (one rank: the same calls, collectives and
