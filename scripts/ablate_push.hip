@@ -20,9 +20,38 @@ struct ProbeArgs {
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 enum { NO_ENTROPY = 1, NO_COEF = 2, NO_SINK = 4, FAST_MATH = 8, NO_STORE = 16, NO_RAND_IO = 32, ENTROPY_1MB = 64, ENTROPY_16KB = 128, ENTROPY_4MB = 256,
+       HOT_FIRST = 512, HOT_ROWS = 1024, // timing only: the texel's place under a layout that puts the hot texels first (round 4)
        GATHER_AUX_SHIFT = 12 }; // bits 12..: (aux + 1) of a buffer-instruction gather: 1 = sc0, 2 = nt, 16 = sc1, sums thereof
 
 typedef unsigned int nat_b128 __attribute__((ext_vector_type(4)));
+
+// Round 4: where would texel (i, j) of the entropy table sit if the table were laid out hot texels first?  The logistic
+// map's invariant density is the arcsine law, so lookups concentrate where i or j is near 0 or 1023: heat ~ 1/sqrt(a b)
+// with a, b the distances to the nearer edge.  Levels la = bit length of a (0..9), blocks (la, lb) of 2^(la-1) x 2^(lb-1) x 4
+// texels in the order of la + lb.  g_hot_base[la][lb] = first texel of the block.
+__constant__ int g_hot_base[10][10];
+__device__ __forceinline__ int hot_first_index(int i, int j)
+{
+    const int a = min(i, 1023 - i), b = min(j, 1023 - j);
+    const int la = 32 - __clz(a), lb = 32 - __clz(b);                 // 0 for a == 0, else floor(log2 a) + 1
+    const int wa = la ? 1 << (la - 1) : 1, wb = lb ? 1 << (lb - 1) : 1; // block extents
+    const int oa = la ? a - wa : 0, ob = lb ? b - wb : 0;
+    const int quad = (i > 511) | ((j > 511) << 1);
+    return g_hot_base[la][lb] + ((ob * wa + oa) << 2) + quad;
+}
+static void fill_hot_base()
+{
+    int base[10][10], next = 0;
+    for (int g = 0; g <= 18; ++g)
+        for (int la = 0; la < 10; ++la) {
+            const int lb = g - la;
+            if (lb < 0 || lb > 9) continue;
+            base[la][lb] = next;
+            next += 4 * (la ? 1 << (la - 1) : 1) * (lb ? 1 << (lb - 1) : 1);
+        }
+    if (next != 1024 * 1024) { printf("hot layout covers %d texels\n", next); exit(1); }
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_hot_base), base, sizeof base));
+}
 
 template <int M>
 __device__ __forceinline__ void substep_v(Particle<float>& q, const ProbeArgs& a)
@@ -33,6 +62,8 @@ __device__ __forceinline__ void substep_v(Particle<float>& q, const ProbeArgs& a
         if (M & ENTROPY_1MB) et &= 0xFFFF;      // timing only: 64K texels = 1 MB footprint
         if (M & ENTROPY_4MB) et &= 0x3FFFF;     // 4 MB
         if (M & ENTROPY_16KB) et &= 0x3FF;      // 16 KB
+        if (M & HOT_FIRST) et = hot_first_index(ngp(q.c1, kEntropySide), ngp(q.c2, kEntropySide));
+        if (M & HOT_ROWS) { const int j = ngp(q.c2, kEntropySide), b = min(j, 1023 - j); et = ngp(q.c1, kEntropySide) + kEntropySide * (2 * b + (j > 511)); } // rows folded: hot rows first
         constexpr int aux1 = M >> GATHER_AUX_SHIFT;
         if constexpr (aux1 == 0) {
             load4(a.entropy + 4 * static_cast<size_t>(et), s);
@@ -200,6 +231,7 @@ int main(int argc, char** argv)
     a.p = p; a.coef = coef; a.sink_alive = sink; a.inv_cdf_xy = inv; a.entropy = ent;
     a.nr = grid; a.nz = grid; a.step_factor = 0.5996f; a.n = n; a.nsub = 2;
     const int reps = 5;
+    fill_hot_base();
     for (int sorted = 1; sorted >= 0; --sorted) {
         printf("---- particles %s, n=%zu, nsub=2\n", sorted ? "tile-sorted" : "random order", n);
         printf("full                       %.3f ms\n", run<0, 256>(a, reps, p, sorted, grid));
@@ -219,6 +251,8 @@ int main(int argc, char** argv)
         printf(" + entropy, buffer load sc1          %.3f ms\n", run<NO_COEF | NO_SINK | (17 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
         printf(" + entropy, buffer load sc0 sc1      %.3f ms\n", run<NO_COEF | NO_SINK | (18 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
         printf(" + entropy, buffer load sc1 nt       %.3f ms\n", run<NO_COEF | NO_SINK | (19 << GATHER_AUX_SHIFT), 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, hot texels first %.3f ms\n", run<NO_COEF | NO_SINK | HOT_FIRST, 256>(a, reps, p, sorted, grid));
+        printf(" + entropy, hot rows first   %.3f ms\n", run<NO_COEF | NO_SINK | HOT_ROWS, 256>(a, reps, p, sorted, grid));
         printf(" + entropy footprint 4 MB  %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_4MB, 256>(a, reps, p, sorted, grid));
         printf(" + entropy footprint 1 MB  %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_1MB, 256>(a, reps, p, sorted, grid));
         printf(" + entropy footprint 16 KB %.3f ms\n", run<NO_COEF | NO_SINK | ENTROPY_16KB, 256>(a, reps, p, sorted, grid));
