@@ -159,6 +159,53 @@ __global__ __launch_bounds__(BS) void push_v(ProbeArgs a)
     *reinterpret_cast<uchar4*>(a.p.alive + base) = make_uchar4(q[0].alive, q[1].alive, q[2].alive, q[3].alive);
 }
 
+__global__ void init_k(ParticleArrays<float> p, size_t n, int sorted, int grid);
+
+// Round 4: K3 alone.  The random state's advance (empic.js:783-820) reads nothing of the particle's motion: what if it ran as
+// a kernel of its own — 16 B in, the two dependent table gathers, 16 B out — beside a push that streams 50 B?
+template <int BS, int NT>
+__global__ __launch_bounds__(BS) void rng_only(ProbeArgs a)
+{
+    constexpr int PPT = 4;
+    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * PPT;
+    if (base >= a.n) return;
+    float u1[PPT], u2[PPT], c1[PPT], c2[PPT];
+    load_lane<float, PPT>(a.p.u1, base, u1); load_lane<float, PPT>(a.p.u2, base, u2);
+    load_lane<float, PPT>(a.p.c1, base, c1); load_lane<float, PPT>(a.p.c2, base, c2);
+    for (int s = 0; s < a.nsub; ++s) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            float e[4];
+            const int et = ngp(c1[k], kEntropySide) + kEntropySide * ngp(c2[k], kEntropySide);
+            load4(a.entropy + 4 * static_cast<size_t>(et), e);
+            const float x0 = 0.999f * c1[k] + 0.001f * e[2], x1 = 0.999f * c2[k] + 0.001f * e[3];
+            const float m0 = u1[k] + e[0], m1 = u2[k] + e[1];
+            u1[k] = (m0 > 1.f) ? m0 - 1.f : m0; u2[k] = (m1 > 1.f) ? m1 - 1.f : m1;
+            c1[k] = 4.f * x0 * (1.f - x0); c2[k] = 4.f * x1 * (1.f - x1);
+        }
+    }
+    store_lane<float, PPT>(a.p.u1, base, u1); store_lane<float, PPT>(a.p.u2, base, u2);
+    store_lane<float, PPT>(a.p.c1, base, c1); store_lane<float, PPT>(a.p.c2, base, c2);
+}
+
+template <int BS>
+float run_rng(ProbeArgs a, int reps, ParticleArrays<float> p, int grid)
+{
+    init_k<<<(a.n + 255) / 256, 256>>>(p, a.n, 1, grid);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const unsigned nb = static_cast<unsigned>((a.n / 4 + BS - 1) / BS);
+    rng_only<BS, 0><<<nb, BS>>>(a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) rng_only<BS, 0><<<nb, BS>>>(a);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 __global__ void init_k(ParticleArrays<float> p, size_t n, int sorted, int grid)
 {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -232,6 +279,11 @@ int main(int argc, char** argv)
     a.nr = grid; a.nz = grid; a.step_factor = 0.5996f; a.n = n; a.nsub = 2;
     const int reps = 5;
     fill_hot_base();
+    printf("---- K3 alone (random state: 16 B in, 2 dependent gathers, 16 B out), n=%zu\n", n);
+    printf("rng only, block 256        %.3f ms\n", run_rng<256>(a, reps, p, grid));
+    printf("rng only, block 1024       %.3f ms\n", run_rng<1024>(a, reps, p, grid));
+    printf("push without the random state: no entropy, no rand I/O, no coef/sink gathers  %.3f ms\n", run<NO_ENTROPY | NO_RAND_IO | NO_COEF | NO_SINK, 256>(a, reps, p, 1, grid));
+    printf("push without the random state, with coef/sink gathers                         %.3f ms\n", run<NO_ENTROPY | NO_RAND_IO, 256>(a, reps, p, 1, grid));
     for (int sorted = 1; sorted >= 0; --sorted) {
         printf("---- particles %s, n=%zu, nsub=2\n", sorted ? "tile-sorted" : "random order", n);
         printf("full                       %.3f ms\n", run<0, 256>(a, reps, p, sorted, grid));
