@@ -18,6 +18,8 @@ back through the reference's own fb.readPixels (utilities.js:701-711).  Only num
   webgl_sor.json + .f32.gz       matrix_webgl.makeSORIterative, the cases of swgl_sor
   webgl_demo.json + .f32.gz      fusionsim.js's 400 x 800 / 160 000-particle scene: SHA-256 of every texture of every
                                  stage + every 61st particle + the touched window of the deposit
+  webgl_rand<k>.json + .f32.gz   16 small scenes with everything drawn at random (grid, cylinder, time step, species, fields,
+                                 masks, painters), inputs and every texture in the blob, the 512^2 injection table by digest
   webgl_info.json                what the GL implementation says about itself
 
 The scenes `webgl_scene` and `webgl_tall` take their inputs from tests/golden/swgl_scene.json / swgl_tall.json unchanged,
@@ -139,6 +141,8 @@ def write_json(path, obj):
         f.write("\n")
 
 
+N_RANDOM = 16      # webgl_rand0 .. webgl_rand15
+
 WHAT = ("outputs of the reference's own host code and shaders run by a real WebGL 1 implementation (kaleido's headless "
         "Chromium, ANGLE on SwiftShader), read back with the reference's fb.readPixels; generated by "
         "oracle/make_golden_webgl.py")
@@ -163,6 +167,7 @@ def run_pic(br, ref, name, job, out_dir, inputs_meta, full=True, keep=None):
     meta = {"what": WHAT, "gl": rep["gl"], "spec": job["spec"], "frames": job["frames"], "entropy_lcg_seed": job["seed"],
             "entropy_rule": ENTROPY_RULE, "painters": job.get("painters", []), "api": rep["api"],
             "layout": "RGBA float32, texel 4*(i + width*j)", "file": name + ".f32.gz"}
+    blob_inputs = inputs_meta.pop("inputs", None)
     meta.update(inputs_meta)
     # the inverse-CDF table: the frame buffer the shaders read must be the host table set() built (a copy draw), and
     # only x, y carry data; store those two channels once
@@ -177,7 +182,17 @@ def run_pic(br, ref, name, job, out_dir, inputs_meta, full=True, keep=None):
     stamp = arrays["init/stamp"].reshape(-1, 4)
     meta["stamp_gba_equal_red"] = bool(np.all(stamp[:, 1:] == stamp[:, :1]))
     arrays["init/stamp_red"] = np.ascontiguousarray(stamp[:, 0])
-    if full:
+    if full == "compact":   # inputs and the random state in the blob, the 512^2 injection table by digest
+        for key, a in blob_inputs.items():
+            blob.put("in/" + key, a)
+        blob.put("in/rand0", arrays["init/rand0"])
+        meta["sha256"] = {"set/inv_cdf_xy": sha(arrays["set/inv_cdf_xy"])}
+        meta["sha256_rule"] = "SHA-256 of the little-endian float32 bytes with every NaN replaced by 0x7FC00000"
+        for key in sorted(arrays):
+            if key.startswith("init/") or key == "set/inv_cdf_xy":
+                continue
+            blob.put(key, arrays[key])
+    elif full:
         meta["rand0"] = [float(v) for v in arrays["init/rand0"]]
         for key in sorted(arrays):
             if key.startswith("init/") and key != "init/stamp_red":
@@ -233,6 +248,40 @@ def scene_f32(br, ref, out_dir, name, spec, seed, input_seed, frames, painters, 
     inputs = {"position_in": pos.astype(float).tolist(), "velocity_in": vel.astype(float).tolist(), "E_in": E.astype(float).tolist(),
               "B_in": B.astype(float).tolist(), "sink_in": sk.astype(float).tolist(), "pdf_in": pd.astype(float).tolist()}
     return run_pic(br, ref, name, job, out_dir, inputs)
+
+
+def scene_random(br, ref, out_dir, k):
+    """A small scene with everything drawn at random from seed k — grid, cylinder, time step, species, fields, masks, painters:
+    breadth for the constants the factory bakes into its shader text (toFixed(20) literals re-read by the GLSL compiler) and
+    for the index arithmetic on grids that are neither square nor powers of two.  Inputs are stored as float32 in the blob
+    (`in/...`), not as JSON."""
+    rng = np.random.default_rng(1000 + k)
+    nr, nz = int(rng.integers(5, 25)), int(rng.integers(5, 25))
+    electron = bool(rng.integers(0, 2))
+    spec = {"radius": float(np.float32(rng.uniform(0.1, 3.0))), "height": float(np.float32(rng.uniform(0.1, 3.0))), "nr": nr, "nz": nz,
+            "dt": float(10.0 ** rng.uniform(-10.5, -8.5)), "nparticles": int(rng.integers(5, 17)),
+            "particle_mass": 9.109e-31 if electron else 1.67e-27, "particle_charge": -1.602e-19 if electron else 1.602e-19}
+    ring = int(rng.integers(0, 3))
+    keep = rng.random((nr, nz)) > rng.uniform(0.0, 0.4)
+    dead_rows = rng.random(nr) < 0.25
+    dead_rows[0] = False                  # (an empty first row makes the reference's set() throw: quirk Q12)
+    pos, vel, E, B, sk, pd = f32_scene(spec, 5000 + k, r_max=float(rng.uniform(0.7, 1.05)), v=float(10.0 ** rng.uniform(-2.5, -0.3)),
+                                       E_amp=float(10.0 ** rng.uniform(3, 6.5)) * (0 if k % 4 == 3 else 1), B_amp=float(10.0 ** rng.uniform(-2, 0.3)),
+                                       sink=lambda i, j: np.where(keep[i, j] & (i < nr - ring) & (j >= ring) & (j < nz - ring), 1.0, 0.0),
+                                       pdf=lambda i, j, u: np.where(dead_rows[i] | (u < 0.3), 0.0, u), z_lo=-0.02 if k % 3 == 0 else 0.05,
+                                       z_hi=1.03 if k % 3 == 0 else 0.95)
+    pd[0, :] = np.maximum(pd[0, :], np.float32(0.125))
+    menu = [["addBZ", float(np.float32(rng.normal(0, 0.3)))], ["addBTheta", float(np.float32(rng.normal(0, 0.1)))],
+            ["addCurrentZ", float(np.float32(rng.normal(0, 3e4)))],
+            ["addCurrentLoop", float(np.float32(rng.uniform(0.2, 0.9) * spec["radius"])), float(np.float32(rng.uniform(0, 1) * spec["height"])), float(np.float32(rng.normal(0, 1e6)))]]
+    painters = [menu[i] for i in range(4) if rng.random() < 0.6]
+    name = "webgl_rand%d" % k
+    job = {"spec": spec, "seed": 0x5EED1000 + k, "frames": 3, "painters": painters, "position": b64f32(pos), "velocity": b64f32(vel),
+           "E": b64f32(E), "B": b64f32(B), "sink_mask": b64f32(sk), "source_pdf": b64f32(pd)}
+    inputs = {"inputs_in_blob": {"position": list(pos.shape), "velocity": list(vel.shape), "E": list(E.shape), "B": list(B.shape),
+                                 "sink_mask": list(sk.shape), "source_pdf": list(pd.shape)},
+              "inputs": {"position": pos, "velocity": vel, "E": E, "B": B, "sink_mask": sk, "source_pdf": pd}}
+    return run_pic(br, ref, name, job, out_dir, inputs, full="compact")
 
 
 def scene_probe(br, ref, out_dir):
@@ -403,6 +452,9 @@ def main():
                       r_max=0.98, v=0.4, E_amp=1e6, B_amp=0.5,
                       sink=lambda i, j: np.where(((i + j) % 3 == 0) | (i >= 28) | (j < 2) | (j >= 22), 0.0, 1.0),
                       pdf=lambda i, j, u: np.where((i % 4 == 2) | (j == 0) | (i > 25), 0.0, 0.1 + u))
+        for k in range(N_RANDOM):
+            if want("webgl_rand%d" % k):
+                scene_random(br, ref, out, k)
         if want("webgl_demo"):
             scene_demo(br, ref, out)
         if want("webgl_sor"):

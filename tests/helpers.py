@@ -59,3 +59,21 @@ def uniform_plasma(n, spec, seed=0x5EEDF051, v_th=1e-3, margin=0.0):
     entropy = rng.random(1024 * 1024 * 4, dtype=np.float32)
     rand = rng.random((n, 4), dtype=np.float32)
     return pos, vel, entropy, rand
+
+
+def load_webgl(name):
+    """A tests/golden/webgl_* fixture (oracle/make_golden_webgl.py): (meta, get(key) -> float32 array, inputs) with inputs =
+    position / velocity / E / B / sink_mask / source_pdf as set() takes them and rand0, whether the fixture keeps them as JSON
+    lists or as float32 in its blob (`in/...`)."""
+    meta = load_json(name + ".json")
+    blob = load_f32gz(meta["file"])
+    get = lambda key: blob[meta["index"][key][0]: meta["index"][key][0] + meta["index"][key][1]]
+    if "inputs_in_blob" in meta:
+        inputs = {k: get("in/" + k).reshape(shape).astype(np.float64) for k, shape in meta["inputs_in_blob"].items()}
+        inputs["rand0"] = get("in/rand0")
+    elif "position_in" in meta:
+        inputs = {"position": meta["position_in"], "velocity": meta["velocity_in"], "E": meta["E_in"], "B": meta["B_in"],
+                  "sink_mask": meta["sink_in"], "source_pdf": meta["pdf_in"], "rand0": np.asarray(meta["rand0"], dtype=np.float32)}
+    else:
+        inputs = None       # (webgl_demo: regenerated from the rules the fixture states)
+    return meta, get, inputs

@@ -21,19 +21,20 @@ import hashlib
 import numpy as np
 import pytest
 
-from helpers import load_f32gz, load_json, same_bits
+from helpers import load_f32gz, load_json, load_webgl, same_bits
 from pic_oracle import OracleSim, stamp as oracle_stamp
 from test_oracle_swgl import lcg_entropy
 
-SCENES = ["webgl_scene", "webgl_tall", "webgl_efield", "webgl_nan", "webgl_probe"]
+RANDOM = ["webgl_rand%d" % k for k in range(16)]      # everything drawn at random: grid, cylinder, dt, species, fields, masks, painters
+SCENES = ["webgl_scene", "webgl_tall", "webgl_efield", "webgl_nan", "webgl_probe"] + RANDOM
 BITS = 4    # gl.getParameter(SUBPIXEL_BITS) of the implementation that wrote the fixtures (webgl_info.json)
 FLOOR = 1e-30   # relative to the image's maximum: below it live the stamp's outermost ring (<= 1.7e-34) and flushed denormals
 
 
 def load_scene(name):
-    meta = load_json(name + ".json")
-    blob = load_f32gz(meta["file"])
-    return meta, (lambda key: blob[meta["index"][key][0]: meta["index"][key][0] + meta["index"][key][1]])
+    meta, get, inputs = load_webgl(name)
+    meta["_inputs"] = inputs
+    return meta, get
 
 
 @pytest.fixture(scope="module", params=SCENES)
@@ -43,10 +44,17 @@ def scene(request):
 
 def fresh(meta, **kw):
     sim = OracleSim(meta["spec"], np.float32, **kw)
-    sim.set_random_state(entropy=lcg_entropy(meta["entropy_lcg_seed"]), rand=np.asarray(meta["rand0"], dtype=np.float32))
-    sim.set(position=meta["position_in"], velocity=meta["velocity_in"], E=meta["E_in"], B=meta["B_in"],
-            sink_mask=meta["sink_in"], source_pdf=meta["pdf_in"])
+    i = meta["_inputs"]
+    sim.set_random_state(entropy=lcg_entropy(meta["entropy_lcg_seed"]), rand=i["rand0"])
+    sim.set(position=i["position"], velocity=i["velocity"], E=i["E"], B=i["B"], sink_mask=i["sink_mask"], source_pdf=i["source_pdf"])
     return sim
+
+
+def sha(a):
+    a = np.ascontiguousarray(a, dtype="<f4").copy()
+    u = a.view("<u4")
+    u[np.isnan(a)] = 0x7FC00000
+    return hashlib.sha256(u.tobytes()).hexdigest()
 
 
 PAINT = {"addCurrentLoop": "add_current_loop", "addCurrentZ": "add_current_z", "addBZ": "add_bz", "addBTheta": "add_btheta"}
@@ -69,14 +77,15 @@ def test_the_fixtures_come_from_a_real_webgl():
 def test_random_state_follows_the_stated_rule(scene):
     meta, get = scene
     n = meta["spec"]["nparticles"] ** 2
+    rand0 = meta["_inputs"]["rand0"]
     x, want = meta["entropy_lcg_seed"], []
     for _ in range(4 * 1024 * 1024 + 8):
         x = (1664525 * x + 1013904223) & 0xFFFFFFFF
         if len(want) < 8 and _ >= 4 * 1024 * 1024:
             want.append(np.float32(x / 4294967296.0))
-    assert same_bits(np.asarray(meta["rand0"][:8], dtype=np.float32), np.asarray(want))
-    assert len(meta["rand0"]) == 4 * n
-    assert same_bits(get("set/rand_A"), np.asarray(meta["rand0"], dtype=np.float32))
+    assert same_bits(np.asarray(rand0[:8], dtype=np.float32), np.asarray(want))
+    assert len(rand0) == 4 * n
+    assert same_bits(get("set/rand_A"), np.asarray(rand0, dtype=np.float32))
 
 
 @pytest.mark.parametrize("name", ["position_A", "velocity_A", "E", "B", "sink_mask"])
@@ -90,6 +99,9 @@ def test_upload(scene, name):
 def test_inverse_cdf_and_stamp(scene):
     meta, get = scene
     sim = fresh(meta)
+    if "sha256" in meta:      # the compact fixtures keep the 512 x 512 table by digest
+        assert sha(sim.inv_cdf.reshape(-1, 4)[:, :2]) == meta["sha256"]["set/inv_cdf_xy"]
+        return
     assert same_bits(sim.inv_cdf.reshape(-1, 4)[:, :2].ravel(), get("set/inv_cdf_xy"))
     assert same_bits(oracle_stamp(), get("init/stamp_red"))
 
@@ -225,7 +237,10 @@ def test_software_evaluator_against_the_real_compiler():
     """The swgl_* fixtures of round 1 (our evaluator of the shader text) and the webgl_* fixtures of the same scenes: identical
     wherever no transcendental is involved; the loop painter's cos() separates them afterwards by parts in 1e5."""
     for sw_name, gl_name in (("swgl_scene", "webgl_scene"), ("swgl_tall", "webgl_tall")):
-        (ms, gs), (mw, gw) = load_scene(sw_name), load_scene(gl_name)
+        ms = load_json(sw_name + ".json")
+        bs = load_f32gz(ms["file"])
+        gs = lambda key: bs[ms["index"][key][0]: ms["index"][key][0] + ms["index"][key][1]]
+        mw, gw = load_scene(gl_name)
         assert ms["spec"] == mw["spec"] and ms["position_in"] == mw["position_in"] and ms["rand0"] == mw["rand0"]
         for key in ("set/position_A", "set/velocity_A", "set/rand_A", "set/E", "set/B", "set/sink_mask", "painted/E"):
             assert same_bits(gs(key), gw(key)), key
@@ -237,13 +252,6 @@ def test_software_evaluator_against_the_real_compiler():
 
 
 # ------------------------------------------------------------------------------------------- the demo at its own size
-
-def sha(a):
-    a = np.ascontiguousarray(a, dtype="<f4").copy()
-    u = a.view("<u4")
-    u[np.isnan(a)] = 0x7FC00000
-    return hashlib.sha256(u.tobytes()).hexdigest()
-
 
 def demo_inputs(meta):
     """Regenerate the inputs from the rules the fixture states (input_rule, sink_rule, pdf_rule, entropy_rule)."""
