@@ -389,7 +389,9 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
     solve_mode = "interface" if solve_mode == "interface" and not em else True
     nspecies = 1 if em else 2          # configs[4] names no second species: electrons against a neutralising background
     share = total // nspecies // world
-    migrate_every = 2 * ghost
+    # a thermal electron of this scene moves 0.08 cells per sub-step: with a migration every 2 G sub-steps the 6.3-sigma tail of
+    # 2e9 particles outran G = 4 ghost planes (5 or 6 particles lost per run in rounds 2 and 3); 2 G - 2 leaves 8.4 sigma
+    migrate_every = max(2, 2 * ghost - 2)
     if em:  # the time step of the Yee lattice (c dt = dx / 2 sqrt 3): a thermal electron moves 3e-4 cells per sub-step
         dx = L / grid
         spec = dict(spec, solver="yee", dt=0.5 * dx / (2.998e8 * 3 ** 0.5), macro_weight=spec["macro_weight"] * 2)
@@ -508,7 +510,9 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
     spec, L, vth, mi, qi = c4_scene(total, grid, world)
     nspecies = 1 if em else 2
     share = total // nspecies // world
-    migrate_every = 2 * ghost
+    # a thermal electron of this scene moves 0.08 cells per sub-step: with a migration every 2 G sub-steps the 6.3-sigma tail of
+    # 2e9 particles outran G = 4 ghost planes (5 or 6 particles lost per run in rounds 2 and 3); 2 G - 2 leaves 8.4 sigma
+    migrate_every = max(2, 2 * ghost - 2)
     if em:
         spec = dict(spec, solver="yee", dt=0.5 * (L / grid) / (2.998e8 * 3 ** 0.5), macro_weight=spec["macro_weight"] * 2)
         migrate_every = 64

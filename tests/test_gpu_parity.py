@@ -1060,7 +1060,7 @@ def test_node_shim_draws_the_sprites_the_browser_drew(tmp_path):
         pytest.skip("node is not installed on this box")
     meta, get = _webgl("webgl_probe")
     (tmp_path / "in.json").write_text(json.dumps(dict(spec=dict(meta["spec"], raster_subpixel_bits=WEBGL_BITS), position=meta["position_in"],
-                                                      velocity=meta["velocity_in"], sink=meta["sink_in"], pdf=meta["pdf_in"], rand=meta["rand0"])))
+                                                      velocity=meta["velocity_in"], sink=meta["sink_in"], pdf=meta["pdf_in"], rand=np.asarray(meta["rand0"], dtype=np.float64).tolist())))
     script = r"""
 const fs = require('fs');
 const empic = require(process.argv[1]);
