@@ -229,6 +229,21 @@ function makeOracle(spec, opts) {
         }
     };
 
+    // opts.raster_bits = b > 0: the point sprites as a rasteriser with b sub-pixel bits draws them (the C twin's deposit_raster,
+    // pic_oracle_impl.h: clip coordinate 2u - 1, window position snapped to 2^-b pixel with ties to even and y running downwards,
+    // left/top edges inclusive, cropped instead of discarded); first column / first row from the bottom, or null when dropped
+    const rasterBits = opts.raster_bits | 0;
+    function roundHalfEven(v) { const r = Math.round(v); return (r - v === 0.5 && r % 2 !== 0) ? r - 1 : r; }
+    function rasterFirst(u, W, yDown) {
+        const ndc = f(f(2 * u) - 1);
+        const sc = 1 << rasterBits;
+        const wb = f(f(W * 0.5) * sc), x0 = f(wb - f(sc * 0.5));
+        const s = f(x0 + f(ndc * (yDown ? -wb : wb)));
+        if (!(s > -1073741824 && s < 1073741824)) return null;
+        const X = roundHalfEven(s), p0 = Math.ceil((X - 11 * sc / 2) / sc);
+        return yDown ? W - 1 - (p0 + 10) : p0;
+    }
+
     o.density = function () {                                        // empic.js:1471-1495
         const M = o.moments, pos = o.pos_A, vel = o.vel_A, w = o.stamp;
         M.fill(0);
@@ -236,13 +251,20 @@ function makeOracle(spec, opts) {
             const q = 4 * p;
             const x = pos[q], y = pos[q + 1], z = pos[q + 2];
             const r = f(Math.sqrt(f(f(x * x) + f(y * y))));
-            if (!(r >= 0 && r <= 1 && z >= 0 && z <= 1)) continue;
+            let ic, jc;
+            if (rasterBits) {
+                const i0 = rasterFirst(r, nr, false), j0 = rasterFirst(z, nz, true);
+                if (i0 === null || j0 === null || i0 >= nr || i0 + 10 < 0 || j0 >= nz || j0 + 10 < 0) continue;
+                ic = i0 + 5; jc = j0 + 5;
+            } else {
+                if (!(r >= 0 && r <= 1 && z >= 0 && z <= 1)) continue;
+                ic = Math.floor(f(r * nr)); jc = Math.floor(f(z * nz));
+            }
             const dx = f(x / r), dy = f(y / r);
             const c0 = f(C001 * f(f(vel[q] * dx) + f(vel[q + 1] * dy)));
             const c1 = f(C001 * f(f(vel[q + 1] * dx) - f(vel[q] * dy)));
             const c2 = f(C001 * vel[q + 2]);
             const c3 = C001;
-            const ic = Math.floor(f(r * nr)), jc = Math.floor(f(z * nz));
             for (let dj = -5; dj <= 5; dj++) {
                 const j = jc + dj;
                 if (j < 0 || j >= nz) continue;

@@ -19,7 +19,7 @@ DRIVER = r"""
 const fs = require('fs');
 const {makeOracle} = require(process.argv[2]);
 const inp = JSON.parse(fs.readFileSync(process.argv[3]));
-const sim = makeOracle(inp.spec, {precision: inp.precision});
+const sim = makeOracle(inp.spec, {precision: inp.precision, raster_bits: inp.raster_bits || 0});
 sim.set({E: inp.E, B: inp.B, position: inp.position, velocity: inp.velocity, sink_mask: inp.sink, source_pdf: inp.pdf});
 const ent = new Float32Array(fs.readFileSync(inp.entropy_file).buffer.slice(0));
 sim.setRandomState({entropy: ent, rand: Float32Array.from(inp.rand)});
@@ -33,8 +33,9 @@ fs.writeFileSync(process.argv[4], JSON.stringify(out));
 """
 
 
+@pytest.mark.parametrize("raster_bits", [0, 4])
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
-def test_js_twin_matches_c_oracle(tmp_path, precision):
+def test_js_twin_matches_c_oracle(tmp_path, precision, raster_bits):
     import base64
     dtype = np.float32 if precision == "fp32" else np.float64
     spec = make_spec(24, 20, 30, radius=0.35, height=0.2)
@@ -47,7 +48,7 @@ def test_js_twin_matches_c_oracle(tmp_path, precision):
     ent_file = tmp_path / "entropy.f32"
     entropy.tofile(ent_file)
     inp = dict(spec=spec, precision=precision, E=E.tolist(), B=B.tolist(), position=pos.tolist(), velocity=vel.tolist(),
-               sink=sink.tolist(), pdf=pdf.tolist(), rand=rand.ravel().tolist(), entropy_file=str(ent_file), cycles=3)
+               sink=sink.tolist(), pdf=pdf.tolist(), rand=rand.ravel().tolist(), entropy_file=str(ent_file), cycles=3, raster_bits=raster_bits)
     (tmp_path / "in.json").write_text(json.dumps(inp))
     (tmp_path / "driver.js").write_text(DRIVER)
     subprocess.check_call([node, str(tmp_path / "driver.js"), os.path.join(ROOT, "oracle", "pic_oracle.js"),
@@ -55,7 +56,7 @@ def test_js_twin_matches_c_oracle(tmp_path, precision):
     out = json.loads((tmp_path / "out.json").read_text())
     js = {k: np.frombuffer(base64.b64decode(v), dtype=dtype) for k, v in out.items()}
 
-    sim = po.OracleSim(spec, dtype=dtype)
+    sim = po.OracleSim(spec, dtype=dtype, raster_bits=raster_bits)      # (4: the rasterised sprites of the WebGL fixtures)
     sim.set(E=E, B=B, position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
     sim.set_random_state(entropy, rand)
     sim.add_bz(0.125)
