@@ -425,6 +425,57 @@ int launch_push_all(fpic_handle* h, int part = 0)
     return FPIC_OK;
 }
 
+// The binning of a grid with more tiles than an LDS histogram holds (512^3: 65 536 tiles of 16 x 16 x 8, 262 144 of 8^3): census
+// and scatter both in two levels, no global atomic per particle anywhere (fes_kernels.hpp, bin3_count_coarse_kernel):
+// coarse census, coarse scan, coarse scatter; tile census of the coarse-sorted array, tile scan (+ work list), tile scatter.
+// Same result as the one-level census (FPIC_CENSUS_GLOBAL=1 keeps that form): the bin table is a function of the positions.
+template <typename T>
+int launch_bin_two_level_census(fpic_handle* h, Species& s)
+{
+    State* st = h->es;
+    const bool em = st->ltx == kEL;
+    const int nw = s.wl ^ 1;
+    uint32_t div = 1;
+    while (div * div < st->ntiles) ++div;
+    const uint32_t ncoarse = (st->ntiles + div - 1) / div;
+    uint32_t* aux = s.tile_cursor + st->ntiles;   // [ncoarse + 1]: the coarse counts and the live total, then chunk_first of the tile pass
+    auto columns = [&](int from) {
+        fpic::SortColumns<T, 6, false> c{};
+        for (int f = 0; f < 6; ++f) {
+            c.src[f] = static_cast<const T*>(s.slab[from]) + f * s.n_pad;
+            c.dst[f] = static_cast<T*>(s.slab[from ^ 1]) + f * s.n_pad;
+        }
+        c.src_id = s.id[from]; c.dst_id = s.id[from ^ 1];
+        return c;
+    };
+    const size_t lds = fpic::sort_scatter_lds(sizeof(T));
+    const unsigned nc = blocks_for(s.n, fpic::kSortChunk), ncount = blocks_for(s.n, 1024 * kCoarsePer);
+    auto run = [&](auto key) -> int {
+        using Key = decltype(key);
+        auto kern = fpic::sort_scatter_kernel<T, 6, false, Key>;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        HIP_TRY(h, hipMemsetAsync(s.tile_cursor, 0, sizeof(uint32_t) * (st->ntiles + ncoarse + 1), h->stream));
+        bin3_count_coarse_kernel<T, Key><<<ncount, 1024, 0, h->stream>>>(static_cast<const T*>(s.slab[s.cur]), s.n_pad, s.n, key, div, ncoarse, aux);
+        coarse_scan_kernel<<<1, 1024, 0, h->stream>>>(aux, ncoarse, div, s.tile_start2[nw]);
+        kern<<<nc, fpic::kSortThreads, lds, h->stream>>>(columns(s.cur), s.n, key, st->ntiles, div, ncoarse, s.tile_start2[nw], s.tile_cursor, nullptr);
+        bin3_count_sorted_kernel<T, Key><<<ncount, 1024, 0, h->stream>>>(static_cast<const T*>(s.slab[s.cur ^ 1]), s.n_pad, aux + ncoarse, key, div, s.tile_count);
+        bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
+        HIP_TRY(h, hipMemsetAsync(s.tile_cursor, 0, sizeof(uint32_t) * st->ntiles, h->stream));
+        fpic::sort_chunks_kernel<<<1, 1024, 0, h->stream>>>(s.tile_start2[nw], st->ntiles, div, ncoarse, aux);
+        kern<<<nc + ncoarse, fpic::kSortThreads, lds, h->stream>>>(columns(s.cur ^ 1), s.n, key, st->ntiles, div, ncoarse, s.tile_start2[nw], s.tile_cursor, aux);
+        return FPIC_OK;
+    };
+    if (int rc = em ? run(BoxTileKey<T, kEL, kEL, kEL>{ st->nx, st->ny, st->nz, st->ntx, st->nty }) : run(BoxTileKey<T>{ st->nx, st->ny, st->nz, st->ntx, st->nty }))
+        return rc;
+    HIP_TRY(h, hipGetLastError());
+    s.wl = nw;                // (two passes: the compact sorted array is back in the set it started in)
+    s.layout++;
+    s.binned = true;
+    s.ids_identity = false;
+    s.census_fresh = s.rebin_pending = s.chunk_census_fresh = false;
+    return FPIC_OK;
+}
+
 // re-bin one species by tile, out of place (count, scan, scatter)
 template <typename T>
 int launch_bin(fpic_handle* h, Species& s)
@@ -439,6 +490,7 @@ int launch_bin(fpic_handle* h, Species& s)
     HIP_TRY(h, hipMemsetAsync(s.tile_count, 0, sizeof(uint32_t) * st->ntiles, h->stream));
     const bool em = st->ltx == kEL;
     const bool many_tiles = st->ntiles > static_cast<uint32_t>(kMaxTiles3); // no LDS histogram of that size
+    if (many_tiles && !std::getenv("FPIC_CENSUS_GLOBAL")) return launch_bin_two_level_census<T>(h, s);
     if (many_tiles && em) bin3_count_global_kernel<T, kEL, kEL, kEL><<<blocks_for(s.n), 256, 0, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, s.tile_count);
     else if (many_tiles) bin3_count_global_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, s.tile_count);
     else if (em) bin3_count_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);

@@ -978,6 +978,75 @@ __global__ __launch_bounds__(256) void bin3_count_global_kernel(const T* __restr
     if (todo) atomicAdd(&tile_count[key], 1u);
 }
 
+// Round 4: the census of a grid with more tiles than an LDS histogram holds WITHOUT a global atomic per particle.  A freshly
+// uploaded population is in random order: bin3_count_global_kernel then sends 1e9 atomics to 65 536 counters (41 ms per
+// species at configs[3]).  The staged scatter is two-level anyway, so the census is too: (1) coarse bins (div consecutive
+// tiles, <= 1024 of them) counted in an LDS histogram; (2) after the coarse pass the array is sorted by coarse bin, and a
+// workgroup's chunk lies in one coarse bin (or straddles two): the tiles of that bin are counted in LDS again.
+constexpr int kCoarsePer = 8;
+template <typename T, typename Key>
+__global__ __launch_bounds__(1024) void bin3_count_coarse_kernel(const T* __restrict__ slab, size_t stride, size_t n, Key key_of_pos, uint32_t div, uint32_t ncoarse,
+                                                                 uint32_t* __restrict__ coarse_count)
+{
+    __shared__ uint32_t hist[1024];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = static_cast<size_t>(blockIdx.x) * (1024 * kCoarsePer);
+#pragma unroll
+    for (int k = 0; k < kCoarsePer; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 1024 + threadIdx.x;
+        if (i >= n) continue;
+        const uint32_t key = key_of_pos(slab[i], slab[stride + i], slab[2 * stride + i]);
+        if (key != ~0u) atomicAdd(&hist[key / div], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < ncoarse && hist[threadIdx.x]) atomicAdd(&coarse_count[threadIdx.x], hist[threadIdx.x]);
+}
+
+// exclusive scan of the coarse counts into the places the coarse pass of sort_scatter_kernel reads (tile_start[c * div]); the
+// live total behind the last count
+static __global__ __launch_bounds__(1024) void coarse_scan_kernel(uint32_t* __restrict__ coarse_count, uint32_t ncoarse, uint32_t div, uint32_t* __restrict__ tile_start)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t c = threadIdx.x;
+    const uint32_t v = c < ncoarse ? coarse_count[c] : 0;
+    part[c] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t t = c >= static_cast<uint32_t>(o) ? part[c - o] : 0;
+        __syncthreads();
+        part[c] += t;
+        __syncthreads();
+    }
+    if (c < ncoarse) tile_start[c * div] = part[c] - v;
+    if (c == 1023) coarse_count[ncoarse] = part[1023];
+}
+
+template <typename T, typename Key>
+__global__ __launch_bounds__(1024) void bin3_count_sorted_kernel(const T* __restrict__ slab, size_t stride, const uint32_t* __restrict__ live, Key key_of_pos, uint32_t div,
+                                                                 uint32_t* __restrict__ tile_count)
+{
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t c0s;
+    const size_t n = *live, base = static_cast<size_t>(blockIdx.x) * (1024 * kCoarsePer);
+    if (base >= n) return;
+    hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) c0s = key_of_pos(slab[base], slab[stride + base], slab[2 * stride + base]) / div;
+    __syncthreads();
+    const uint32_t c0 = c0s;
+#pragma unroll
+    for (int k = 0; k < kCoarsePer; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 1024 + threadIdx.x;
+        if (i >= n) continue;
+        const uint32_t key = key_of_pos(slab[i], slab[stride + i], slab[2 * stride + i]);
+        if (key == ~0u) continue;                       // (the coarse pass copies no dead slot: cannot happen, costs nothing)
+        if (key / div == c0) atomicAdd(&hist[key - c0 * div], 1u);
+        else atomicAdd(&tile_count[key], 1u);           // the chunk straddles into the next coarse bin
+    }
+    __syncthreads();
+    if (threadIdx.x < div && hist[threadIdx.x]) atomicAdd(&tile_count[c0 * div + threadIdx.x], hist[threadIdx.x]);
+}
+
 template <typename T, int LX = 4, int LY = 4, int LZ = 3>
 __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t stride, const uint32_t* __restrict__ src_id,
                                                            uint32_t* __restrict__ dst_id, size_t n, int nx, int ny, int nz, int ntx, int nty,
