@@ -2392,6 +2392,15 @@ template <typename T>
 int dom_precalc(Ranks& rk)
 {
     for (fpic_handle* h : rk.hs) {
+        // a "decomposition" of one rank (bench.py's strong_c4 at N = 1) bins a large fresh population before its first deposit
+        // like an undecomposed handle (precalc()); the ranks of a real decomposition do not: whether a rank is binned decides
+        // whether its first sub-step migrates, and that decision must not depend on one rank's population
+        if (h->es->dom->world == 1 && h->es->solver != FPIC_SOLVER_YEE) {
+            bool bin_first = false;
+            for (const Species& sp : h->es->sp) bin_first |= !sp.binned && sp.n >= h->two_level_min;
+            if (bin_first)
+                if (int e = bin_all<T>(h, false)) return e;
+        }
         if (int e = deposit_cycle<T, true>(h)) return e;
         h->deposit_launches++;
     }
