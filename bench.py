@@ -762,12 +762,11 @@ def main():
 
     stream = torch.cuda.Stream(device=local_rank)
 
-    def build(rng_mode, shape="ref11", raster_bits=0):
+    def build(rng_mode, shape="ref11"):
         # counter mode: no gather hides the LDS atomics of the fused sums, so only the tile census and
         # the re-binning stay in the push there (spec.unfused_deposit = 2)
         s_ = fp.makeCylindricalParticlePusher(spec, device=local_rank, rng=rng_mode, seed=0x5EEDF051, count=n_local if strong else 0, sort_interval=args.sort_interval,
-                                              fuse_deposit="census" if (rng_mode == "counter" or shape == "cic") else True, shape=shape,
-                                              raster_subpixel_bits=raster_bits)
+                                              fuse_deposit="census" if (rng_mode == "counter" or shape == "cic") else True, shape=shape)
         s_.setStream(stream.cuda_stream)
         s_.set(position=pos, velocity=vel, sink_mask=sink, source_pdf=pdf)
         if rng_mode == "reference":
@@ -990,26 +989,6 @@ def main():
             "push_avg_launch_ms": cs["ms_push"] / max(1, cs["step_launches"]),
             "cic_sums_avg_launch_ms": cs["ms_deposit"] / max(1, cs["deposit_launches"]), "rebinning_launches": cs["sort_passes"]}
         cic.destroy()
-        # the headline frame with density()'s sprites drawn as a rasteriser with 4 sub-pixel bits draws them (the convention under which
-        # the library reproduces the reference's own WebGL run bit for bit): the switch changes which cell a
-        # sprite is centred on, nothing else
-        ras = build("reference", raster_bits=4)
-        ras.precalc(); ras.sort()
-        for _ in range(args.warmup):
-            ras.precalc(); ras.step(); ras.density()
-        ras.sync(); torch.cuda.synchronize()
-        ras.resetStats(); ras.profile(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ras.precalc(); ras.step(); ras.density()
-        ras.sync(); torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        rs = ras.stats()
-        out["extensions"]["c2_raster4"] = {
-            "what": "spec.raster_subpixel_bits = 4: the same frame with the point sprites snapped and cropped as Chromium's SwiftShader rasteriser does",
-            "value": 2.0 * n_local * args.steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / args.steps,
-            "push_avg_launch_ms": rs["ms_push"] / max(1, rs["step_launches"]), "rebinning_launches": rs["sort_passes"]}
-        ras.destroy()
         out["extensions"]["dense_sor"] = dense_sor_line(local_rank)
         out["extensions"]["em"] = em_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, "fp64")
         out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(8, args.steps // 4), 1, stream=stream,
