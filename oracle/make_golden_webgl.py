@@ -14,7 +14,8 @@ density() — every shader compiled by the browser's GLSL compiler and run by it
 back through the reference's own fb.readPixels (utilities.js:701-711).  Only numbers are written:
 
   webgl_<scene>.json + .f32.gz   same layout as the swgl_* fixtures of oracle/make_golden.js (index of [offset, length]
-                                 into one float32 blob), so tests/ can hold the oracle and the HIP library to both
+                                 into one float32 blob), so tests/ can hold the oracle and the HIP library to both;
+                                 inputs that are exactly float32 live in the blob too (`in/...`, `inputs_in_blob`)
   webgl_sor.json + .f32.gz       matrix_webgl.makeSORIterative, the cases of swgl_sor
   webgl_demo.json + .f32.gz      fusionsim.js's 400 x 800 / 160 000-particle scene: SHA-256 of every texture of every
                                  stage + every 61st particle + the touched window of the deposit
@@ -182,10 +183,11 @@ def run_pic(br, ref, name, job, out_dir, inputs_meta, full=True, keep=None):
     stamp = arrays["init/stamp"].reshape(-1, 4)
     meta["stamp_gba_equal_red"] = bool(np.all(stamp[:, 1:] == stamp[:, :1]))
     arrays["init/stamp_red"] = np.ascontiguousarray(stamp[:, 0])
-    if full == "compact":   # inputs and the random state in the blob, the 512^2 injection table by digest
+    if blob_inputs is not None:   # inputs that are exactly float32 live in the blob, not in the JSON (and so does the random state)
         for key, a in blob_inputs.items():
             blob.put("in/" + key, a)
         blob.put("in/rand0", arrays["init/rand0"])
+    if full == "compact":   # ... and the 512^2 injection table by digest
         meta["sha256"] = {"set/inv_cdf_xy": sha(arrays["set/inv_cdf_xy"])}
         meta["sha256_rule"] = "SHA-256 of the little-endian float32 bytes with every NaN replaced by 0x7FC00000"
         for key in sorted(arrays):
@@ -193,7 +195,8 @@ def run_pic(br, ref, name, job, out_dir, inputs_meta, full=True, keep=None):
                 continue
             blob.put(key, arrays[key])
     elif full:
-        meta["rand0"] = [float(v) for v in arrays["init/rand0"]]
+        if blob_inputs is None:
+            meta["rand0"] = [float(v) for v in arrays["init/rand0"]]
         for key in sorted(arrays):
             if key.startswith("init/") and key != "init/stamp_red":
                 continue
@@ -245,8 +248,9 @@ def scene_f32(br, ref, out_dir, name, spec, seed, input_seed, frames, painters, 
     pos, vel, E, B, sk, pd = f32_scene(spec, input_seed, **kw)
     job = {"spec": spec, "seed": seed, "frames": frames, "painters": painters, "position": b64f32(pos), "velocity": b64f32(vel),
            "E": b64f32(E), "B": b64f32(B), "sink_mask": b64f32(sk), "source_pdf": b64f32(pd)}
-    inputs = {"position_in": pos.astype(float).tolist(), "velocity_in": vel.astype(float).tolist(), "E_in": E.astype(float).tolist(),
-              "B_in": B.astype(float).tolist(), "sink_in": sk.astype(float).tolist(), "pdf_in": pd.astype(float).tolist()}
+    inputs = {"inputs_in_blob": {"position": list(pos.shape), "velocity": list(vel.shape), "E": list(E.shape), "B": list(B.shape),
+                                 "sink_mask": list(sk.shape), "source_pdf": list(pd.shape)},
+              "inputs": {"position": pos, "velocity": vel, "E": E, "B": B, "sink_mask": sk, "source_pdf": pd}}
     return run_pic(br, ref, name, job, out_dir, inputs)
 
 
@@ -306,8 +310,10 @@ def scene_probe(br, ref, out_dir):
     ones = np.ones((64, 64), dtype=np.float32)
     job = {"spec": spec, "seed": 0x5EED000A, "frames": 1, "painters": [], "position": b64f32(pos), "velocity": b64f32(vel),
            "sink_mask": b64f32(ones), "source_pdf": b64f32(ones)}
-    inputs = {"position_in": pos.astype(float).tolist(), "velocity_in": vel.astype(float).tolist(), "E_in": None, "B_in": None,
-              "sink_in": ones.astype(float).tolist(), "pdf_in": ones.astype(float).tolist(), "offsets_r": fr, "offsets_z": fz}
+    zero = np.zeros((64, 64, 3), dtype=np.float32)
+    inputs = {"inputs_in_blob": {"position": list(pos.shape), "velocity": list(vel.shape), "E": [64, 64, 3], "B": [64, 64, 3], "sink_mask": [64, 64],
+                                 "source_pdf": [64, 64]},
+              "inputs": {"position": pos, "velocity": vel, "E": zero, "B": zero, "sink_mask": ones, "source_pdf": ones}, "offsets_r": fr, "offsets_z": fz}
     return run_pic(br, ref, "webgl_probe", job, out_dir, inputs)
 
 

@@ -1059,8 +1059,9 @@ def test_node_shim_draws_the_sprites_the_browser_drew(tmp_path):
     if node is None:
         pytest.skip("node is not installed on this box")
     meta, get = _webgl("webgl_probe")
-    (tmp_path / "in.json").write_text(json.dumps(dict(spec=dict(meta["spec"], raster_subpixel_bits=WEBGL_BITS), position=meta["position_in"],
-                                                      velocity=meta["velocity_in"], sink=meta["sink_in"], pdf=meta["pdf_in"], rand=np.asarray(meta["rand0"], dtype=np.float64).tolist())))
+    lst = lambda a: np.asarray(a, dtype=np.float64).tolist()
+    (tmp_path / "in.json").write_text(json.dumps(dict(spec=dict(meta["spec"], raster_subpixel_bits=WEBGL_BITS), position=lst(meta["position_in"]),
+                                                      velocity=lst(meta["velocity_in"]), sink=lst(meta["sink_in"]), pdf=lst(meta["pdf_in"]), rand=lst(meta["rand0"]))))
     script = r"""
 const fs = require('fs');
 const empic = require(process.argv[1]);
