@@ -310,10 +310,9 @@ def scene_probe(br, ref, out_dir):
     ones = np.ones((64, 64), dtype=np.float32)
     job = {"spec": spec, "seed": 0x5EED000A, "frames": 1, "painters": [], "position": b64f32(pos), "velocity": b64f32(vel),
            "sink_mask": b64f32(ones), "source_pdf": b64f32(ones)}
-    zero = np.zeros((64, 64, 3), dtype=np.float32)
-    inputs = {"inputs_in_blob": {"position": list(pos.shape), "velocity": list(vel.shape), "E": [64, 64, 3], "B": [64, 64, 3], "sink_mask": [64, 64],
-                                 "source_pdf": [64, 64]},
-              "inputs": {"position": pos, "velocity": vel, "E": zero, "B": zero, "sink_mask": ones, "source_pdf": ones}, "offsets_r": fr, "offsets_z": fz}
+    # (no E, no B: set() is not given them, so the reference's field textures keep their initial zeros, alpha included)
+    inputs = {"inputs_in_blob": {"position": list(pos.shape), "velocity": list(vel.shape), "sink_mask": [64, 64], "source_pdf": [64, 64]},
+              "inputs": {"position": pos, "velocity": vel, "sink_mask": ones, "source_pdf": ones}, "offsets_r": fr, "offsets_z": fz}
     return run_pic(br, ref, "webgl_probe", job, out_dir, inputs)
 
 

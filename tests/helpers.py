@@ -71,6 +71,8 @@ def load_webgl(name):
     if "inputs_in_blob" in meta:
         inputs = {k: get("in/" + k).reshape(shape).astype(np.float64) for k, shape in meta["inputs_in_blob"].items()}
         inputs["rand0"] = get("in/rand0")
+        for k in ("E", "B"):                    # a scene whose set() was not given a field
+            inputs.setdefault(k, None)
     elif "position_in" in meta:
         inputs = {"position": meta["position_in"], "velocity": meta["velocity_in"], "E": meta["E_in"], "B": meta["B_in"],
                   "sink_mask": meta["sink_in"], "source_pdf": meta["pdf_in"], "rand0": np.asarray(meta["rand0"], dtype=np.float32)}
