@@ -76,6 +76,11 @@ struct State {
     void *rho = nullptr, *hat = nullptr, *phi = nullptr, *E4 = nullptr;
     // full EM (solver = YEE): the lattice's E and B, the node-centred B (E4 holds the node-centred E), the integer current grid
     void *Ey = nullptr, *By = nullptr, *B4n = nullptr;
+    // the chained lattice step of an undecomposed full-EM handle (em_chain_kernel): B at half time, two arrays taken in turns;
+    // em_open: Ey is E of the integer time reached, Bh[bh_cur] is B half a step before it, By is stale until em_close()
+    void* Bh[2] = { nullptr, nullptr };
+    int bh_cur = 0;
+    bool em_open = false;
     long long* Jfix = nullptr;
     double* k2[3] = {};
     rocfft_plan fwd = nullptr, inv = nullptr;
@@ -919,22 +924,40 @@ struct EmCoef {
 };
 
 template <typename T>
-int em_half_b(fpic_handle* h, const EmCoef<T>& c, int k0, int nk)
+int em_half_b(fpic_handle* h, const EmCoef<T>& c, int k0, int nk, const void* from = nullptr, void* to = nullptr)
 {
     State* st = h->es;
     k0 = (k0 % st->nz + st->nz) % st->nz;
-    em_update_b_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->By), static_cast<const T*>(st->Ey), st->nx, st->ny,
-                                                                                                     st->nz, c.cb[0], c.cb[1], c.cb[2], k0, nk, held_of(st));
+    em_update_b_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(to ? to : st->By), static_cast<const T*>(st->Ey), st->nx, st->ny,
+                                                                                                     st->nz, c.cb[0], c.cb[1], c.cb[2], k0, nk, held_of(st),
+                                                                                                     static_cast<const T*>(from));
     HIP_TRY(h, hipGetLastError());
     return FPIC_OK;
 }
 
+// By <- the B of the integer time the chained step has reached (the half step it left open); whoever reads or replaces By calls it
 template <typename T>
-int em_full_e(fpic_handle* h, const EmCoef<T>& c, int k0, int nk)
+int em_close(fpic_handle* h)
+{
+    State* st = h->es;
+    if (!st->em_open) return FPIC_OK;
+    const EmCoef<T> co(h);
+    if (int rc = em_half_b<T>(h, co, 0, st->nz, st->Bh[st->bh_cur], st->By)) return rc;
+    st->em_open = false;
+    return FPIC_OK;
+}
+int em_close_any(fpic_handle* h)
+{
+    if (!h->es || !h->es->em_open) return FPIC_OK;
+    return h->prec == FPIC_F32 ? em_close<float>(h) : em_close<double>(h);
+}
+
+template <typename T>
+int em_full_e(fpic_handle* h, const EmCoef<T>& c, int k0, int nk, const void* b = nullptr)
 {
     State* st = h->es;
     k0 = (k0 % st->nz + st->nz) % st->nz;
-    em_update_e_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(st->By), st->Jfix, st->nx,
+    em_update_e_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(b ? b : st->By), st->Jfix, st->nx,
                                                                                                      st->ny, st->nz, c.ce[0], c.ce[1], c.ce[2], c.je, c.js[0], c.js[1],
                                                                                                      c.js[2], k0, nk, held_of(st));
     HIP_TRY(h, hipGetLastError());
@@ -948,6 +971,7 @@ int em_precalc(fpic_handle* h)
     if (int rc = deposit_cycle<T, true>(h)) return rc;
     h->deposit_launches++;
     if (int rc = launch_solve<T>(h)) return rc; // rho -> phi -> E on the edges
+    st->em_open = false;                        // (both lattice fields are set afresh)
     fill4_kernel<T><<<blocks_for(held_nodes(st)), 256, 0, h->stream>>>(static_cast<T*>(st->By), held_nodes(st), static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
                                                                      static_cast<T>(st->B0[2]));
     HIP_TRY(h, hipGetLastError());
@@ -975,7 +999,32 @@ int em_substep(fpic_handle* h)
     if (rebin)
         if (int rc = bin_all<T>(h, true)) return rc;
     HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
-    if (int rc = em_nodes<T>(h)) return rc;
+    // FPIC_EM_CHAIN=1 (round 4, measured and NOT adopted as the default): the lattice in two sweeps per sub-step instead of
+    // four — the sub-step's second B half step, the next sub-step's node centring and its first B half step as one kernel
+    // (em_chain_kernel) between two half-time arrays, B at the integer time formed when somebody asks for it (em_close).
+    // Bit-identical, 21.5 GB of HBM traffic instead of 43 GB at 512^3 fp64 — and no faster: the kernel re-forms B on three
+    // neighbouring faces per component (60 cached loads per node) and is bound by the L1, not by HBM: 13.74 ms per sub-step
+    // against 13.62 ms at 256^3 / 5e8 (profiles/r04_em_chain_ablation.txt).  An LDS-tiled form would be needed to collect.
+    const char* chain_env = std::getenv("FPIC_EM_CHAIN");
+    const bool chain = chain_env && std::strcmp(chain_env, "1") == 0 && !st->dom;
+    const EmCoef<T> co(h);
+    if (!chain && st->em_open)      // (the switch was turned off between two sub-steps)
+        if (int rc = em_close<T>(h)) return rc;
+    if (chain && !st->Bh[0]) {
+        int rc;
+        if ((rc = dev_alloc(h, &st->Bh[0], st->nodes * 4 * sizeof(T), &h->bytes_grid)) || (rc = dev_alloc(h, &st->Bh[1], st->nodes * 4 * sizeof(T), &h->bytes_grid))) return rc;
+    }
+    if (chain && st->em_open) {
+        timing_begin(h, KC_SOLVE);
+        em_chain_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->Bh[st->bh_cur]), static_cast<const T*>(st->Ey), st->nx, st->ny, st->nz,
+                                                                       co.cb[0], co.cb[1], co.cb[2], static_cast<T*>(st->E4), static_cast<T*>(st->B4n),
+                                                                       static_cast<T*>(st->Bh[st->bh_cur ^ 1]));
+        HIP_TRY(h, hipGetLastError());
+        timing_end(h);
+        st->bh_cur ^= 1;
+    } else if (int rc = em_nodes<T>(h)) {
+        return rc;
+    }
     timing_begin(h, KC_PUSH);
     HIP_TRY(h, hipMemsetAsync(st->Jfix, 0, st->nodes * 3 * sizeof(long long), h->stream));
     if (int rc = em_push_all<T>(h)) return rc;
@@ -987,10 +1036,18 @@ int em_substep(fpic_handle* h)
         st->spill_pending[slot] = true;
     }
     timing_begin(h, KC_SOLVE);
-    const EmCoef<T> co(h);
-    if (int rc = em_half_b<T>(h, co, 0, st->nz)) return rc;
-    if (int rc = em_full_e<T>(h, co, 0, st->nz)) return rc;
-    if (int rc = em_half_b<T>(h, co, 0, st->nz)) return rc;
+    if (chain) {
+        if (!st->em_open) { // from B at the integer time: its first half step goes to the half-time array, By goes stale
+            st->bh_cur = 0;
+            if (int rc = em_half_b<T>(h, co, 0, st->nz, st->By, st->Bh[0])) return rc;
+            st->em_open = true;
+        }
+        if (int rc = em_full_e<T>(h, co, 0, st->nz, st->Bh[st->bh_cur])) return rc;
+    } else {
+        if (int rc = em_half_b<T>(h, co, 0, st->nz)) return rc;
+        if (int rc = em_full_e<T>(h, co, 0, st->nz)) return rc;
+        if (int rc = em_half_b<T>(h, co, 0, st->nz)) return rc;
+    }
     timing_end(h);
     st->substeps_since_bin++;
     h->step_launches++;
@@ -1315,7 +1372,7 @@ void release(fpic_handle* h)
         }
         delete d;
     }
-    for (void* p : { st->Ey, st->By, st->B4n, static_cast<void*>(st->Jfix), st->fft_tw[0], st->fft_tw[1], st->fft_tw[2] })
+    for (void* p : { st->Ey, st->By, st->B4n, st->Bh[0], st->Bh[1], static_cast<void*>(st->Jfix), st->fft_tw[0], st->fft_tw[1], st->fft_tw[2] })
         if (p) (void)hipFree(p);
     for (void* p : { static_cast<void*>(st->rho_fixed), st->rho, st->hat, st->phi, st->E4, static_cast<void*>(st->k2[0]), static_cast<void*>(st->k2[1]),
                      static_cast<void*>(st->k2[2]), st->work_f, st->work_i, static_cast<void*>(st->spilled), static_cast<void*>(st->joint_work),
@@ -1676,6 +1733,7 @@ int save_checkpoint(fpic_handle* h, const char* path)
 {
     State* st = h->es;
     if (st->dom) return save_rank_checkpoint(h, path);
+    if (int rc = em_close_any(h)) return rc;    // (the file holds B of the integer time)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     BoxFile bf{ std::fopen(path, "wb") };
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);
@@ -1747,6 +1805,7 @@ int load_checkpoint(fpic_handle* h, const char* path)
     if (int rc = checkpoint_arrays(h, bf.f, false)) return rc;
     for (int a = 0; a < 3; ++a) st->B0[a] = hd.B0[a];
     st->fields_ready = hd.fields_ready != 0;
+    st->em_open = false;    // (the file's B is B of the integer time)
     return FPIC_OK;
 }
 
@@ -1767,6 +1826,7 @@ int set_field3(fpic_handle* h, int which, const void* data, int nx, int ny, int 
     if (nx != st->nx || ny != st->ny || nz != st->nz) return fail(h, FPIC_ERR_INVALID_ARG, ".grid <- expected %d x %d x %d, got %d x %d x %d", st->nx, st->ny, st->nz, nx, ny, nz);
     if (dtype != FPIC_F32 && dtype != FPIC_F64) return fail(h, FPIC_ERR_INVALID_ARG, ".dtype <- must be 0 (f32) or 1 (f64)");
     st->fields_ready = true;
+    if (int rc0 = em_close_any(h)) return rc0;  // (an upload of one lattice field leaves the other at the integer time)
     void* target = which == FPIC_F3_E ? st->E4 : (which == FPIC_F3_EDGE_E ? st->Ey : st->By);
     int rc;
     if (h->prec == FPIC_F32)
@@ -1792,6 +1852,8 @@ int read_field3(fpic_handle* h, int which, void* out, int dtype)
 {
     State* st = h->es;
     if (!out) return fail(h, FPIC_ERR_INVALID_ARG, ".out <- Non-optional property is undefined!");
+    if (which == FPIC_F3_FACE_B)
+        if (int rc = em_close_any(h)) return rc;   // (B of the integer time is formed when somebody asks for it)
     if (which == FPIC_F3_RHO_FIXED || which == FPIC_F3_J_FIXED) {
         if (which == FPIC_F3_J_FIXED && !st->Jfix) return fail(h, FPIC_ERR_STATE, ".which <- the current grid exists in the full-EM mode only (spec.solver = 2)");
         const void* src = which == FPIC_F3_RHO_FIXED ? static_cast<const void*>(st->rho_fixed) : static_cast<const void*>(st->Jfix);
@@ -2721,6 +2783,7 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
 {
     State* st = h->es;
     if (st->dom) return fail(h, FPIC_ERR_STATE, "the handle is already decomposed");
+    if (int rc0 = em_close_any(h)) return rc0;
     if (world < 1 || rank < 0 || rank >= world) return fail(h, FPIC_ERR_INVALID_ARG, ".rank <- %d is outside a world of %d", rank, world);
     if (st->nz % world) return fail(h, FPIC_ERR_INVALID_ARG, ".world <- the %d planes along z do not divide into %d slabs", st->nz, world);
     const int nzl = st->nz / world;

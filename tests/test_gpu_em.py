@@ -577,3 +577,44 @@ def test_em_randomised_against_the_oracle(fp, eo, monkeypatch, seed):
         fixed = sim.readField(fp.F3_RHO_FIXED)
         assert np.array_equal(fixed, ora.rho_fixed), (seed, frame)
     sim.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_chained_lattice_step_is_bit_identical(fp, eo, monkeypatch, precision):
+    """FPIC_EM_CHAIN=1 (round 4; measured, not the default — DESIGN.md 9): the second B half step of a sub-step, the next
+    sub-step's node centring and its first B half step as ONE sweep between two half-time arrays, B of the integer time
+    formed only when somebody reads it.  Against the oracle's four-sweep cycle: particles, the integer current and both
+    lattice fields bit for bit after every frame, with read-backs (which close the chain) at different points of it, a
+    checkpoint in between and the switch turned off half way."""
+    monkeypatch.setenv("FPIC_EM_CHAIN", "1")
+    rng = np.random.default_rng(44)
+    shape, L, n = (12, 10, 16), (0.012, 0.010, 0.016), 6000
+    dt = cfl_dt(shape, L, 0.5)
+    spec = em_spec(shape, L, n, dt, macro_weight=1e6)
+    dtype = np.float32 if precision == "fp32" else np.float64
+    sim, ora = fp.makeCylindricalParticlePusher(spec, precision=precision), eo.OracleES3D(spec, dtype)
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.3, (n, 3))
+    E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
+    for s in (sim, ora):
+        s.set(position=pos, velocity=vel)
+    sim.set(edge_E=E, face_B=B); ora.set_lattice(E=E, B=B)
+
+    def same(tag, fields=True):
+        got = sim.getParticles()
+        assert same_bits(got["position"], ora.positions()) and same_bits(got["velocity"], ora.velocities()), tag
+        if fields:
+            assert np.array_equal(sim.readField(fp.F3_J_FIXED).ravel(), ora.J_fixed), tag
+            assert same_bits(sim.readField(fp.F3_EDGE_E).ravel(), ora.Ey), tag
+            assert same_bits(sim.readField(fp.F3_FACE_B).ravel(), ora.By), tag
+
+    sim.step(); ora.step()                    # two sub-steps: one from the integer time, one chained
+    same("after one frame")
+    sim.step(3); ora.step(3)                  # six chained on
+    same("after four frames, particles only", fields=False)      # (no read-back of B: the chain stays open)
+    sim.substeps(1); ora.em_substep()
+    same("after an odd sub-step")
+    sim.step(2); ora.step(2)
+    monkeypatch.setenv("FPIC_EM_CHAIN", "0")  # the switch goes off while the chain is open
+    sim.step(); ora.step()
+    same("after the switch went off")
+    sim.destroy()
