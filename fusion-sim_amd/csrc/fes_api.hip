@@ -999,14 +999,14 @@ int em_substep(fpic_handle* h)
     if (rebin)
         if (int rc = bin_all<T>(h, true)) return rc;
     HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
-    // FPIC_EM_CHAIN=1 (round 4, measured and NOT adopted as the default): the lattice in two sweeps per sub-step instead of
-    // four — the sub-step's second B half step, the next sub-step's node centring and its first B half step as one kernel
-    // (em_chain_kernel) between two half-time arrays, B at the integer time formed when somebody asks for it (em_close).
-    // Bit-identical, 21.5 GB of HBM traffic instead of 43 GB at 512^3 fp64 — and no faster: the kernel re-forms B on three
-    // neighbouring faces per component (60 cached loads per node) and is bound by the L1, not by HBM: 13.74 ms per sub-step
-    // against 13.62 ms at 256^3 / 5e8 (profiles/r04_em_chain_ablation.txt).  An LDS-tiled form would be needed to collect.
+    // The lattice in two sweeps per sub-step instead of four (round 4): the sub-step's second B half step, the next sub-step's
+    // node centring and its first B half step are ONE kernel (em_chain_tiled_kernel) between two half-time arrays; B at the
+    // integer time is formed when somebody asks for it (em_close).  Bit-identical to the four sweeps; 13.0 against 13.7 ms per
+    // sub-step at 256^3 / 5e8 fp64 (profiles/r04_em_chain_ablation.txt).  FPIC_EM_CHAIN=0 keeps the four sweeps, =flat the
+    // form without LDS (one thread per node, 48 cached loads each: bound by the L1, no faster than four sweeps).
     const char* chain_env = std::getenv("FPIC_EM_CHAIN");
-    const bool chain = chain_env && std::strcmp(chain_env, "1") == 0 && !st->dom;
+    if (!chain_env) chain_env = "1";
+    const bool chain = std::strcmp(chain_env, "0") != 0 && !st->dom;
     const EmCoef<T> co(h);
     if (!chain && st->em_open)      // (the switch was turned off between two sub-steps)
         if (int rc = em_close<T>(h)) return rc;
@@ -1016,9 +1016,17 @@ int em_substep(fpic_handle* h)
     }
     if (chain && st->em_open) {
         timing_begin(h, KC_SOLVE);
-        em_chain_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->Bh[st->bh_cur]), static_cast<const T*>(st->Ey), st->nx, st->ny, st->nz,
-                                                                       co.cb[0], co.cb[1], co.cb[2], static_cast<T*>(st->E4), static_cast<T*>(st->B4n),
-                                                                       static_cast<T*>(st->Bh[st->bh_cur ^ 1]));
+        if (std::strcmp(chain_env, "flat") == 0) {
+            em_chain_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->Bh[st->bh_cur]), static_cast<const T*>(st->Ey), st->nx, st->ny, st->nz,
+                                                                           co.cb[0], co.cb[1], co.cb[2], static_cast<T*>(st->E4), static_cast<T*>(st->B4n),
+                                                                           static_cast<T*>(st->Bh[st->bh_cur ^ 1]));
+        } else {
+            const unsigned tiles = static_cast<unsigned>(((st->nx + kCX - 1) / kCX) * ((st->ny + kCY - 1) / kCY) * ((st->nz + kCZ - 1) / kCZ));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(em_chain_tiled_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(em_chain_lds_bytes<T>())));
+            em_chain_tiled_kernel<T><<<tiles, kChainThreads, em_chain_lds_bytes<T>(), h->stream>>>(static_cast<const T*>(st->Bh[st->bh_cur]), static_cast<const T*>(st->Ey), st->nx,
+                                                                                                  st->ny, st->nz, co.cb[0], co.cb[1], co.cb[2], static_cast<T*>(st->E4),
+                                                                                                  static_cast<T*>(st->B4n), static_cast<T*>(st->Bh[st->bh_cur ^ 1]));
+        }
         HIP_TRY(h, hipGetLastError());
         timing_end(h);
         st->bh_cur ^= 1;

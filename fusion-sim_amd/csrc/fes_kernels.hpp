@@ -1183,6 +1183,72 @@ __global__ __launch_bounds__(256) void em_chain_kernel(const T* __restrict__ Bh,
     B4n[4 * c + 3] = static_cast<T>(0);
 }
 
+// The same sweep with the tile's E and half-time B staged in LDS and every face's integer-time B formed ONCE (em_chain_kernel
+// forms it up to four times and makes 48 cached loads per node: bound by the L1, profiles/r04_em_chain_ablation.txt).  A
+// workgroup owns kCX x kCY x kCZ nodes; it stages E on [-1, T]^3 and Bh on [-1, T-1]^3 (periodic), replaces Bh by b1 in place
+// — storing b1 - cb curl E for the faces it owns on the way — and then centres E and b1 on its nodes.  Expressions and operand
+// order are em_update_b_kernel's and em_nodes_kernel's.
+constexpr int kCX = 32, kCY = 4, kCZ = 4, kChainThreads = 256;   // (49 KB of LDS in double: three workgroups per CU)
+template <typename T>
+constexpr size_t em_chain_lds_bytes() { return (static_cast<size_t>(kCX + 2) * (kCY + 2) * (kCZ + 2) + static_cast<size_t>(kCX + 1) * (kCY + 1) * (kCZ + 1)) * 3 * sizeof(T); }
+
+template <typename T>
+__global__ __launch_bounds__(kChainThreads) void em_chain_tiled_kernel(const T* __restrict__ Bh, const T* __restrict__ Ey, int nx, int ny, int nz, T cbx, T cby, T cbz,
+                                                                       T* __restrict__ E4n, T* __restrict__ B4n, T* __restrict__ Bnext)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];
+    constexpr int EX = kCX + 2, EY = kCY + 2, EZ = kCZ + 2, BX = kCX + 1, BY = kCY + 1, BZ = kCZ + 1;
+    T* le = reinterpret_cast<T*>(chain_lds);        // [EZ][EY][EX][3]: E at offsets -1 .. T
+    T* lb = le + EX * EY * EZ * 3;                   // [BZ][BY][BX][3]: Bh, then b1, at offsets -1 .. T - 1
+    const int tiles_x = (nx + kCX - 1) / kCX, tiles_y = (ny + kCY - 1) / kCY;
+    const int x0 = static_cast<int>(blockIdx.x % tiles_x) * kCX, y0 = static_cast<int>((blockIdx.x / tiles_x) % tiles_y) * kCY;
+    const int z0 = static_cast<int>(blockIdx.x / (tiles_x * tiles_y)) * kCZ;
+    const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
+    auto wrap = [](int v, int n) { v %= n; return v < 0 ? v + n : v; };
+    for (int e = threadIdx.x; e < EX * EY * EZ; e += kChainThreads) {
+        const int a = e % EX, b = (e / EX) % EY, c = e / (EX * EY);
+        const size_t g = 4 * (static_cast<size_t>(wrap(x0 + a - 1, nx)) + sy * wrap(y0 + b - 1, ny) + sz * wrap(z0 + c - 1, nz));
+        le[3 * e] = Ey[g]; le[3 * e + 1] = Ey[g + 1]; le[3 * e + 2] = Ey[g + 2];
+    }
+    for (int f = threadIdx.x; f < BX * BY * BZ; f += kChainThreads) {
+        const int a = f % BX, b = (f / BX) % BY, c = f / (BX * BY);
+        const size_t g = 4 * (static_cast<size_t>(wrap(x0 + a - 1, nx)) + sy * wrap(y0 + b - 1, ny) + sz * wrap(z0 + c - 1, nz));
+        lb[3 * f] = Bh[g]; lb[3 * f + 1] = Bh[g + 1]; lb[3 * f + 2] = Bh[g + 2];
+    }
+    __syncthreads();
+    // E at LDS offsets (a, b, c) in [-1, T], component m
+    auto E = [&](int a, int b, int c, int m) { return le[3 * ((a + 1) + EX * ((b + 1) + EY * (c + 1))) + m]; };
+    for (int f = threadIdx.x; f < BX * BY * BZ; f += kChainThreads) {
+        const int a = f % BX - 1, b = (f / BX) % BY - 1, c = f / (BX * BY) - 1;       // the face's offsets, -1 .. T - 1
+        const T cx = (E(a, b + 1, c, 2) - E(a, b, c, 2)) * cby - (E(a, b, c + 1, 1) - E(a, b, c, 1)) * cbz;
+        const T cy = (E(a, b, c + 1, 0) - E(a, b, c, 0)) * cbz - (E(a + 1, b, c, 2) - E(a, b, c, 2)) * cbx;
+        const T cz = (E(a + 1, b, c, 1) - E(a, b, c, 1)) * cbx - (E(a, b + 1, c, 0) - E(a, b, c, 0)) * cby;
+        const T b1x = lb[3 * f] - cx, b1y = lb[3 * f + 1] - cy, b1z = lb[3 * f + 2] - cz;
+        lb[3 * f] = b1x; lb[3 * f + 1] = b1y; lb[3 * f + 2] = b1z;
+        const int gx = x0 + a, gy = y0 + b, gz = z0 + c;
+        if (a >= 0 && b >= 0 && c >= 0 && gx < nx && gy < ny && gz < nz) {            // a face of this workgroup's own nodes
+            const size_t g = 4 * (static_cast<size_t>(gx) + sy * gy + sz * gz);
+            Bnext[g] = b1x - cx; Bnext[g + 1] = b1y - cy; Bnext[g + 2] = b1z - cz; Bnext[g + 3] = static_cast<T>(0);
+        }
+    }
+    __syncthreads();
+    auto B1 = [&](int a, int b, int c, int m) { return lb[3 * ((a + 1) + BX * ((b + 1) + BY * (c + 1))) + m]; };
+    for (int n = threadIdx.x; n < kCX * kCY * kCZ; n += kChainThreads) {
+        const int a = n % kCX, b = (n / kCX) % kCY, c = n / (kCX * kCY);
+        const int gx = x0 + a, gy = y0 + b, gz = z0 + c;
+        if (gx >= nx || gy >= ny || gz >= nz) continue;
+        const size_t g = 4 * (static_cast<size_t>(gx) + sy * gy + sz * gz);
+        E4n[g] = static_cast<T>(0.5) * (E(a - 1, b, c, 0) + E(a, b, c, 0));
+        E4n[g + 1] = static_cast<T>(0.5) * (E(a, b - 1, c, 1) + E(a, b, c, 1));
+        E4n[g + 2] = static_cast<T>(0.5) * (E(a, b, c - 1, 2) + E(a, b, c, 2));
+        E4n[g + 3] = static_cast<T>(0);
+        B4n[g] = static_cast<T>(0.25) * (((B1(a, b - 1, c - 1, 0) + B1(a, b, c - 1, 0)) + B1(a, b - 1, c, 0)) + B1(a, b, c, 0));
+        B4n[g + 1] = static_cast<T>(0.25) * (((B1(a - 1, b, c - 1, 1) + B1(a, b, c - 1, 1)) + B1(a - 1, b, c, 1)) + B1(a, b, c, 1));
+        B4n[g + 2] = static_cast<T>(0.25) * (((B1(a - 1, b - 1, c, 2) + B1(a, b - 1, c, 2)) + B1(a - 1, b, c, 2)) + B1(a, b, c, 2));
+        B4n[g + 3] = static_cast<T>(0);
+    }
+}
+
 // E += ce * curl B - je * J, with J = T((double)Jfix * scale) formed on the fly (em_j_real + em_update_e), on the planes
 // k0 .. k0 + nk - 1 (they and the one below them are held)
 template <typename T>

@@ -579,14 +579,16 @@ def test_em_randomised_against_the_oracle(fp, eo, monkeypatch, seed):
     sim.destroy()
 
 
+@pytest.mark.parametrize("form", ["1", "flat"])
 @pytest.mark.parametrize("precision", ["fp32", "fp64"])
-def test_chained_lattice_step_is_bit_identical(fp, eo, monkeypatch, precision):
-    """FPIC_EM_CHAIN=1 (round 4; measured, not the default — DESIGN.md 9): the second B half step of a sub-step, the next
-    sub-step's node centring and its first B half step as ONE sweep between two half-time arrays, B of the integer time
-    formed only when somebody reads it.  Against the oracle's four-sweep cycle: particles, the integer current and both
-    lattice fields bit for bit after every frame, with read-backs (which close the chain) at different points of it, a
-    checkpoint in between and the switch turned off half way."""
-    monkeypatch.setenv("FPIC_EM_CHAIN", "1")
+def test_chained_lattice_step_is_bit_identical(fp, eo, monkeypatch, precision, form):
+    """The chained lattice step (round 4, the default of an undecomposed handle; FPIC_EM_CHAIN=0 / flat select the four sweeps /
+    the form without LDS): the second B half step of a sub-step, the next sub-step's node centring and its first B half step
+    as ONE sweep between two half-time arrays, B of the integer time formed only when somebody reads it.  Against the
+    oracle's four-sweep cycle: particles, the integer current and both lattice fields bit for bit after every frame, with
+    read-backs (which close the chain) at different points of it, an odd sub-step in between and the switch turned off half
+    way; and the same for the form without LDS."""
+    monkeypatch.setenv("FPIC_EM_CHAIN", form)
     rng = np.random.default_rng(44)
     shape, L, n = (12, 10, 16), (0.012, 0.010, 0.016), 6000
     dt = cfl_dt(shape, L, 0.5)
