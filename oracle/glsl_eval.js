@@ -18,6 +18,10 @@
  * x * (1 / y) with a rounded reciprocal, the viewport transform of a point in float32 (swgl.js) — so that
  * running the reference under both gives an honest error bar on "matches the reference" for a real browser
  * GPU (tests/golden/conventions.json, tests/test_oracle_conventions.py).  Neither set is "the" GPU.
+ * Since round 4 the first set has been checked against a real GLSL compiler: the reference run under Chromium's WebGL
+ * (oracle/make_golden_webgl.py, tests/golden/webgl_*) gives the same numbers wherever no transcendental and no division by a
+ * varying is involved (tests/test_oracle_webgl.py::test_software_evaluator_against_the_real_compiler); those fixtures, not
+ * these, are what pins the oracle's arithmetic now.
  *
  * Supported: precision / uniform / varying / attribute declarations; void main(); float,
  * vec2-4 locals; = and += ; if / else; for (float i = a; i < b; i++); ternaries; + - * / ;

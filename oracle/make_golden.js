@@ -6,8 +6,10 @@
  *   node oracle/make_golden.js [/root/reference] [tests/golden]
  *
  * What it does: evaluates utilities.js, spindle.js and empic.js through an AMD
- * define() shim, replaces util.webGL with a recorder (no WebGL context exists in
- * the image, so no shader is ever executed), calls the reference factory and its
+ * define() shim, replaces util.webGL with a recorder (Node has no WebGL: no shader is
+ * executed HERE — oracle/make_golden_webgl.py runs the reference under a real WebGL in the
+ * headless Chromium of the kaleido package and writes the webgl_* fixtures), calls the
+ * reference factory and its
  * set()/step()/density() methods, and writes ONLY numeric data and call-order
  * metadata: Float32Array contents the reference computed on the host, uniform
  * values it set, and which resource each draw reads and writes.  No reference
