@@ -539,6 +539,7 @@ struct Push3Joint {
     const BlockWork* work;
     const uint32_t* nwork;
     uint32_t chunk;
+    int xcd_order;                // see work_index
 };
 
 // the joint work list from the species' bin tables: tile t contributes max over the species of ceil(n_s(t) / chunk) items
@@ -576,6 +577,23 @@ __global__ __launch_bounds__(1024) void joint_scan_kernel(JointTables tabs, uint
         for (uint32_t k = 0; k < m; ++k) work[at++] = BlockWork{ t, k, 0u, 0u };
     }
     if (threadIdx.x == 1023) *nwork = part[1023];
+}
+
+// Which work item a workgroup takes.  Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own; in list
+// (= tile) order a tile's neighbours — which stage the same halo nodes — therefore run on OTHER XCDs and every L2 fetches
+// the halo again.  xcd_order gives each XCD a contiguous eighth of the list instead (when the launch's grid covers it).
+__device__ __forceinline__ bool work_index(uint32_t nwork, int xcd_order, uint32_t& wi)
+{
+    wi = blockIdx.x;
+    if (xcd_order) {
+        const uint32_t chunk = (nwork + 7u) / 8u;
+        if (chunk * 8u <= gridDim.x) {
+            const uint32_t slot = wi >> 3;
+            if (slot >= chunk) return false;
+            wi = (wi & 7u) * chunk + slot;
+        }
+    }
+    return wi < nwork;
 }
 
 // The slots of a work item in one species, in groups of PPT: a group that straddles two items belongs to the earlier one
@@ -621,8 +639,9 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
     FPIC_LDS uint32_t* lrank = lcensus + kNbr3;
     FPIC_LDS uint32_t* lrange = lrank + kNbr3;
     const Push3Args<T>& c0 = J.sp[0]; // (what is the same for every species is read from the first)
-    if (blockIdx.x >= *J.nwork) return;
-    const BlockWork w = J.work[blockIdx.x];
+    uint32_t wi;
+    if (!work_index(*J.nwork, J.xcd_order, wi)) return;
+    const BlockWork w = J.work[wi];
     if (!in_part(w.tile, c0.part, c0.tiles_per_layer, c0.layer_lo, c0.layer_hi)) return;
     const int ti = static_cast<int>(w.tile % c0.ntx), tj = static_cast<int>((w.tile / c0.ntx) % c0.nty), tk = static_cast<int>(w.tile / (c0.ntx * c0.nty));
     const int ox = ti * kTX - kHalo, oy = tj * kTY - kHalo, oz = tk * kTZ - kHalo;
@@ -671,7 +690,7 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
             counted_before = layer >= a.layer_lo && layer < a.layer_hi;
         }
         if (counted_before) {
-            if (threadIdx.x < kNbr3) lrank[threadIdx.x] = a.chunk_census[static_cast<size_t>(blockIdx.x) * kNbr3 + threadIdx.x];
+            if (threadIdx.x < kNbr3) lrank[threadIdx.x] = a.chunk_census[static_cast<size_t>(wi) * kNbr3 + threadIdx.x];
         } else
         for (size_t g = g_begin + threadIdx.x; g < g_end; g += THREADS) {
             const size_t base = g * PPT;
@@ -787,7 +806,7 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
             const uint32_t bin = nb.bin_of_slot(threadIdx.x);
             if (c && bin != ~0u) atomicAdd(a.tile_count + bin, c);
             if constexpr (!REBIN) {
-                if (a.chunk_census) a.chunk_census[static_cast<size_t>(blockIdx.x) * kNbr3 + threadIdx.x] = c;
+                if (a.chunk_census) a.chunk_census[static_cast<size_t>(wi) * kNbr3 + threadIdx.x] = c;
             }
         }
     }
@@ -1473,6 +1492,11 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 // face crossing, a cell outside the window, a weight rounded up to a whole cell — is an out-of-line call with the
 // particle's numbers BY VALUE (and the grid through a resident copy of the arguments), so that the common path keeps no
 // state in memory.
+#if defined(FES_ABL_EM)                 // development probes (timing only): 4 = no current deposit in the common case, 8 = no window staging / flush
+#define FES_ABL_EM_V FES_ABL_EM
+#else
+#define FES_ABL_EM_V 0
+#endif
 constexpr int kEL = 3;                 // log2 of the EM tile edge
 constexpr int kET = 1 << kEL;
 constexpr int kEmThreads = 768;
@@ -1498,6 +1522,7 @@ struct EmTileArgs {
     unsigned long long* spilled;
     const uint32_t* tile_start;    // the live bin table (the slots of the interior layers: fes_groups.hpp)
     const EmPushArgs<T>* resident; // a copy of p in device memory: what the out-of-line rare paths read their grid from
+    int xcd_order;                 // see work_index
 };
 
 template <typename A>
@@ -1640,8 +1665,9 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     FPIC_LDS T* lE = (FPIC_LDS T*)ldsem;
     FPIC_LDS T* lB = lE + 4 * WN;
     FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(lB + 4 * WN);
-    if (blockIdx.x >= *t.nwork) return;
-    const BlockWork w = t.work[blockIdx.x];
+    uint32_t wi;
+    if (!work_index(*t.nwork, t.xcd_order, wi)) return;
+    const BlockWork w = t.work[wi];
     if (!in_part(w.tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) return;
     const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
     const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
@@ -1649,7 +1675,7 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
     const Held hs = a.held;
     const Held hf = a.held;
-    for (int s = threadIdx.x; s < WN; s += kEmThreads) {
+    for (int s = threadIdx.x; s < ((FES_ABL_EM_V & 8) ? 0 : WN); s += kEmThreads) {
         const int n = s / (W * W), rem = s - n * (W * W);
         const int m = rem / W, l = rem - m * W;
         int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - hs.zs0 + n) % a.nz; // gk: among the planes held
@@ -1786,7 +1812,7 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
         }
     }
     __syncthreads();
-    for (int s3 = threadIdx.x; s3 < 3 * WN; s3 += kEmThreads) {
+    for (int s3 = threadIdx.x; s3 < ((FES_ABL_EM_V & 8) ? 0 : 3 * WN); s3 += kEmThreads) {
         const unsigned long long val = lJ[s3];
         if (val == 0ull) continue;
         const int s = s3 / 3, m3 = s3 - 3 * s;
