@@ -309,13 +309,6 @@ int ensure_joint_list(fpic_handle* h, const std::vector<size_t>& set)
     return FPIC_OK;
 }
 
-// FPIC_XCD_ORDER=1: each XCD takes a contiguous eighth of a tiled launch's work list (work_index in fes_kernels.hpp)
-static int xcd_order()
-{
-    const char* v = std::getenv("FPIC_XCD_ORDER");
-    return v && std::strcmp(v, "0") != 0 ? 1 : 0;
-}
-
 // The push (or, DEPOSIT_ONLY, the deposit) of every species of the handle.  part 0: whole; a rank of a decomposition may
 // push in two parts: 1 = the tile layers along the slab's faces (and the arrivals of a migration), 2 = the interior; the
 // re-binning decision, the census reset and the switch of the particle sets are taken once.  Binned species share ONE
@@ -401,14 +394,14 @@ int launch_push_all(fpic_handle* h, int part = 0)
         Push3Joint<T> J{};
         J.nsp = static_cast<int>(tiled.size());
         for (size_t k = 0; k < tiled.size(); ++k) J.sp[k] = args[k];
-        J.work = st->joint_work; J.nwork = st->joint_nwork; J.chunk = static_cast<uint32_t>(kChunk3); J.xcd_order = xcd_order();
+        J.work = st->joint_work; J.nwork = st->joint_nwork; J.chunk = static_cast<uint32_t>(kChunk3);
         if (int rc = launch(J, static_cast<unsigned>(st->joint_cap), rebin)) return rc;
     } else {
         for (size_t k = 0; k < tiled.size(); ++k) {
             Species& s = st->sp[tiled[k]];
             Push3Joint<T> J{};
             J.nsp = 1; J.sp[0] = args[k];
-            J.work = args[k].work; J.nwork = args[k].nwork; J.chunk = 0; J.xcd_order = xcd_order();
+            J.work = args[k].work; J.nwork = args[k].nwork; J.chunk = 0;
             if (int rc = launch(J, static_cast<unsigned>(s.work_cap), DEPOSIT_ONLY ? false : s.rebin_now)) return rc;
         }
     }
@@ -903,8 +896,7 @@ int em_push_all(fpic_handle* h, int part = 0)
                 store_args_kernel<EmPushArgs<T>><<<1, 1, 0, h->stream>>>(a, static_cast<EmPushArgs<T>*>(s.em_args));
             }
             t.resident = static_cast<const EmPushArgs<T>*>(s.em_args);
-            t.xcd_order = xcd_order();
-            em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmThreads, em_lds_bytes<T>(), h->stream>>>(t);
+            em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), em_threads<T>(), em_lds_bytes<T>(), h->stream>>>(t);
         } else if (part != 2) { // (an unbinned species is pushed whole with the first part)
             em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
         }

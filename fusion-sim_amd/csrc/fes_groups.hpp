@@ -43,6 +43,20 @@ FESGRP_HD void groups(uint32_t b0, uint32_t b1, int ppt, int part, uint32_t A, u
     else if (part == 1 && b0 == B && b1 > b0 && static_cast<size_t>(B / ppt) * ppt >= A) g_begin = B / ppt;
 }
 
+// The other rule (the full-EM push since round 4): a work item takes exactly its own slots.  Groups [g_begin, g_end) are those
+// that hold any of [b0, b1); slot g * ppt + q of a group is the item's iff owns(b0, b1, slot); a group that is not wholly
+// the item's is stored slot by slot, so two items that share a group never write each other's slots (what either reads of
+// the other's it does not use).  Why: a shared group's foreign particles lie in ANOTHER tile, i.e. outside the window of the
+// workgroup that pushes them, and take the global-memory path — up to ppt - 1 of them one after the other in one lane, at
+// the end of every tile: measured 40 ns of launch time per tile in single precision (profiles/r04_em_tile_overhead.txt).
+// No exception for two-part launches: an item belongs to one part with all its slots.
+FESGRP_HD void groups_exact(uint32_t b0, uint32_t b1, int ppt, size_t& g_begin, size_t& g_end)
+{
+    g_begin = static_cast<size_t>(b0) / ppt;
+    g_end = b1 > b0 ? (static_cast<size_t>(b1) + ppt - 1) / ppt : g_begin;
+}
+FESGRP_HD bool owns(uint32_t b0, uint32_t b1, size_t slot) { return slot >= b0 && slot < b1; }
+
 } // namespace fesgrp
 
 namespace fes {

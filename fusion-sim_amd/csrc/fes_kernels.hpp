@@ -355,6 +355,54 @@ __device__ __forceinline__ void store_state3(const Push3Args<T>& a, size_t base,
     }
 }
 
+// The same for a group of which the work item owns the slots of `own` only (bit k: slot base + k; fes_groups.hpp,
+// groups_exact): a slot of another item is neither used nor written.
+template <typename T>
+__device__ __forceinline__ unsigned own_mask(uint32_t b0, uint32_t b1, size_t base)
+{
+    constexpr int PPT = Vec16<T>::N;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) m |= fesgrp::owns(b0, b1, base + k) ? 1u << k : 0u;
+    return m;
+}
+template <typename T>
+__device__ __forceinline__ void load_state3_own(const Push3Args<T>& a, size_t base, unsigned own, P3<T> (&q)[Vec16<T>::N])
+{
+    constexpr int PPT = Vec16<T>::N;
+    T v[6][PPT];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        q[k].x = v[0][k]; q[k].y = v[1][k]; q[k].z = v[2][k];
+        q[k].vx = v[3][k]; q[k].vy = v[4][k]; q[k].vz = v[5][k];
+        if (!((own >> k) & 1u)) { q[k].x = q[k].y = q[k].z = static_cast<T>(0.5); q[k].vx = q[k].vy = q[k].vz = static_cast<T>(0); }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_state3_own(const Push3Args<T>& a, size_t base, unsigned own, const P3<T> (&q)[Vec16<T>::N])
+{
+    constexpr int PPT = Vec16<T>::N;
+    T v[6][PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        v[0][k] = q[k].x; v[1][k] = q[k].y; v[2][k] = q[k].z;
+        v[3][k] = q[k].vx; v[4][k] = q[k].vy; v[5][k] = q[k].vz;
+    }
+    if (own == (1u << PPT) - 1u) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) store_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if ((own >> k) & 1u) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) a.slab[f * a.stride + base + k] = v[f][k];
+            }
+    }
+}
+
 static_assert((kTX & (kTX - 1)) == 0 && (kTY & (kTY - 1)) == 0 && (kTZ & (kTZ - 1)) == 0, "tile edges are powers of two: cell -> tile is a shift");
 // LX, LY, LZ: log2 of the tile edges (the electrostatic cycle bins by 16x16x8 cells, the full-EM cycle by 8x8x8)
 template <int LX = 4, int LY = 4, int LZ = 3>
@@ -539,7 +587,6 @@ struct Push3Joint {
     const BlockWork* work;
     const uint32_t* nwork;
     uint32_t chunk;
-    int xcd_order;                // see work_index
 };
 
 // the joint work list from the species' bin tables: tile t contributes max over the species of ceil(n_s(t) / chunk) items
@@ -579,35 +626,16 @@ __global__ __launch_bounds__(1024) void joint_scan_kernel(JointTables tabs, uint
     if (threadIdx.x == 1023) *nwork = part[1023];
 }
 
-// Which work item a workgroup takes.  Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own; in list
-// (= tile) order a tile's neighbours — which stage the same halo nodes — therefore run on OTHER XCDs and every L2 fetches
-// the halo again.  xcd_order gives each XCD a contiguous eighth of the list instead (when the launch's grid covers it).
-__device__ __forceinline__ bool work_index(uint32_t nwork, int xcd_order, uint32_t& wi)
-{
-    wi = blockIdx.x;
-    if (xcd_order) {
-        const uint32_t chunk = (nwork + 7u) / 8u;
-        if (chunk * 8u <= gridDim.x) {
-            const uint32_t slot = wi >> 3;
-            if (slot >= chunk) return false;
-            wi = (wi & 7u) * chunk + slot;
-        }
-    }
-    return wi < nwork;
-}
-
-// The slots of a work item in one species, in groups of PPT: a group that straddles two items belongs to the earlier one
-// (begin rounds up, end rounds up).  In a two-part launch the group that holds the first slot of the layer along the
-// upper face — B = tile_start[layer_hi * tiles_per_layer] — holds particles of that face layer, which may deposit on
-// planes that are exchanged before the interior is pushed: the interior never takes it (part 2), the item that begins at B
-// does (part 1).
+// The slots [b0, b1) of a work item in one species and the groups of PPT slots that hold them: the item pushes exactly its
+// own slots (fes_groups.hpp, groups_exact — since round 4; before, a group that straddled two items went to the earlier one,
+// whose workgroup then pushed up to PPT - 1 particles of ANOTHER tile through global memory at the end of every tile).
 template <typename T>
-__device__ __forceinline__ void species_groups(const Push3Joint<T>& j, const Push3Args<T>& a, const BlockWork& w, int ppt, size_t& g_begin, size_t& g_end)
+__device__ __forceinline__ void species_groups(const Push3Joint<T>& j, const Push3Args<T>& a, const BlockWork& w, int ppt, uint32_t& b0, uint32_t& b1, size_t& g_begin,
+                                               size_t& g_end)
 {
-    uint32_t b0 = w.begin, b1 = w.end;
+    b0 = w.begin; b1 = w.end;
     if (j.chunk) fesgrp::piece(a.tile_start[w.tile], a.tile_start[w.tile + 1], w.begin, j.chunk, b0, b1);
-    const uint32_t A = a.part != 0 ? a.tile_start[a.layer_lo * a.tiles_per_layer] : 0u, B = a.part != 0 ? a.tile_start[a.layer_hi * a.tiles_per_layer] : 0u;
-    fesgrp::groups(b0, b1, ppt, a.part, A, B, a.tile_start[a.ntx * a.nty * a.ntz], g_begin, g_end);
+    fesgrp::groups_exact(b0, b1, ppt, g_begin, g_end);
 }
 
 
@@ -639,9 +667,11 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
     FPIC_LDS uint32_t* lrank = lcensus + kNbr3;
     FPIC_LDS uint32_t* lrange = lrank + kNbr3;
     const Push3Args<T>& c0 = J.sp[0]; // (what is the same for every species is read from the first)
-    uint32_t wi;
-    if (!work_index(*J.nwork, J.xcd_order, wi)) return;
-    const BlockWork w = J.work[wi];
+    // (the item is read before the count that may send the workgroup home: one memory latency instead of two; the list
+    // has a slot for every workgroup of the launch)
+    const BlockWork w = J.work[blockIdx.x];
+    if (blockIdx.x >= *J.nwork) return;
+    const uint32_t wi = blockIdx.x;
     if (!in_part(w.tile, c0.part, c0.tiles_per_layer, c0.layer_lo, c0.layer_hi)) return;
     const int ti = static_cast<int>(w.tile % c0.ntx), tj = static_cast<int>((w.tile / c0.ntx) % c0.nty), tk = static_cast<int>(w.tile / (c0.ntx * c0.nty));
     const int ox = ti * kTX - kHalo, oy = tj * kTY - kHalo, oz = tk * kTZ - kHalo;
@@ -678,7 +708,8 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
     const Push3Args<T>& a = J.sp[sp];
     uint32_t census_own = 0;
     size_t g_begin, g_end;
-    species_groups(J, a, w, PPT, g_begin, g_end);
+    uint32_t b0, b1;
+    species_groups(J, a, w, PPT, b0, b1, g_begin, g_end);
 
     if constexpr (REBIN) {
         // Pass A: the chunk's LOADED positions per destination bin — what the launch before counted as its new positions
@@ -694,14 +725,14 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
         } else
         for (size_t g = g_begin + threadIdx.x; g < g_end; g += THREADS) {
             const size_t base = g * PPT;
-            const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+            const unsigned own = own_mask<T>(b0, b1, base);
             T px[PPT], py[PPT], pz[PPT];
             load_lane<T, PPT>(a.slab + 0 * a.stride, base, px);
             load_lane<T, PPT>(a.slab + 1 * a.stride, base, py);
             load_lane<T, PPT>(a.slab + 2 * a.stride, base, pz);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                if (k >= cnt || px[k] < static_cast<T>(0)) continue; // (x < 0: the slot of a particle that has migrated away)
+                if (!((own >> k) & 1u) || px[k] < static_cast<T>(0)) continue; // (x < 0: the slot of a particle that has migrated away)
                 int i, j, kk, wgt;
                 axis(px[k], a.nx, i, wgt); axis(py[k], a.ny, j, wgt); axis(pz[k], a.nz, kk, wgt);
                 uint32_t key;
@@ -729,16 +760,16 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
 
     for (size_t g = g_begin + threadIdx.x; g < g_end; g += THREADS) {
         const size_t base = g * PPT;
-        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
+        const unsigned own = own_mask<T>(b0, b1, base);
         P3<T> q[PPT];
         uint32_t dest[PPT], pid[PPT];
         int slot_of[PPT];
-        load_state3(a, base, cnt, q);
+        load_state3_own(a, base, own, q);
         if constexpr (REBIN) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 dest[k] = 0; pid[k] = 0; slot_of[k] = -2;
-                if (k >= cnt || q[k].x < static_cast<T>(0)) continue;
+                if (!((own >> k) & 1u) || q[k].x < static_cast<T>(0)) continue;
                 pid[k] = a.id[base + k];
                 int i, j, kk, wgt;
                 axis(q[k].x, a.nx, i, wgt); axis(q[k].y, a.ny, j, wgt); axis(q[k].z, a.nz, kk, wgt);
@@ -752,21 +783,21 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
             // consecutive destinations: the stores below coalesce)
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const bool own = k < cnt && slot_of[k] == 0;
-                const unsigned long long mask = __ballot(own);
+                const bool stays = slot_of[k] == 0; // (-2 for a slot that is not the item's, or dead)
+                const unsigned long long mask = __ballot(stays);
                 if (mask) {
                     const int lane = static_cast<int>(threadIdx.x & 63);
                     const int leader = __ffsll(static_cast<long long>(mask)) - 1;
                     uint32_t wave_base = 0;
                     if (lane == leader) wave_base = __hip_atomic_fetch_add(lrank, static_cast<uint32_t>(__popcll(mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     wave_base = __shfl(wave_base, leader);
-                    if (own) dest[k] = lrange[0] + wave_base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+                    if (stays) dest[k] = lrange[0] + wave_base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
                 }
             }
         }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            if (k >= cnt) continue;
+            if (!((own >> k) & 1u)) continue;
             if constexpr (REBIN) { if (slot_of[k] == -2) continue; } // a dead slot
             int ni, nj, nk;
             if constexpr (DEPOSIT_ONLY) {
@@ -788,14 +819,14 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
         if constexpr (REBIN) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                if (k >= cnt || slot_of[k] == -2) continue;
+                if (slot_of[k] == -2) continue; // (not the item's, or dead)
                 const size_t d = dest[k];
                 a.dst_slab[0 * a.stride + d] = q[k].x; a.dst_slab[1 * a.stride + d] = q[k].y; a.dst_slab[2 * a.stride + d] = q[k].z;
                 a.dst_slab[3 * a.stride + d] = q[k].vx; a.dst_slab[4 * a.stride + d] = q[k].vy; a.dst_slab[5 * a.stride + d] = q[k].vz;
                 a.dst_id[d] = pid[k];
             }
         } else if constexpr (!DEPOSIT_ONLY) {
-            store_state3(a, base, cnt, q);
+            store_state3_own(a, base, own, q);
         }
     }
     if (census_own) __hip_atomic_fetch_add(lcensus, census_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1492,14 +1523,20 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 // face crossing, a cell outside the window, a weight rounded up to a whole cell — is an out-of-line call with the
 // particle's numbers BY VALUE (and the grid through a resident copy of the arguments), so that the common path keeps no
 // state in memory.
-#if defined(FES_ABL_EM)                 // development probes (timing only): 4 = no current deposit in the common case, 8 = no window staging / flush
+#if defined(FES_ABL_EM)                 // development probes (timing only): 4 = no current deposit in the common case, 8 = no window staging / flush, 16 = out-of-window particles skipped
 #define FES_ABL_EM_V FES_ABL_EM
 #else
 #define FES_ABL_EM_V 0
 #endif
 constexpr int kEL = 3;                 // log2 of the EM tile edge
 constexpr int kET = 1 << kEL;
-constexpr int kEmThreads = 768;
+#if !defined(FES_EM_THREADS_F32)
+#define FES_EM_THREADS_F32 768
+#endif
+// (float: 74.5 KB of LDS lets two workgroups share a CU only if their waves fit as well: 149 VGPRs = 3 waves per SIMD = 12 per
+// CU, i.e. one workgroup of 768 threads or two of 384 — FES_EM_THREADS_F32 is the development switch that measured it)
+template <typename T>
+constexpr int em_threads() { return sizeof(T) == 4 ? FES_EM_THREADS_F32 : 768; }
 template <typename T>
 struct EmWin {
     // one halo cell: an EM step moves a particle by a small fraction of a cell (c dt < dx / sqrt 3), and at 74.5 KB the
@@ -1522,7 +1559,6 @@ struct EmTileArgs {
     unsigned long long* spilled;
     const uint32_t* tile_start;    // the live bin table (the slots of the interior layers: fes_groups.hpp)
     const EmPushArgs<T>* resident; // a copy of p in device memory: what the out-of-line rare paths read their grid from
-    int xcd_order;                 // see work_index
 };
 
 template <typename A>
@@ -1656,8 +1692,9 @@ __device__ __attribute__((noinline)) P3<T> em_particle_rare(P3<T> p, const EmPus
 }
 
 template <typename T>
-__global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T> t)
+__global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu(3))) void em_push_tiles_kernel(EmTileArgs<T> t)
 {
+    constexpr int kEmThreads = em_threads<T>();
     const EmPushArgs<T>& a = t.p;
     constexpr int PPT = Vec16<T>::N;
     constexpr int W = EmWin<T>::W, WN = EmWin<T>::N, H = EmWin<T>::H;
@@ -1665,9 +1702,10 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     FPIC_LDS T* lE = (FPIC_LDS T*)ldsem;
     FPIC_LDS T* lB = lE + 4 * WN;
     FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(lB + 4 * WN);
-    uint32_t wi;
-    if (!work_index(*t.nwork, t.xcd_order, wi)) return;
-    const BlockWork w = t.work[wi];
+    // (the item is read before the count that may send the workgroup home: one memory latency instead of two; the list
+    // has a slot for every workgroup of the launch)
+    const BlockWork w = t.work[blockIdx.x];
+    if (blockIdx.x >= *t.nwork) return;
     if (!in_part(w.tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) return;
     const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
     const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
@@ -1675,6 +1713,18 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
     const Held hs = a.held;
     const Held hf = a.held;
+    // The lane's first particles are asked for BEFORE the window is staged: a tile of configs[4]'s lattice holds 4 000 to 8 000
+    // particles — one or two turns of the loop below — and with one workgroup per CU nothing else hides the latencies of
+    // a workgroup's start (work item -> window -> barrier -> particles, each a trip to memory under full load); this way the
+    // window's and the particles' trips overlap.
+    size_t g_begin, g_end;
+    fesgrp::groups_exact(w.begin, w.end, PPT, g_begin, g_end); // (exactly the item's own slots: fes_groups.hpp)
+    size_t g = g_begin + threadIdx.x;
+    T v[6][PPT];
+    if (g < g_end) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, g * PPT, v[f]);
+    }
     for (int s = threadIdx.x; s < ((FES_ABL_EM_V & 8) ? 0 : WN); s += kEmThreads) {
         const int n = s / (W * W), rem = s - n * (W * W);
         const int m = rem / W, l = rem - m * W;
@@ -1698,20 +1748,12 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
     }
     __syncthreads();
     unsigned my_spill = 0;
-    size_t g_begin, g_end;
-    {
-        const uint32_t A = t.part != 0 ? t.tile_start[t.layer_lo * t.tiles_per_layer] : 0u, B = t.part != 0 ? t.tile_start[t.layer_hi * t.tiles_per_layer] : 0u;
-        fesgrp::groups(w.begin, w.end, PPT, t.part, A, B, t.tile_start[t.ntx * t.nty * t.ntz], g_begin, g_end);
-    }
-    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kEmThreads) {
+    while (g < g_end) {
         const size_t base = g * PPT;
-        const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
-        T v[6][PPT];
-#pragma unroll
-        for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
+        const bool whole = base >= w.begin && base + PPT <= w.end; // (w.end <= n)
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            if (q >= cnt) continue;
+            if (!whole && !fesgrp::owns(w.begin, w.end, base + q)) continue;
             T x = v[0][q], y = v[1][q], z = v[2][q];
             if (x < static_cast<T>(0)) continue;
             // cell, upper weight (14-bit fixed point) and single fixed-point coordinate cell * 2^14 + weight per axis
@@ -1719,6 +1761,7 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
             axis(x, a.nx, i, wx1); axis(y, a.ny, j, wy1); axis(z, a.nz, k, wz1);
             const int s0 = em_slot<T>(i, j, k, ox, oy, oz, a.nx, a.ny, a.nz);
             if (s0 < 0) { // rare: the cell has left the window
+                if constexpr ((FES_ABL_EM_V & 16) != 0) continue; // (timing probe: what the out-of-window particles cost)
                 P3<T> p{ x, y, z, v[3][q], v[4][q], v[5][q] };
                 p = em_particle_rare<T>(p, t.resident);
                 v[0][q] = p.x; v[1][q] = p.y; v[2][q] = p.z; v[3][q] = p.vx; v[4][q] = p.vy; v[5][q] = p.vz;
@@ -1799,16 +1842,21 @@ __global__ __launch_bounds__(kEmThreads) void em_push_tiles_kernel(EmTileArgs<T>
                 my_spill += em_current_rare<T>((i << 14) + wx1, (j << 14) + wy1, (k << 14) + wz1, (i << 14) + e0, (j << 14) + e1, (k << 14) + e2, ox, oy, oz, a.nx, a.ny,
                                                a.nz, a.Z, lJ, t.resident);
         }
-        if (cnt == PPT) {
+        if (whole) {
 #pragma unroll
             for (int f = 0; f < 6; ++f) store_lane<T, PPT>(a.slab + f * a.stride, base, v[f]);
         } else {
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
-                if (q < cnt) {
+                if (fesgrp::owns(w.begin, w.end, base + q)) {
 #pragma unroll
                     for (int f = 0; f < 6; ++f) a.slab[f * a.stride + base + q] = v[f][q];
                 }
+        }
+        g += kEmThreads;
+        if (g < g_end) {
+#pragma unroll
+            for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, g * PPT, v[f]);
         }
     }
     __syncthreads();

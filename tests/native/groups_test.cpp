@@ -4,7 +4,9 @@
 //   * one launch (part 0): every group of every species is taken exactly once;
 //   * two parts: again exactly once over both; part 2 (the interior) takes no group that holds a slot of the layers along
 //     the faces or beyond (>= B, or below the interior's first slot ... the lower face's straddling group goes to part 1);
-//   * the single-species form (chunk 0, items with explicit begin / end) gives the same.
+//   * the single-species form (chunk 0, items with explicit begin / end) gives the same;
+//   * the exact rule of the full-EM push (groups_exact, owns): every slot once, by its own tile's item, no vector store over
+//     slots of another item.
 #include "../../fusion-sim_amd/csrc/fes_groups.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +74,33 @@ int main()
                             if (first < A) return fail("the interior's launch pushed a particle of the lower face layer", seed);
                         }
                     }
+                    ++cases;
+                }
+                // the exact rule (groups_exact / owns: the full-EM push): every slot is pushed once, by the item whose range
+                // holds it — whatever the part — and a group is stored as one vector only by an item that owns all of it
+                {
+                    std::vector<int> pushed(n, 0), vector_stores(ngroups + 1, 0), scalar_touch(ngroups + 1, 0);
+                    for (const Item& w : list) {
+                        uint32_t b0 = w.begin, b1 = w.end;
+                        if (!form) fesgrp::piece(start[s][w.tile], start[s][w.tile + 1], w.begin, chunk, b0, b1);
+                        size_t g0, g1;
+                        fesgrp::groups_exact(b0, b1, ppt, g0, g1);
+                        if (b1 > b0 && (g0 * ppt > b0 || g1 * ppt < b1)) return fail("exact: the groups do not cover the item", seed);
+                        if (b1 == b0 && g1 != g0) return fail("exact: an empty item has groups", seed);
+                        for (size_t g = g0; g < g1; ++g) {
+                            const size_t base = g * ppt;
+                            const bool whole = base >= b0 && base + ppt <= b1;
+                            if (whole) vector_stores[g]++; else scalar_touch[g]++;
+                            for (int q = 0; q < ppt; ++q)
+                                if (whole || fesgrp::owns(b0, b1, base + q)) {
+                                    if (base + q >= n) return fail("exact: a slot beyond the array", seed);
+                                    if (base + q < start[s][w.tile] || base + q >= start[s][w.tile + 1]) return fail("exact: a slot of another tile", seed);
+                                    pushed[base + q]++;
+                                }
+                        }
+                    }
+                    for (uint32_t i = 0; i < n; ++i) if (pushed[i] != 1) return fail(pushed[i] ? "exact: a slot pushed twice" : "exact: a slot nobody pushed", seed);
+                    for (size_t g = 0; g < ngroups; ++g) if (vector_stores[g] > 1 || (vector_stores[g] && scalar_touch[g])) return fail("exact: a vector store over another item's slots", seed);
                     ++cases;
                 }
             }
