@@ -85,5 +85,16 @@ FESGRP_HD unsigned wrap_near(int d, int n)
     return a < b ? a : b;
 }
 
+// d mod n for the nodes of a tile's window: d = first node of the window (one or two halo cells below a tile, less the
+// first plane a rank holds: down to -n - 2) + node within the window (< 32).  Boxes of 32 nodes or more along the axis
+// take three compare-and-adds (-2 n <= d < 2 n), smaller ones the division (the choice is uniform over the launch).
+FESGRP_HD int wrap_window(int d, int n)
+{
+    if (n < 32) { d %= n; return d < 0 ? d + n : d; }
+    if (d < 0) d += n;
+    if (d < 0) d += n;
+    return d >= n ? d - n : d;
+}
+
 } // namespace fes
 #endif

@@ -682,10 +682,9 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
     for (int s = threadIdx.x; s < ((ABL & 4) ? 0 : kWN); s += THREADS) {
         const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
         const int m = rem / kWX, l = rem - m * kWX;
-        int gi = (ox + l) % c0.nx, gj = (oy + m) % c0.ny, gk = (oz - c0.held.zs0 + n) % c0.nz; // gk: among the planes held
-        if (gi < 0) gi += c0.nx;
-        if (gj < 0) gj += c0.ny;
-        if (gk < 0) gk += c0.nz;
+        // (wrap_window: no division by a run-time number for boxes of 32 nodes or more)
+        const int gi = wrap_window(ox + l, c0.nx), gj = wrap_window(oy + m, c0.ny),
+                  gk = wrap_window(oz - c0.held.zs0 + n, c0.nz); // gk: among the planes held
         lrho[s] = 0ull;
         if constexpr (!DEPOSIT_ONLY) {
             const int lk = gk < c0.held.nzs ? gk : -1;
@@ -853,10 +852,9 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
         if (v == 0ull) continue;
         const int n = s / (kWX * kWY), rem = s - n * (kWX * kWY);
         const int m = rem / kWX, l = rem - m * kWX;
-        int gi = (ox + l) % c0.nx, gj = (oy + m) % c0.ny, gk = (oz - c0.held.zs0 + n) % c0.nz;
-        if (gi < 0) gi += c0.nx;
-        if (gj < 0) gj += c0.ny;
-        if (gk < 0) gk += c0.nz;
+        // (wrap_window: no division by a run-time number for boxes of 32 nodes or more)
+        const int gi = wrap_window(ox + l, c0.nx), gj = wrap_window(oy + m, c0.ny),
+                  gk = wrap_window(oz - c0.held.zs0 + n, c0.nz);
         if (gk < c0.held.nzs) atomicAdd(c0.rho + (static_cast<size_t>(gi) + static_cast<size_t>(c0.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(c0.ny) * gk)), v);
     }
     if (my_spill) atomicAdd(c0.spilled, static_cast<unsigned long long>(my_spill));
@@ -1533,10 +1531,16 @@ constexpr int kET = 1 << kEL;
 #if !defined(FES_EM_THREADS_F32)
 #define FES_EM_THREADS_F32 768
 #endif
+#if !defined(FES_EM_THREADS_F64)
+#define FES_EM_THREADS_F64 768
+#endif
+#if !defined(FES_EM_WAVES)
+#define FES_EM_WAVES 3          // waves per SIMD the register allocation aims at (development switch, like the two above)
+#endif
 // (float: 74.5 KB of LDS lets two workgroups share a CU only if their waves fit as well: 149 VGPRs = 3 waves per SIMD = 12 per
 // CU, i.e. one workgroup of 768 threads or two of 384 — FES_EM_THREADS_F32 is the development switch that measured it)
 template <typename T>
-constexpr int em_threads() { return sizeof(T) == 4 ? FES_EM_THREADS_F32 : 768; }
+constexpr int em_threads() { return sizeof(T) == 4 ? FES_EM_THREADS_F32 : FES_EM_THREADS_F64; }
 template <typename T>
 struct EmWin {
     // one halo cell: an EM step moves a particle by a small fraction of a cell (c dt < dx / sqrt 3), and at 74.5 KB the
@@ -1692,7 +1696,7 @@ __device__ __attribute__((noinline)) P3<T> em_particle_rare(P3<T> p, const EmPus
 }
 
 template <typename T>
-__global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu(3))) void em_push_tiles_kernel(EmTileArgs<T> t)
+__global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu(FES_EM_WAVES))) void em_push_tiles_kernel(EmTileArgs<T> t)
 {
     constexpr int kEmThreads = em_threads<T>();
     const EmPushArgs<T>& a = t.p;
@@ -1728,10 +1732,9 @@ __global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu
     for (int s = threadIdx.x; s < ((FES_ABL_EM_V & 8) ? 0 : WN); s += kEmThreads) {
         const int n = s / (W * W), rem = s - n * (W * W);
         const int m = rem / W, l = rem - m * W;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - hs.zs0 + n) % a.nz; // gk: among the planes held
-        if (gi < 0) gi += a.nx;
-        if (gj < 0) gj += a.ny;
-        if (gk < 0) gk += a.nz;
+        // (wrap_window: no division by a run-time number for boxes of 32 nodes or more)
+        const int gi = wrap_window(ox + l, a.nx), gj = wrap_window(oy + m, a.ny),
+                  gk = wrap_window(oz - hs.zs0 + n, a.nz); // gk: among the planes held
         const int lk = gk < hs.nzs ? gk : -1;
         const size_t node = static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * (lk < 0 ? 0 : lk));
         lJ[3 * s] = 0ull; lJ[3 * s + 1] = 0ull; lJ[3 * s + 2] = 0ull;
@@ -1866,10 +1869,9 @@ __global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu
         const int s = s3 / 3, m3 = s3 - 3 * s;
         const int n = s / (W * W), rem = s - n * (W * W);
         const int m = rem / W, l = rem - m * W;
-        int gi = (ox + l) % a.nx, gj = (oy + m) % a.ny, gk = (oz - hf.zs0 + n) % a.nz;
-        if (gi < 0) gi += a.nx;
-        if (gj < 0) gj += a.ny;
-        if (gk < 0) gk += a.nz;
+        // (wrap_window: no division by a run-time number for boxes of 32 nodes or more)
+        const int gi = wrap_window(ox + l, a.nx), gj = wrap_window(oy + m, a.ny),
+                  gk = wrap_window(oz - hf.zs0 + n, a.nz);
         if (gk < hf.nzs) atomicAdd(a.Jfix + 3 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)) + m3, val);
     }
     if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));

@@ -134,6 +134,10 @@ int main()
     for (int n = 1; n <= 70; ++n)
         for (int d = -n + 1; d < 2 * n; ++d)
             if (fes::wrap_near(d, n) != static_cast<unsigned>(((d % n) + n) % n)) return fail("wrap_near", n);
+    // wrap_window(d, n) == d mod n over everything a window can ask for: -n - 2 <= d < n + 32
+    for (int n = 1; n <= 200; ++n)
+        for (int d = -n - 2; d < n + 32; ++d)
+            if (fes::wrap_window(d, n) != ((d % n) + n) % n) return fail("wrap_window", n);
     std::printf("cases=%d planes=%d\nok\n", cases, planes);
     return 0;
 }
