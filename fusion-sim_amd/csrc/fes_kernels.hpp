@@ -1528,17 +1528,21 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 #endif
 constexpr int kEL = 3;                 // log2 of the EM tile edge
 constexpr int kET = 1 << kEL;
+// Workgroup sizes of the full-EM push (development switches; profiles/r04_em_tile_overhead.txt).  The kernel needs 149 (float)
+// / 166 (double) VGPRs: three waves per SIMD, and a workgroup's waves go to the SIMDs in turn, so a CU holds twelve waves as ONE
+// workgroup or eight as TWO of four waves each (two of six do not fit: a fourth wave on SIMD 0).  Double: 117 KB of LDS, one
+// workgroup per CU anyway, 768 threads.  Float: 74.5 KB, and two workgroups of 256 threads — one stages or flushes its
+// window while the other computes, and their uneven last turns interleave — beat one of 768 by 11 % at 7.45 particles per
+// cell and tie at 30.
 #if !defined(FES_EM_THREADS_F32)
-#define FES_EM_THREADS_F32 768
+#define FES_EM_THREADS_F32 256
 #endif
 #if !defined(FES_EM_THREADS_F64)
 #define FES_EM_THREADS_F64 768
 #endif
 #if !defined(FES_EM_WAVES)
-#define FES_EM_WAVES 3          // waves per SIMD the register allocation aims at (development switch, like the two above)
+#define FES_EM_WAVES 3          // waves per SIMD the register allocation aims at
 #endif
-// (float: 74.5 KB of LDS lets two workgroups share a CU only if their waves fit as well: 149 VGPRs = 3 waves per SIMD = 12 per
-// CU, i.e. one workgroup of 768 threads or two of 384 — FES_EM_THREADS_F32 is the development switch that measured it)
 template <typename T>
 constexpr int em_threads() { return sizeof(T) == 4 ? FES_EM_THREADS_F32 : FES_EM_THREADS_F64; }
 template <typename T>
