@@ -121,7 +121,10 @@ struct GlobalTables {
 
 constexpr int kPushHalo = 4;                           // cells staged around a tile for the push
 constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
-constexpr int kPushThreads = 512;
+#if !defined(FPIC_PUSH_THREADS)
+#define FPIC_PUSH_THREADS 768
+#endif
+constexpr int kPushThreads = FPIC_PUSH_THREADS;
 constexpr int kNbr = 5;                                // tile neighbourhood tracked in LDS when binning
 constexpr int kNbrSlots = kNbr * kNbr + 1;             // + the bin of clipped particles
 constexpr int kOwnSlot = (kNbr / 2) * kNbr + kNbr / 2; // the workgroup's own tile
