@@ -263,27 +263,27 @@ int launch_push(fpic_handle* h, int nsub)
                 HIP_TRY(h, hipMemsetAsync(h->cell_sums, 0, gcells * 4 * sizeof(T), h->stream)); // clear_color (empic.js:1476)
                 HIP_TRY(h, hipMemsetAsync(h->spilled, 0, sizeof(unsigned long long), h->stream));
                 constexpr size_t lds = push_tiles_lds_bytes<T, true>();
-                if (scatter && ctr) push_tiles_kernel<T, true, true, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-                else if (scatter) push_tiles_kernel<T, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-                else if (ctr) push_tiles_kernel<T, true, false, true><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-                else push_tiles_kernel<T, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                if (scatter && ctr) push_tiles_kernel<T, true, true, true><<<grid, push_threads<true>(), lds, h->stream>>>(a, t);
+                else if (scatter) push_tiles_kernel<T, true, true, false><<<grid, push_threads<false>(), lds, h->stream>>>(a, t);
+                else if (ctr) push_tiles_kernel<T, true, false, true><<<grid, push_threads<true>(), lds, h->stream>>>(a, t);
+                else push_tiles_kernel<T, true, false, false><<<grid, push_threads<false>(), lds, h->stream>>>(a, t);
             } else {
                 constexpr size_t lds = push_tiles_lds_bytes<T, true, false>();
-                if (scatter && ctr) push_tiles_kernel<T, true, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-                else if (scatter) push_tiles_kernel<T, true, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-                else if (ctr) push_tiles_kernel<T, true, false, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-                else push_tiles_kernel<T, true, false, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+                if (scatter && ctr) push_tiles_kernel<T, true, true, true, false><<<grid, push_threads<true>(), lds, h->stream>>>(a, t);
+                else if (scatter) push_tiles_kernel<T, true, true, false, false><<<grid, push_threads<false>(), lds, h->stream>>>(a, t);
+                else if (ctr) push_tiles_kernel<T, true, false, true, false><<<grid, push_threads<true>(), lds, h->stream>>>(a, t);
+                else push_tiles_kernel<T, true, false, false, false><<<grid, push_threads<false>(), lds, h->stream>>>(a, t);
             }
         } else {
             constexpr size_t lds = push_tiles_lds_bytes<T, true, false>();
-            if (scatter && ctr) push_tiles_kernel<T, true, true, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-            else if (scatter) push_tiles_kernel<T, true, true, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-            else if (ctr) push_tiles_kernel<T, true, false, true, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
-            else push_tiles_kernel<T, true, false, false, false><<<grid, kPushThreads, lds, h->stream>>>(a, t);
+            if (scatter && ctr) push_tiles_kernel<T, true, true, true, false><<<grid, push_threads<true>(), lds, h->stream>>>(a, t);
+            else if (scatter) push_tiles_kernel<T, true, true, false, false><<<grid, push_threads<false>(), lds, h->stream>>>(a, t);
+            else if (ctr) push_tiles_kernel<T, true, false, true, false><<<grid, push_threads<true>(), lds, h->stream>>>(a, t);
+            else push_tiles_kernel<T, true, false, false, false><<<grid, push_threads<false>(), lds, h->stream>>>(a, t);
         }
     } else if (h->binned) { // the work list of the last binning is valid until the next one: the push is in place
-        if (ctr) push_tiles_kernel<T, false, false, true><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
-        else push_tiles_kernel<T, false, false, false><<<grid, kPushThreads, push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
+        if (ctr) push_tiles_kernel<T, false, false, true><<<grid, push_threads<true>(), push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
+        else push_tiles_kernel<T, false, false, false><<<grid, push_threads<false>(), push_tiles_lds_bytes<T, false>(), h->stream>>>(a, t);
     } else {
         if (ctr) push_kernel<T, true><<<blocks_for(lanes), 256, 0, h->stream>>>(a);
         else push_kernel<T, false><<<blocks_for(lanes), 256, 0, h->stream>>>(a);

@@ -121,10 +121,18 @@ struct GlobalTables {
 
 constexpr int kPushHalo = 4;                           // cells staged around a tile for the push
 constexpr int kPushLds = kTileSide + 2 * kPushHalo;    // 40
+// Workgroup size of the tiled push (one workgroup per CU: 152 KB of LDS).  The reference generator's form holds 150 VGPRs —
+// three waves per SIMD — and is bound by the table gather's misses: 768 threads (12 waves) beat 512 by 3 %, 1024 would spill.
+// The counter-based form streams at 0.67 of the HBM peak and loses 11 % with 768.  (profiles/r04_push_threads.txt;
+// FPIC_PUSH_THREADS / FPIC_PUSH_THREADS_CTR: development switches)
 #if !defined(FPIC_PUSH_THREADS)
 #define FPIC_PUSH_THREADS 768
 #endif
-constexpr int kPushThreads = FPIC_PUSH_THREADS;
+#if !defined(FPIC_PUSH_THREADS_CTR)
+#define FPIC_PUSH_THREADS_CTR 512
+#endif
+template <bool CTR>
+constexpr int push_threads() { return CTR ? FPIC_PUSH_THREADS_CTR : FPIC_PUSH_THREADS; }
 constexpr int kNbr = 5;                                // tile neighbourhood tracked in LDS when binning
 constexpr int kNbrSlots = kNbr * kNbr + 1;             // + the bin of clipped particles
 constexpr int kOwnSlot = (kNbr / 2) * kNbr + kNbr / 2; // the workgroup's own tile
@@ -481,8 +489,9 @@ constexpr size_t push_tiles_lds_bytes()
 }
 
 template <typename T, bool FUSE, bool SCATTER, bool CTR, bool SUMS = true>
-__global__ __launch_bounds__(kPushThreads) void push_tiles_kernel(PushArgs<T> a, TileArgs<T> t)
+__global__ __launch_bounds__(push_threads<CTR>()) void push_tiles_kernel(PushArgs<T> a, TileArgs<T> t)
 {
+    constexpr int kPushThreads = push_threads<CTR>();
     static_assert(FUSE || !SCATTER, "the re-binning launch relies on the census of the fused form");
     constexpr int PPT = Vec16<T>::N;
     constexpr int LW = kPushLds;
