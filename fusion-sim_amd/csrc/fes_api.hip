@@ -323,8 +323,26 @@ int launch_push_all(fpic_handle* h, int part = 0)
     for (size_t i = 0; i < st->sp.size(); ++i) {
         Species& s = st->sp[i];
         if (s.n == 0) continue;
-        // (the full-EM mode bins by 8x8x8-cell tiles: its charge grid — a diagnostic there — takes the flat form)
         if (s.binned && st->solver != FPIC_SOLVER_YEE) { tiled.push_back(i); continue; }
+        if constexpr (DEPOSIT_ONLY) {
+            // the full-EM mode bins by 8x8x8-cell tiles: its charge grid (density(), the start field) has a tiled form of its own
+            if (s.binned) {
+                EmTileArgs<T> t{};
+                t.p.slab = static_cast<T*>(s.slab[s.cur]); t.p.stride = s.n_pad; t.p.n = s.n;
+                t.p.nx = st->nx; t.p.ny = st->ny; t.p.nz = st->nz;
+                t.p.held = held_of(st);
+                t.p.Z = s.Z;
+                t.ntx = st->ntx; t.nty = st->nty; t.ntz = st->ntz;
+                t.work = s.work2[s.wl]; t.nwork = s.nwork2[s.wl];
+                t.part = part; t.tiles_per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
+                interior_layers(st, t.layer_lo, t.layer_hi);
+                t.spilled = st->spilled;
+                t.tile_start = s.tile_start2[s.wl];
+                em_rho_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), kEmRhoThreads, 0, h->stream>>>(t, reinterpret_cast<unsigned long long*>(st->rho_fixed));
+                HIP_TRY(h, hipGetLastError());
+                continue;
+            }
+        }
         if (part == 2) continue; // (an unbinned species is pushed whole with the first part)
         Push3Args<T> a = push_args<T>(h, s);
         const size_t lanes = (s.n + Vec16<T>::N - 1) / Vec16<T>::N;
@@ -968,6 +986,13 @@ template <typename T>
 int em_precalc(fpic_handle* h)
 {
     State* st = h->es;
+    // A large fresh population is binned first, as in precalc() of the electrostatic cycle: the first sub-step would bin it
+    // anyway, and although the charge grid of this mode is deposited in the flat form (a diagnostic, and the start field),
+    // particles in tile order add to neighbouring nodes — the atomics of a wave meet in a few cache lines instead of 512.
+    bool bin_first = false;
+    for (const Species& sp : st->sp) bin_first |= !sp.binned && sp.n >= h->two_level_min;
+    if (bin_first)
+        if (int rc = bin_all<T>(h, true)) return rc;
     if (int rc = deposit_cycle<T, true>(h)) return rc;
     h->deposit_launches++;
     if (int rc = launch_solve<T>(h)) return rc; // rho -> phi -> E on the edges

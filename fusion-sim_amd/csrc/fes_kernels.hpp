@@ -1881,6 +1881,68 @@ __global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu
     if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));
 }
 
+// The charge grid of a population binned by the full-EM tiles (density() and the start field of precalc() in that mode):
+// the same work list and window as em_push_tiles_kernel with ONE int64 accumulator per node (10.6 KB of LDS, so a CU holds
+// many workgroups), eight ds_add_u64 per particle, one flush.  The flat form's eight global atomics per particle are bound
+// by the memory side's atomic rate whatever the particle order (125 ms for 5e8 particles, sorted or not): five times a
+// step() of the same population, which a host that runs the reference's frame (step + density) would pay every frame.
+constexpr int kEmRhoThreads = 256;
+template <typename T>
+__global__ __launch_bounds__(kEmRhoThreads) void em_rho_tiles_kernel(EmTileArgs<T> t, unsigned long long* __restrict__ rho)
+{
+    const EmPushArgs<T>& a = t.p;
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int W = EmWin<T>::W, WN = EmWin<T>::N, H = EmWin<T>::H;
+    __shared__ unsigned long long lrho[WN];
+    const BlockWork w = t.work[blockIdx.x];
+    if (blockIdx.x >= *t.nwork) return;
+    if (!in_part(w.tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) return;
+    const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
+    const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
+    for (int s = threadIdx.x; s < WN; s += kEmRhoThreads) lrho[s] = 0ull;
+    __syncthreads();
+    const GlobalGrid<T> grid{ nullptr, rho, a.nx, a.ny, a.nz, a.held };
+    unsigned my_spill = 0;
+    size_t g_begin, g_end;
+    fesgrp::groups_exact(w.begin, w.end, PPT, g_begin, g_end);
+    for (size_t g = g_begin + threadIdx.x; g < g_end; g += kEmRhoThreads) {
+        const size_t base = g * PPT;
+        T px[PPT], py[PPT], pz[PPT];
+        load_lane<T, PPT>(a.slab + 0 * a.stride, base, px);
+        load_lane<T, PPT>(a.slab + 1 * a.stride, base, py);
+        load_lane<T, PPT>(a.slab + 2 * a.stride, base, pz);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (!fesgrp::owns(w.begin, w.end, base + q) || px[q] < static_cast<T>(0)) continue; // (x < 0: a migrated slot)
+            int i, j, k, wx[2], wy[2], wz[2];
+            axis(px[q], a.nx, i, wx[1]); wx[0] = 16384 - wx[1];
+            axis(py[q], a.ny, j, wy[1]); wy[0] = 16384 - wy[1];
+            axis(pz[q], a.nz, k, wz[1]); wz[0] = 16384 - wz[1];
+            const int s0 = em_slot<T>(i, j, k, ox, oy, oz, a.nx, a.ny, a.nz);
+            if (s0 < 0) { grid.template deposit<true>(i, j, k, wx, wy, wz, a.Z); ++my_spill; continue; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa) {
+                        const long long v = weight3(wx[aa], wy[b], wz[c] * a.Z);
+                        __hip_atomic_fetch_add(lrho + (s0 + aa + W * b + W * W * c), static_cast<unsigned long long>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < WN; s += kEmRhoThreads) {
+        const unsigned long long val = lrho[s];
+        if (val == 0ull) continue;
+        const int n = s / (W * W), rem = s - n * (W * W);
+        const int m = rem / W, l = rem - m * W;
+        const int gi = wrap_window(ox + l, a.nx), gj = wrap_window(oy + m, a.ny), gk = wrap_window(oz - a.held.zs0 + n, a.nz);
+        if (gk < a.held.nzs) atomicAdd(rho + (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)), val);
+    }
+    if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));
+}
+
 // ------------------------------------------------------------------ spatial decomposition (z-slabs), SURVEY.md 8(e) row 2
 
 // One migrating particle on the wire: the six coordinates and the caller's (global) index.
