@@ -320,6 +320,14 @@ def em_line(device, n, grid, steps, warmup, precision="fp64"):
     el = time.perf_counter() - t0
     st = sim.stats()
     device_bytes = st["bytes_particle_state"] + st["bytes_grid_state"]
+    # density() of this mode (the charge grid is a diagnostic here, not part of the cycle): what a host that runs the reference's
+    # frame — step() + density() — pays on top of the step; tiled over the EM tiles since round 4
+    sim.density(); sim.sync(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        sim.density()
+    sim.sync(); torch.cuda.synchronize()
+    density_ms = 1e3 * (time.perf_counter() - t1) / 3
     sim.destroy()
     sub = 2 * steps
     esize = 8 if precision == "fp64" else 4
@@ -336,6 +344,7 @@ def em_line(device, n, grid, steps, warmup, precision="fp64"):
                          "traffic": tr.get("bytes_per_launch") if tr else None,
                          "traffic_source": ("%s: %s" % (tr.get("file"), tr.get("source"))) if tr else "no committed PMC pass for this configuration (profiles/r*_traffic.json)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": push_ms},
+            "density_ms": density_ms,
             "fdtd_algorithmic_bytes": 21 * esize * grid ** 3, "device_bytes": device_bytes}
 
 
