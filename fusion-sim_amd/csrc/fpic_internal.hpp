@@ -20,7 +20,10 @@ constexpr int kEntropySide = 1024;           // empic.js:142
 constexpr int kTileSide = 32;                // cells per tile edge
 constexpr int kTileHalo = 8;                 // extra cells kept in LDS around a tile
 constexpr int kTileLds = kTileSide + 2 * kTileHalo;
-constexpr int kDepositChunk = 16384;         // particles per workgroup and chunk (sweep: profiles/r01_rebin_ablation.txt)
+#if !defined(FPIC_DEPOSIT_CHUNK)
+#define FPIC_DEPOSIT_CHUNK 16384
+#endif
+constexpr int kDepositChunk = FPIC_DEPOSIT_CHUNK; // particles per workgroup and chunk (sweep: profiles/r01_rebin_ablation.txt)
 constexpr int kMaxTiles = 16384;             // LDS histogram limit of the binning pass
 
 // The per-cell sums of density()'s point sprites live on the cells a sprite's CENTRE can have: columns 0..nr (r = 1
