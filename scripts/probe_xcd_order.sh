@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round 4 probe: (1) FPIC_XCD_ORDER (each XCD a contiguous eighth of a tiled launch's work list) on the full-EM push at
+# Round 4 probe — of commit c. "XCD-aware work order ... behind FPIC_XCD_ORDER"; the switch measured nothing gained and was
+# removed again (profiles/r04_xcd_order_and_staging.txt), so part (1) of this script needs that commit's library.
+# (1) FPIC_XCD_ORDER (each XCD a contiguous eighth of a tiled launch's work list) on the full-EM push at
 # configs[4]'s lattice and on the electrostatic push; (2) FES_ABL_EM bits 8 (no window staging / flush) and 4 (no current
 # deposit) at that lattice: what the 512^3 lattice costs the push beyond its particle streams.  Rebuilds fes_api.o ON THE
 # GPU BOX for (2) and restores the real build.     scripts/probe_xcd_order.sh > gpurun_out/xcd_order.txt
