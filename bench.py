@@ -487,7 +487,9 @@ def c4_line(device, total, grid, world, steps, warmup, precision="fp32", skip_si
         "particles_migrated_per_substep": (sum(d["migrated"] for d in dom) - mig0[0]) / float(sub), "lost": sum(d["lost"] for d in dom),
         "ghost_planes": ghost, "migrate_every": migrate_every,
         "exchange_bytes_per_rank_per_substep":
-            {"current_ghost_planes_int64_reduce": 2 * (ghost + 2) * plane * 3 * 8, "lattice_halo_copies_E_and_B": 2 * 2 * (ghost + 2) * plane * 4 * esz} if em else
+            {"current_ghost_planes_int64_reduce": 2 * (ghost + 2) * plane * 3 * 8,
+             # (round 4, chained lattice step: a rank forms the half-time B of its halo planes itself; E goes one plane deeper into the upper halo)
+             "lattice_halo_copies_E": (2 * (ghost + 2) + 1) * plane * 4 * esz} if em else
             {"ghost_planes_int64_reduce": (2 * ghost + 1) * plane * 8,
              # (rows of the half spectrum are padded to whole 128-byte tiles in the library's own transform buffers)
              # (one formula with box_workload; ADVICE r03: the two used different leading factors)

@@ -953,6 +953,21 @@ int em_half_b(fpic_handle* h, const EmCoef<T>& c, int k0, int nk, const void* fr
     return FPIC_OK;
 }
 
+// the chained lattice step (em_chain_tiled_kernel) on the node planes k0 .. k0 + nk - 1: Bh[bh_cur], Ey -> E4, B4n, Bh[bh_cur ^ 1]
+template <typename T>
+int em_chain_launch(fpic_handle* h, const EmCoef<T>& co, int k0, int nk, bool below_too)
+{
+    State* st = h->es;
+    k0 = (k0 % st->nz + st->nz) % st->nz;
+    const unsigned tiles = static_cast<unsigned>(((st->nx + kCX - 1) / kCX) * ((st->ny + kCY - 1) / kCY) * ((nk + kCZ - 1) / kCZ));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(em_chain_tiled_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(em_chain_lds_bytes<T>())));
+    em_chain_tiled_kernel<T><<<tiles, kChainThreads, em_chain_lds_bytes<T>(), h->stream>>>(static_cast<const T*>(st->Bh[st->bh_cur]), static_cast<const T*>(st->Ey), st->nx, st->ny,
+                                                                                          st->nz, co.cb[0], co.cb[1], co.cb[2], static_cast<T*>(st->E4), static_cast<T*>(st->B4n),
+                                                                                          static_cast<T*>(st->Bh[st->bh_cur ^ 1]), k0, nk, held_of(st), below_too ? 1 : 0);
+    HIP_TRY(h, hipGetLastError());
+    return FPIC_OK;
+}
+
 // By <- the B of the integer time the chained step has reached (the half step it left open); whoever reads or replaces By calls it
 template <typename T>
 int em_close(fpic_handle* h)
@@ -1046,11 +1061,7 @@ int em_substep(fpic_handle* h)
                                                                            co.cb[0], co.cb[1], co.cb[2], static_cast<T*>(st->E4), static_cast<T*>(st->B4n),
                                                                            static_cast<T*>(st->Bh[st->bh_cur ^ 1]));
         } else {
-            const unsigned tiles = static_cast<unsigned>(((st->nx + kCX - 1) / kCX) * ((st->ny + kCY - 1) / kCY) * ((st->nz + kCZ - 1) / kCZ));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(em_chain_tiled_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(em_chain_lds_bytes<T>())));
-            em_chain_tiled_kernel<T><<<tiles, kChainThreads, em_chain_lds_bytes<T>(), h->stream>>>(static_cast<const T*>(st->Bh[st->bh_cur]), static_cast<const T*>(st->Ey), st->nx,
-                                                                                                  st->ny, st->nz, co.cb[0], co.cb[1], co.cb[2], static_cast<T*>(st->E4),
-                                                                                                  static_cast<T*>(st->B4n), static_cast<T*>(st->Bh[st->bh_cur ^ 1]));
+            if (int rc = em_chain_launch<T>(h, co, 0, st->nz, false)) return rc;
         }
         HIP_TRY(h, hipGetLastError());
         timing_end(h);
@@ -1950,6 +1961,15 @@ struct Xfer {
 };
 enum Exchange { X_GHOST = 0, X_MIG_COUNTS, X_MIG_PAYLOAD, X_TRANSPOSE, X_TRANSPOSE_BACK, X_PHI, X_EM_J, X_EM_E, X_EM_B };
 
+// A rank of a full-EM decomposition may run the chained lattice step (em_chain_tiled_kernel) when its slab can give H + 1
+// planes to a neighbour's halo and the planes it forms the half-time B on, z0 - H .. z0 + nzl + H - 1, are distinct planes
+// of the periodic lattice.  The same for every rank (nzl, H and nz are).
+bool em_deep_halo(const State* st)
+{
+    const Domain* d = st->dom;
+    return d && d->world > 1 && st->solver == FPIC_SOLVER_YEE && d->H + 1 <= d->nzl && d->nzl + 2 * d->H + 1 <= st->nz;
+}
+
 // The messages of one exchange, in an order every rank shares: [0] goes to the slab below and is met there by
 // what arrives from above, [1] goes up and is met by what arrives from below.  (RCCL matches the sends and
 // receives of a pair of ranks in the order they are issued; with two ranks both messages have the same peer.)
@@ -1986,11 +2006,14 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
         out.push_back({ up, down, st->Jfix + 3 * lp(st, hi) * plane, bytes, d.j_recv[1], bytes, 1 });
     } else if (which == X_EM_E || which == X_EM_B) {
         // halo copy of a lattice field: my first H planes are the lower neighbour's upper halo, my last H planes the
-        // upper neighbour's lower halo; what arrives lands in my halo planes in place
+        // upper neighbour's lower halo; what arrives lands in my halo planes in place.  E goes one plane deeper into the
+        // UPPER halo (the last plane a rank holds, z0 + nzl + H): the chained lattice step forms the half-time B of the
+        // top halo plane from the E one plane above it (dom_em_substep).
         T* f = static_cast<T*>(which == X_EM_E ? st->Ey : st->By);
         const size_t bytes = static_cast<size_t>(d.H) * plane * 4 * sizeof(T);
+        const size_t deep = static_cast<size_t>(which == X_EM_E && em_deep_halo(st) ? d.H + 1 : d.H) * plane * 4 * sizeof(T);
         const int above = (d.z0 + d.nzl) % st->nz, below = (d.z0 - d.H + st->nz) % st->nz;
-        out.push_back({ down, up, f + 4 * lp(st, d.z0) * plane, bytes, f + 4 * lp(st, above) * plane, bytes, 0 });
+        out.push_back({ down, up, f + 4 * lp(st, d.z0) * plane, deep, f + 4 * lp(st, above) * plane, deep, 0 });
         out.push_back({ up, down, f + 4 * lp(st, d.z0 + d.nzl - d.H) * plane, bytes, f + 4 * lp(st, below) * plane, bytes, 1 });
     } else { // X_PHI: the potential on the planes the gradient of my slab and its ghost planes needs
         T* phi = static_cast<T*>(st->phi);
@@ -2544,8 +2567,13 @@ int dom_em_after_precalc(Ranks& rk)
         fill4_kernel<T><<<blocks_for(held_nodes(st)), 256, 0, h->stream>>>(static_cast<T*>(st->By), held_nodes(st), static_cast<T>(st->B0[0]), static_cast<T>(st->B0[1]),
                                                                          static_cast<T>(st->B0[2]));
         HIP_TRY(h, hipGetLastError());
+        st->em_open = false;                   // (both lattice fields are set afresh)
         if (int e = em_nodes<T>(h)) return e; // (every rank has solved the whole grid: its E is valid everywhere)
     }
+    // (with the decomposed solve E comes from the potential on the slab and its H halo planes; the one plane above them that
+    // the chained lattice step reads arrives with a halo copy — collective, as precalc() is)
+    if (rk.hs[0]->es->dom->world > 1 && em_deep_halo(rk.hs[0]->es))
+        if (int e = exchange<T>(rk, X_EM_E)) return e;
     return FPIC_OK;
 }
 
@@ -2571,13 +2599,36 @@ int dom_em_substep(Ranks& rk)
         if (int e = exchange<T>(rk, X_EM_B)) return e;
         for (fpic_handle* h : rk.hs) h->es->dom->halos_stale = false;
     }
+    // The chained lattice step on the ranks of a decomposition (round 4; em_substep has the undecomposed form).  A rank keeps
+    // the half-time B on the planes z0 - H .. z0 + nzl + H - 1 — its slab and its halos — and forms it there ITSELF, from the
+    // E halo it receives (one plane deeper above: X_EM_E), with the arithmetic its neighbours use on their own planes: the
+    // second B half step, the node centring and the next first half step are one sweep, and the halo copy of B is gone
+    // (half the lattice halo bytes).  B of the integer time is formed when somebody reads or replaces it (em_close), plane
+    // for plane on whatever the rank holds — no exchange, so one rank may close and reopen without the others.
+    // FPIC_EM_CHAIN=0 keeps the four sweeps and both halo copies.
+    const char* chain_env = std::getenv("FPIC_EM_CHAIN");
+    const bool chain = multi && em_deep_halo(s0) && !(chain_env && std::strcmp(chain_env, "0") == 0);
     for (fpic_handle* h : rk.hs) {
         State* st = h->es;
         const Domain& d = *st->dom;
         const size_t plane = static_cast<size_t>(st->nx) * st->ny;
         HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
+        if (!chain && st->em_open)      // (the switch was turned off between two sub-steps)
+            if (int e = em_close<T>(h)) return e;
+        if (chain && !st->Bh[0]) {
+            int e;
+            if ((e = dev_alloc(h, &st->Bh[0], held_nodes(st) * 4 * sizeof(T), &h->bytes_grid)) || (e = dev_alloc(h, &st->Bh[1], held_nodes(st) * 4 * sizeof(T), &h->bytes_grid))) return e;
+        }
         // node-centred fields where this rank's particles can be: cells [z0 - G, z0 + nzl + G) -> nodes one further up
-        if (int e = multi ? em_nodes<T>(h, d.z0 - d.G - 1, std::min(st->nz, d.nzl + 2 * d.G + 3)) : em_nodes<T>(h)) return e;
+        if (chain && st->em_open) {
+            timing_begin(h, KC_SOLVE);
+            const EmCoef<T> co(h);
+            if (int e = em_chain_launch<T>(h, co, d.z0 - d.G - 1, d.nzl + 2 * d.G + 3, true)) return e;
+            timing_end(h);
+            st->bh_cur ^= 1;
+        } else if (int e = multi ? em_nodes<T>(h, d.z0 - d.G - 1, std::min(st->nz, d.nzl + 2 * d.G + 3)) : em_nodes<T>(h)) {
+            return e;
+        }
         timing_begin(h, KC_PUSH);
         if (multi) { // the planes the slab's particles can deposit on
             if (int e = zero_planes(h, st->Jfix, 3 * plane * sizeof(long long), d.z0 - d.H, d.nzl + 2 * d.H)) return e;
@@ -2609,9 +2660,18 @@ int dom_em_substep(Ranks& rk)
             ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * lp(st, d.z0 + d.nzl - d.H) * plane, d.j_recv[0], count);
             ghost_add_kernel<<<blocks_for(count), 256, 0, h->stream>>>(st->Jfix + 3 * lp(st, d.z0) * plane, d.j_recv[1], count);
             HIP_TRY(h, hipGetLastError());
-            // B half a step on the slab and on the plane below it (the E update of the first owned plane reads it)
-            if (int e = em_half_b<T>(h, co, d.z0 - 1, d.nzl + 1)) return e;
-            if (int e = em_full_e<T>(h, co, d.z0, d.nzl)) return e;
+            if (chain) {
+                if (!st->em_open) { // from B at the integer time: its first half step on every plane the rank reads it on
+                    st->bh_cur = 0;
+                    if (int e = em_half_b<T>(h, co, d.z0 - d.H, d.nzl + 2 * d.H, st->By, st->Bh[0])) return e;
+                    st->em_open = true;
+                }
+                if (int e = em_full_e<T>(h, co, d.z0, d.nzl, st->Bh[st->bh_cur])) return e;
+            } else {
+                // B half a step on the slab and on the plane below it (the E update of the first owned plane reads it)
+                if (int e = em_half_b<T>(h, co, d.z0 - 1, d.nzl + 1)) return e;
+                if (int e = em_full_e<T>(h, co, d.z0, d.nzl)) return e;
+            }
         } else {
             if (int e = em_half_b<T>(h, co, 0, st->nz)) return e;
             if (int e = em_full_e<T>(h, co, 0, st->nz)) return e;
@@ -2623,17 +2683,19 @@ int dom_em_substep(Ranks& rk)
     for (fpic_handle* h : rk.hs) {
         State* st = h->es;
         const Domain& d = *st->dom;
-        timing_begin(h, KC_SOLVE);
-        const EmCoef<T> co(h);
-        if (int e = multi ? em_half_b<T>(h, co, d.z0, d.nzl) : em_half_b<T>(h, co, 0, st->nz)) return e;
-        timing_end(h);
+        if (!chain) {
+            timing_begin(h, KC_SOLVE);
+            const EmCoef<T> co(h);
+            if (int e = multi ? em_half_b<T>(h, co, d.z0, d.nzl) : em_half_b<T>(h, co, 0, st->nz)) return e;
+            timing_end(h);
+        }
         st->substeps_since_bin++;
         st->dom->substeps_since_migration++;
         h->step_launches++;
         h->solve_launches++;
         h->particle_updates += total_particles(st);
     }
-    if (multi)
+    if (multi && !chain)
         if (int e = exchange<T>(rk, X_EM_B)) return e;
     return FPIC_OK;
 }
@@ -2793,7 +2855,8 @@ int keep_slab_only(fpic_handle* h, int halo)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     struct Arr { void** p; size_t per_node; };
     const Arr arrs[] = { { reinterpret_cast<void**>(&st->rho_fixed), sizeof(long long) }, { &st->rho, sizeof(T) }, { &st->phi, sizeof(T) }, { &st->E4, 4 * sizeof(T) },
-                         { &st->Ey, 4 * sizeof(T) }, { &st->By, 4 * sizeof(T) }, { &st->B4n, 4 * sizeof(T) }, { reinterpret_cast<void**>(&st->Jfix), 3 * sizeof(long long) } };
+                         { &st->Ey, 4 * sizeof(T) }, { &st->By, 4 * sizeof(T) }, { &st->B4n, 4 * sizeof(T) }, { reinterpret_cast<void**>(&st->Jfix), 3 * sizeof(long long) },
+                         { &st->Bh[0], 4 * sizeof(T) }, { &st->Bh[1], 4 * sizeof(T) } }; // (Bh: the half-time arrays of a handle that ran the chained lattice step before)
     st->zs0 = ((d.z0 - halo) % st->nz + st->nz) % st->nz; // (held_plane() takes it in [0, nz))
     st->nzs = nzs;
     for (const Arr& a : arrs) {

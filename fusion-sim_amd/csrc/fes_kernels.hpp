@@ -1242,26 +1242,43 @@ constexpr size_t em_chain_lds_bytes() { return (static_cast<size_t>(kCX + 2) * (
 
 template <typename T>
 __global__ __launch_bounds__(kChainThreads) void em_chain_tiled_kernel(const T* __restrict__ Bh, const T* __restrict__ Ey, int nx, int ny, int nz, T cbx, T cby, T cbz,
-                                                                       T* __restrict__ E4n, T* __restrict__ B4n, T* __restrict__ Bnext)
+                                                                       T* __restrict__ E4n, T* __restrict__ B4n, T* __restrict__ Bnext, int k0, int nk, Held held,
+                                                                       int below_too)
 {
+    // The node planes k0 .. k0 + nk - 1 (periodic) of the planes `held` holds: the whole lattice of an undecomposed handle
+    // (0, nz), or the planes a rank's particles can gather on.  E is read on k0 - 1 .. k0 + nk and the half-time B on
+    // k0 - 1 .. k0 + nk - 1; the next half-time B is written on the node planes and, below_too, on plane k0 - 1 as well — a
+    // rank forms it on every plane it will read it on, from the E halo it receives, instead of receiving it (fes_api.hip,
+    // dom_em_substep).  A plane that is not held reads as zero and is not written.
     extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];
     constexpr int EX = kCX + 2, EY = kCY + 2, EZ = kCZ + 2, BX = kCX + 1, BY = kCY + 1, BZ = kCZ + 1;
     T* le = reinterpret_cast<T*>(chain_lds);        // [EZ][EY][EX][3]: E at offsets -1 .. T
     T* lb = le + EX * EY * EZ * 3;                   // [BZ][BY][BX][3]: Bh, then b1, at offsets -1 .. T - 1
     const int tiles_x = (nx + kCX - 1) / kCX, tiles_y = (ny + kCY - 1) / kCY;
     const int x0 = static_cast<int>(blockIdx.x % tiles_x) * kCX, y0 = static_cast<int>((blockIdx.x / tiles_x) % tiles_y) * kCY;
-    const int z0 = static_cast<int>(blockIdx.x / (tiles_x * tiles_y)) * kCZ;
+    const int z0 = static_cast<int>(blockIdx.x / (tiles_x * tiles_y)) * kCZ;    // (offset within the range)
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
     auto wrap = [](int v, int n) { v %= n; return v < 0 ? v + n : v; };
+    auto plane = [&](int c) { return held_plane(wrap(k0 + z0 + c, nz), held, nz); }; // place of the plane at offset c of this tile, or -1
     for (int e = threadIdx.x; e < EX * EY * EZ; e += kChainThreads) {
         const int a = e % EX, b = (e / EX) % EY, c = e / (EX * EY);
-        const size_t g = 4 * (static_cast<size_t>(wrap(x0 + a - 1, nx)) + sy * wrap(y0 + b - 1, ny) + sz * wrap(z0 + c - 1, nz));
-        le[3 * e] = Ey[g]; le[3 * e + 1] = Ey[g + 1]; le[3 * e + 2] = Ey[g + 2];
+        const int pl = plane(c - 1);
+        T v0 = 0, v1 = 0, v2 = 0;
+        if (pl >= 0) {
+            const size_t g = 4 * (static_cast<size_t>(wrap(x0 + a - 1, nx)) + sy * wrap(y0 + b - 1, ny) + sz * pl);
+            v0 = Ey[g]; v1 = Ey[g + 1]; v2 = Ey[g + 2];
+        }
+        le[3 * e] = v0; le[3 * e + 1] = v1; le[3 * e + 2] = v2;
     }
     for (int f = threadIdx.x; f < BX * BY * BZ; f += kChainThreads) {
         const int a = f % BX, b = (f / BX) % BY, c = f / (BX * BY);
-        const size_t g = 4 * (static_cast<size_t>(wrap(x0 + a - 1, nx)) + sy * wrap(y0 + b - 1, ny) + sz * wrap(z0 + c - 1, nz));
-        lb[3 * f] = Bh[g]; lb[3 * f + 1] = Bh[g + 1]; lb[3 * f + 2] = Bh[g + 2];
+        const int pl = plane(c - 1);
+        T v0 = 0, v1 = 0, v2 = 0;
+        if (pl >= 0) {
+            const size_t g = 4 * (static_cast<size_t>(wrap(x0 + a - 1, nx)) + sy * wrap(y0 + b - 1, ny) + sz * pl);
+            v0 = Bh[g]; v1 = Bh[g + 1]; v2 = Bh[g + 2];
+        }
+        lb[3 * f] = v0; lb[3 * f + 1] = v1; lb[3 * f + 2] = v2;
     }
     __syncthreads();
     // E at LDS offsets (a, b, c) in [-1, T], component m
@@ -1274,8 +1291,11 @@ __global__ __launch_bounds__(kChainThreads) void em_chain_tiled_kernel(const T* 
         const T b1x = lb[3 * f] - cx, b1y = lb[3 * f + 1] - cy, b1z = lb[3 * f + 2] - cz;
         lb[3 * f] = b1x; lb[3 * f + 1] = b1y; lb[3 * f + 2] = b1z;
         const int gx = x0 + a, gy = y0 + b, gz = z0 + c;
-        if (a >= 0 && b >= 0 && c >= 0 && gx < nx && gy < ny && gz < nz) {            // a face of this workgroup's own nodes
-            const size_t g = 4 * (static_cast<size_t>(gx) + sy * gy + sz * gz);
+        // a face of this workgroup's own nodes (or, below_too, of the plane under the range's first)
+        const bool mine = a >= 0 && b >= 0 && gx < nx && gy < ny && gz < nk && (c >= 0 || (below_too && gz == -1));
+        const int pl = mine ? plane(c) : -1;
+        if (pl >= 0) {
+            const size_t g = 4 * (static_cast<size_t>(gx) + sy * gy + sz * pl);
             Bnext[g] = b1x - cx; Bnext[g + 1] = b1y - cy; Bnext[g + 2] = b1z - cz; Bnext[g + 3] = static_cast<T>(0);
         }
     }
@@ -1284,8 +1304,10 @@ __global__ __launch_bounds__(kChainThreads) void em_chain_tiled_kernel(const T* 
     for (int n = threadIdx.x; n < kCX * kCY * kCZ; n += kChainThreads) {
         const int a = n % kCX, b = (n / kCX) % kCY, c = n / (kCX * kCY);
         const int gx = x0 + a, gy = y0 + b, gz = z0 + c;
-        if (gx >= nx || gy >= ny || gz >= nz) continue;
-        const size_t g = 4 * (static_cast<size_t>(gx) + sy * gy + sz * gz);
+        if (gx >= nx || gy >= ny || gz >= nk) continue;
+        const int pl = plane(c);
+        if (pl < 0) continue;
+        const size_t g = 4 * (static_cast<size_t>(gx) + sy * gy + sz * pl);
         E4n[g] = static_cast<T>(0.5) * (E(a - 1, b, c, 0) + E(a, b, c, 0));
         E4n[g + 1] = static_cast<T>(0.5) * (E(a, b - 1, c, 1) + E(a, b, c, 1));
         E4n[g + 2] = static_cast<T>(0.5) * (E(a, b, c - 1, 2) + E(a, b, c, 2));

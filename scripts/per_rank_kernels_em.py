@@ -7,7 +7,8 @@ rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # decomposed part: em_update_e launches on nk = nzl planes are short; find the first short one
 ue=[(i,(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3) for i,r in enumerate(rows) if 'em_update_e_kernel' in r['Kernel_Name']]
 mx=max(d for _,d in ue)
-short=[i for i,d in ue if d<mx/3]
+mn=min(d for _,d in ue)
+short=[i for i,d in ue if d<mx/3] if mx>2*mn else [i for i,_ in ue]   # (--c4-skip-single: ranks only)
 i0,i1=short[8],short[-1]
 n=len(short)-9
 agg=collections.Counter(); tot=0

@@ -620,3 +620,71 @@ def test_chained_lattice_step_is_bit_identical(fp, eo, monkeypatch, precision, f
     sim.step(); ora.step()
     same("after the switch went off")
     sim.destroy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("form", ["chained", "four sweeps"])
+def test_chained_lattice_step_on_the_ranks_of_a_decomposition(fp, eo, monkeypatch, precision, form):
+    """Round 4: the ranks of a full-EM decomposition run the chained lattice step too — each forms the half-time B of its slab
+    AND of its halo planes itself, from the E halo it receives (one plane deeper above), so the halo copy of B is gone.
+    Four ranks on a (24, 16, 48) lattice, two ghost planes, compared with ONE handle bit for bit: (1) six frames WITHOUT any
+    read-back in between (the chain stays open across frames and migrations); (2) then B is read from rank 1 ALONE — it forms
+    B of the integer time from what it holds and reopens by itself, the others stay open, nothing is exchanged for it — and
+    two more frames; (3) a checkpoint-free close of every rank at the end.  FPIC_EM_CHAIN=0: the same with four sweeps and
+    both halo copies."""
+    monkeypatch.setenv("FPIC_EM_CHAIN", "1" if form == "chained" else "0")
+    world, shape, ghost = 4, (24, 16, 48), 2
+    rng = np.random.default_rng(77)
+    n = 30000
+    L = tuple(1e-3 * s for s in shape)
+    spec = em_spec(shape, L, n, cfl_dt(shape, L), macro_weight=1e6)
+    nzl = shape[2] // world
+    pos, vel = rng.random((n, 3)) * L, rng.normal(0, 0.3, (n, 3))
+    owner = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
+    order = np.argsort(owner, kind="stable")
+    pos, vel, counts = pos[order], vel[order], np.bincount(owner, minlength=world)
+    E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
+    one = fp.makeCylindricalParticlePusher(spec, precision=precision)
+    one.set(position=pos, velocity=vel)
+    one.set(edge_E=E, face_B=B)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(spec, precision=precision)
+        s.domainInit(r, world, ghost_planes=ghost, migrate_every=3)
+        first = int(counts[:r].sum())
+        s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
+        s.set(edge_E=E, face_B=B)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+
+    def compare(tag, which_ranks=range(world), fields=(fp.F3_EDGE_E, fp.F3_FACE_B)):
+        for which in fields:
+            ref = one.readField(which).reshape(shape[2], -1)
+            for r in which_ranks:
+                got = ranks[r].readField(which).reshape(shape[2], -1)
+                assert same_bits(got[r * nzl:(r + 1) * nzl], ref[r * nzl:(r + 1) * nzl]), (tag, which, r)
+
+    def compare_particles(tag):
+        parts = [s.domainGet() for s in ranks]
+        ids = np.concatenate([p["ids"] for p in parts])
+        assert np.array_equal(np.sort(ids), np.arange(n)), tag
+        ref = one.getParticles()
+        assert same_bits(np.concatenate([p["position"] for p in parts])[np.argsort(ids)], ref["position"]), tag
+        assert same_bits(np.concatenate([p["velocity"] for p in parts])[np.argsort(ids)], ref["velocity"]), tag
+
+    for frame in range(6):
+        one.step(); group.step()
+    compare_particles("six frames without a read-back")
+    compare("rank 1 alone", which_ranks=[1])        # (closes rank 1's chain, and the one handle's)
+    for frame in range(2):
+        one.step(); group.step()
+    compare_particles("after one rank had closed")
+    compare("the end")
+    jref = one.readField(fp.F3_J_FIXED).reshape(shape[2], -1)
+    for r, s in enumerate(ranks):
+        got = s.readField(fp.F3_J_FIXED).reshape(shape[2], -1)
+        assert np.array_equal(got[r * nzl:(r + 1) * nzl], jref[r * nzl:(r + 1) * nzl]), r
+    stats = [s.domainStats() for s in ranks]
+    assert sum(s["migrated"] for s in stats) > 0 and all(s["lost"] == 0 for s in stats)
+    for s in ranks + [one]:
+        s.destroy()
