@@ -1760,6 +1760,7 @@ int load_rank_checkpoint(fpic_handle* h, const char* path)
     for (const auto& a : rank_fields(h))
         if (int rc = rank_io(h, bf.f, a.first, a.second, false)) return rc;
     for (int a = 0; a < 3; ++a) st->B0[a] = hd.B0[a];
+    st->em_open = false;    // (the file's B is B of the integer time)
     st->spill_pending[0] = st->spill_pending[1] = false;
     st->last_spill = 0;
     st->substeps_since_bin = 0;
@@ -1776,8 +1777,8 @@ int load_rank_checkpoint(fpic_handle* h, const char* path)
 int save_checkpoint(fpic_handle* h, const char* path)
 {
     State* st = h->es;
+    if (int rc = em_close_any(h)) return rc;    // (the file holds B of the integer time; a rank forms it from what it holds)
     if (st->dom) return save_rank_checkpoint(h, path);
-    if (int rc = em_close_any(h)) return rc;    // (the file holds B of the integer time)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     BoxFile bf{ std::fopen(path, "wb") };
     if (!bf.f) return fail(h, FPIC_ERR_STATE, "cannot open %s for writing", path);

@@ -295,7 +295,9 @@ def test_configs4_decomposition_at_its_lattice(fp, eo, bench):
     """The full-EM decomposition at configs[4]'s lattice (until now asserted at 64 x 64 x 128): 512^3
     Yee lattice, fp64, 8 in-process ranks of 64 planes against ONE handle on a population that can sit beside it (2e8
     electrons): after 3 frames (6 sub-steps, one migration) the integer current grid and both lattice fields on every
-    rank's planes and every particle are bit-identical to the one handle's, none lost."""
+    rank's planes and every particle are bit-identical to the one handle's, none lost.  The ranks take the decomposed solve
+    for their start field and keep their slab and halo planes only, as a run of that size would (with whole-grid arrays
+    eight ranks' two half-time arrays of the chained lattice step no longer fit beside the one handle: 69 GB)."""
     import torch
     n, grid, world = 200_000_000, 512, 8
     c, eps0, me, qe, vth, wp = 2.998e8, 8.8541878128e-12, 9.109e-31, -1.602e-19, 1e-3, 1e10
@@ -308,7 +310,7 @@ def test_configs4_decomposition_at_its_lattice(fp, eo, bench):
     ranks = []
     for r in range(world):
         s = fp.makeCylindricalParticlePusher(dict(spec, count=int(share * 1.25)))
-        s.domainInit(r, world, ghost_planes=2, migrate_every=4)
+        s.domainInit(r, world, ghost_planes=2, migrate_every=4, distributed_solve=True)   # (a rank keeps 73 of the 512 planes)
         ranks.append(s)
     for r in range(world):
         p, v = bench.c4_rank_particles(r, world, 0, share, L, vth, 1.0, 0)
