@@ -128,8 +128,11 @@ struct Domain {
     int H = 0;
     long long* j_recv[2] = {};
     bool halos_stale = false;           // lattice fields restored from a checkpoint: the halo planes are refreshed before the next sub-step
-    unsigned* counts_dev = nullptr;     // down, up, lost, overflow | received from above, from below
+    // per species a block of 8 words: down, up, lost, overflow | received from above, from below | -, - ; after the
+    // kMigSpecies blocks one more, whose first word is the ranks' agreement (agree_max)
+    unsigned* counts_dev = nullptr;
     unsigned* counts_host = nullptr;    // pinned copy
+    int mig_sp = 0;                     // the species whose payload the exchange X_MIG_PAYLOAD moves
     // the ghost-plane exchange of a sub-step runs on a stream of its own while the interior of the slab is pushed
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_boundary = nullptr, ev_ghost = nullptr;
@@ -1960,6 +1963,8 @@ struct Xfer {
     size_t recv_bytes;
     int tag;                // a message meets the receive of its destination that names the sender and carries the same tag
 };
+constexpr int kMigSpecies = 16;                    // species a decomposition can migrate (their counter blocks)
+constexpr size_t kMigWords = 8 * (kMigSpecies + 1);  // words of Domain::counts_dev / counts_host
 enum Exchange { X_GHOST = 0, X_MIG_COUNTS, X_MIG_PAYLOAD, X_TRANSPOSE, X_TRANSPOSE_BACK, X_PHI, X_EM_J, X_EM_E, X_EM_B };
 
 // A rank of a full-EM decomposition may run the chained lattice step (em_chain_tiled_kernel) when its slab can give H + 1
@@ -1986,13 +1991,17 @@ void dom_xfers(fpic_handle* h, int which, std::vector<Xfer>& out)
         const int lo = (d.z0 - d.G + st->nz) % st->nz, hi = (d.z0 + d.nzl) % st->nz;
         out.push_back({ down, up, st->rho_fixed + lp(st, lo) * plane, d.G * plane * 8, d.ghost_recv[0], d.G * plane * 8, 0 });
         out.push_back({ up, down, st->rho_fixed + lp(st, hi) * plane, (d.G + 1) * plane * 8, d.ghost_recv[1], (d.G + 1) * plane * 8, 1 });
-    } else if (which == X_MIG_COUNTS) {
-        out.push_back({ down, up, d.counts_dev + 0, 4, d.counts_dev + 4, 4, 0 });
-        out.push_back({ up, down, d.counts_dev + 1, 4, d.counts_dev + 5, 4, 1 });
+    } else if (which == X_MIG_COUNTS) { // every species' two counts in one exchange
+        for (size_t sp = 0; sp < st->sp.size(); ++sp) {
+            unsigned* c = d.counts_dev + 8 * sp;
+            out.push_back({ down, up, c + 0, 4, c + 4, 4, static_cast<int>(2 * sp) });
+            out.push_back({ up, down, c + 1, 4, c + 5, 4, static_cast<int>(2 * sp + 1) });
+        }
     } else if (which == X_MIG_PAYLOAD) {
         const size_t rec = sizeof(MigRecord<T>);
-        out.push_back({ down, up, d.mig_send[0], d.counts_host[0] * rec, d.mig_recv[0], d.counts_host[4] * rec, 0 });
-        out.push_back({ up, down, d.mig_send[1], d.counts_host[1] * rec, d.mig_recv[1], d.counts_host[5] * rec, 1 });
+        const unsigned* c = d.counts_host + 8 * d.mig_sp;
+        out.push_back({ down, up, d.mig_send[0], c[0] * rec, d.mig_recv[0], c[4] * rec, 0 });
+        out.push_back({ up, down, d.mig_send[1], c[1] * rec, d.mig_recv[1], c[5] * rec, 1 });
     } else if (which == X_TRANSPOSE || which == X_TRANSPOSE_BACK) {
         // all-to-all of equal chunks: chunk q of the send side goes to rank q and lands there as chunk `rank`
         const size_t chunk = static_cast<size_t>(d.nzl) * d.nyl * row_pitch<T>(st) * 2 * sizeof(T);
@@ -2153,112 +2162,125 @@ int agree_max(Ranks& rk, unsigned mine_of_rank0, const std::vector<unsigned>& mi
     }
     fpic_handle* h = rk.hs[0];
     Domain& d = *h->es->dom;
-    d.counts_host[6] = mine_of_rank0;
-    HIP_TRY(h, hipMemcpyAsync(d.counts_dev + 6, d.counts_host + 6, sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
-    if (int e = fcomm::check(h, fdyn::rccl().AllReduce(d.counts_dev + 6, d.counts_dev + 6, 1, ncclUint32, ncclMax, h->comm->nccl, h->stream), "ncclAllReduce")) return e;
-    HIP_TRY(h, hipMemcpyAsync(d.counts_host + 6, d.counts_dev + 6, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    constexpr size_t W = 8 * kMigSpecies; // (the word after the species' counter blocks)
+    d.counts_host[W] = mine_of_rank0;
+    HIP_TRY(h, hipMemcpyAsync(d.counts_dev + W, d.counts_host + W, sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+    if (int e = fcomm::check(h, fdyn::rccl().AllReduce(d.counts_dev + W, d.counts_dev + W, 1, ncclUint32, ncclMax, h->comm->nccl, h->stream), "ncclAllReduce")) return e;
+    HIP_TRY(h, hipMemcpyAsync(d.counts_host + W, d.counts_dev + W, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    out = d.counts_host[6];
+    out = d.counts_host[W];
     return FPIC_OK;
 }
 
 // particles that have left the slab move to the neighbour that owns them; then every species is re-binned.
 // Every rank takes the same path through the exchanges: a leaver that does not fit the message stays where it is (it
 // still deposits on the ghost planes) and leaves with the next migration; a rank that cannot hold its arrivals is an
-// error that ALL ranks return, agreed before any payload moves, with the packed particles put back in their slots.
+// error that ALL ranks return — agreed ONCE, for every species, before the first particle of any species is touched
+// (round 4: a count-only scan of every species first; rounds 2-3 agreed species by species, so a later species' refusal
+// came after earlier ones had moved, and cost a blocking all-reduce per species).
 template <typename T>
 int migrate(Ranks& rk)
 {
     const size_t nsp = rk.hs[0]->es->sp.size();
+    if (nsp > static_cast<size_t>(kMigSpecies))
+        return fail(rk.hs[0], FPIC_ERR_STATE, "migration: %zu species, the decomposition's counters hold %d", nsp, kMigSpecies);
     for (fpic_handle* h : rk.hs) timing_begin(h, KC_SORT);
-    for (size_t sp = 0; sp < nsp; ++sp) {
-        for (fpic_handle* h : rk.hs) {
-            State* st = h->es;
-            Domain& d = *st->dom;
-            Species& s = st->sp[sp];
-            HIP_TRY(h, hipMemsetAsync(d.counts_dev, 0, 8 * sizeof(unsigned), h->stream));
-            // a species whose last push left a census of the current positions is not re-binned by separate passes:
-            // the census is corrected for leavers and arrivals and the next push re-bins (and compacts) itself
-            const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
-            if (s.n) {
-                // a species binned since its last upload is scanned along the slab's faces only: the interior tile layers
-                // (interior_layers: the same rule as the two-part push) cannot hold a leaver
-                uint32_t lo = 0, hi = 0;
-                const bool faces_only = s.binned && interior_layers(st, lo, hi);
-                const uint32_t per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
-                mig_pack_kernel<T><<<std::min<unsigned>(blocks_for(s.n, 256 * kMigPer), 4096u), 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
-                                                                          static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]),
-                                                                          d.mig_cap, d.counts_dev, riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty,
-                                                                          faces_only ? s.tile_start2[s.wl] : nullptr, lo * per_layer, hi * per_layer);
-            }
-            // the message counters counted every leaver; what the messages hold is at most mig_cap records each
-            mig_clamp_kernel<<<1, 64, 0, h->stream>>>(d.counts_dev, d.mig_cap);
-            HIP_TRY(h, hipGetLastError());
+    // the scan of one species of one rank: its leavers counted (COUNT_ONLY) or packed into the two messages
+    auto scan = [&](fpic_handle* h, size_t sp, bool count_only) -> int {
+        State* st = h->es;
+        Domain& d = *st->dom;
+        Species& s = st->sp[sp];
+        unsigned* counts = d.counts_dev + 8 * sp;
+        HIP_TRY(h, hipMemsetAsync(counts, 0, 4 * sizeof(unsigned), h->stream)); // (what has arrived in words 4, 5 stays)
+        // a species whose last push left a census of the current positions is not re-binned by separate passes:
+        // the census is corrected for leavers and arrivals and the next push re-bins (and compacts) itself
+        const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
+        if (s.n) {
+            // a species binned since its last upload is scanned along the slab's faces only: the interior tile layers
+            // (interior_layers: the same rule as the two-part push) cannot hold a leaver
+            uint32_t lo = 0, hi = 0;
+            const bool faces_only = s.binned && interior_layers(st, lo, hi);
+            const uint32_t per_layer = static_cast<uint32_t>(st->ntx) * st->nty;
+            const unsigned grid = std::min<unsigned>(blocks_for(s.n, 256 * kMigPer), 4096u);
+            const uint32_t* ts = faces_only ? s.tile_start2[s.wl] : nullptr;
+            if (count_only)
+                mig_pack_kernel<T, true><<<grid, 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world, nullptr, nullptr,
+                                                                     d.mig_cap, counts, nullptr, st->nx, st->ny, st->ntx, st->nty, ts, lo * per_layer, hi * per_layer);
+            else
+                mig_pack_kernel<T, false><<<grid, 256, 0, h->stream>>>(static_cast<T*>(s.slab[s.cur]), s.n_pad, s.id[s.cur], s.n, st->nz, d.z0, d.nzl, d.G, d.world,
+                                                                      static_cast<MigRecord<T>*>(d.mig_send[0]), static_cast<MigRecord<T>*>(d.mig_send[1]), d.mig_cap, counts,
+                                                                      riding ? s.tile_count : nullptr, st->nx, st->ny, st->ntx, st->nty, ts, lo * per_layer, hi * per_layer);
         }
-        if (int e = exchange<T>(rk, X_MIG_COUNTS)) return e;
-        std::vector<unsigned> verdict(rk.hs.size(), 0u);
-        for (size_t r = 0; r < rk.hs.size(); ++r) {
-            fpic_handle* h = rk.hs[r];
-            Domain& d = *h->es->dom;
+        // the message counters counted every leaver; what the messages hold is at most mig_cap records each
+        mig_clamp_kernel<<<1, 64, 0, h->stream>>>(counts, d.mig_cap, count_only ? 1 : 0);
+        HIP_TRY(h, hipGetLastError());
+        return FPIC_OK;
+    };
+    // 1. every species counted, the counts exchanged, ONE verdict
+    for (size_t sp = 0; sp < nsp; ++sp)
+        for (fpic_handle* h : rk.hs)
+            if (int e = scan(h, sp, true)) return e;
+    if (int e = exchange<T>(rk, X_MIG_COUNTS)) return e;
+    std::vector<unsigned> verdict(rk.hs.size(), 0u);
+    for (size_t r = 0; r < rk.hs.size(); ++r) {
+        fpic_handle* h = rk.hs[r];
+        Domain& d = *h->es->dom;
+        HIP_TRY(h, hipMemcpyAsync(d.counts_host, d.counts_dev, 8 * nsp * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (size_t sp = 0; sp < nsp && !verdict[r]; ++sp) {
             const Species& s = h->es->sp[sp];
-            HIP_TRY(h, hipMemcpyAsync(d.counts_host, d.counts_dev, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            const size_t in = static_cast<size_t>(d.counts_host[4]) + d.counts_host[5];
-            const size_t out = static_cast<size_t>(d.counts_host[0]) + d.counts_host[1];
-            if (d.counts_host[4] > d.mig_cap || d.counts_host[5] > d.mig_cap) {
+            const unsigned* c = d.counts_host + 8 * sp;
+            const size_t in = static_cast<size_t>(c[4]) + c[5], out = static_cast<size_t>(c[0]) + c[1];
+            if (c[4] > d.mig_cap || c[5] > d.mig_cap) {
                 verdict[r] = 2;
-                fail(h, FPIC_ERR_STATE, "migration: rank %d would receive %u and %u records, its message buffers hold %u", d.rank, d.counts_host[4], d.counts_host[5], d.mig_cap);
+                fail(h, FPIC_ERR_STATE, "migration: rank %d would receive %u and %u records of species %zu, its message buffers hold %u", d.rank, c[4], c[5], sp, d.mig_cap);
             } else if (s.n + in > s.n_pad || s.n - out + in > s.cap) {
                 verdict[r] = 1;
                 fail(h, FPIC_ERR_STATE, "migration: rank %d would hold %zu particles of species %zu, capacity %zu", d.rank, s.n - out + in, sp, s.cap);
             }
         }
-        unsigned worst = 0;
-        if (int e = agree_max(rk, verdict[0], verdict, worst)) return e;
-        if (worst) { // nothing has been delivered yet: every rank puts its packed particles back and returns the error
-            int first_bad = -1;
-            for (size_t r = 0; r < rk.hs.size(); ++r) {
-                fpic_handle* h = rk.hs[r];
-                State* st = h->es;
-                Domain& d = *st->dom;
-                Species& s = st->sp[sp];
-                const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
-                for (int k = 0; k < 2; ++k)
-                    if (d.counts_host[k])
-                        mig_restore_kernel<T><<<blocks_for(d.counts_host[k]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_send[k]), d.counts_host[k],
-                                                                                                  static_cast<T*>(s.slab[s.cur]), riding ? s.tile_count : nullptr, st->nx, st->ny,
-                                                                                                  st->nz, st->ntx, st->nty);
-                HIP_TRY(h, hipGetLastError());
-                if (verdict[r] && first_bad < 0) first_bad = static_cast<int>(r);
-                else if (!verdict[r]) fail(h, FPIC_ERR_STATE, "migration: another rank cannot hold its arrivals (species %zu); nothing was moved", sp);
-                timing_end(h);
-            }
-            if (first_bad > 0) rk.hs[0]->err = rk.hs[first_bad]->err; // (a group reports through its first member)
-            return FPIC_ERR_STATE;
+    }
+    unsigned worst = 0;
+    if (int e = agree_max(rk, verdict[0], verdict, worst)) return e;
+    if (worst) { // nothing has been touched: every rank returns the error
+        int first_bad = -1;
+        for (size_t r = 0; r < rk.hs.size(); ++r) {
+            fpic_handle* h = rk.hs[r];
+            if (verdict[r] && first_bad < 0) first_bad = static_cast<int>(r);
+            else if (!verdict[r]) fail(h, FPIC_ERR_STATE, "migration: another rank cannot hold its arrivals; nothing was moved");
+            timing_end(h);
         }
+        if (first_bad > 0) rk.hs[0]->err = rk.hs[first_bad]->err; // (a group reports through its first member)
+        return FPIC_ERR_STATE;
+    }
+    // 2. species by species: pack (the same scan: the same counts), payload, arrivals, the next bin table
+    for (size_t sp = 0; sp < nsp; ++sp) {
         for (fpic_handle* h : rk.hs) {
+            if (int e = scan(h, sp, false)) return e;
             Domain& d = *h->es->dom;
-            d.lost += d.counts_host[2];
-            d.deferred += d.counts_host[3];
-            d.migrated += d.counts_host[0] + d.counts_host[1];
+            const unsigned* c = d.counts_host + 8 * sp;
+            d.mig_sp = static_cast<int>(sp);
+            d.lost += c[2];
+            d.deferred += c[3];
+            d.migrated += c[0] + c[1];
         }
         if (int e = exchange<T>(rk, X_MIG_PAYLOAD)) return e;
         for (fpic_handle* h : rk.hs) {
             State* st = h->es;
             Domain& d = *st->dom;
             Species& s = st->sp[sp];
-            const size_t in = static_cast<size_t>(d.counts_host[4]) + d.counts_host[5];
-            const size_t out = static_cast<size_t>(d.counts_host[0]) + d.counts_host[1];
+            const unsigned* c = d.counts_host + 8 * sp;
+            const size_t in = static_cast<size_t>(c[4]) + c[5];
+            const size_t out = static_cast<size_t>(c[0]) + c[1];
             T* slab = static_cast<T*>(s.slab[s.cur]);
             const bool riding = s.binned && s.census_fresh && st->solver != FPIC_SOLVER_YEE;
             uint32_t* census = riding ? s.tile_count : nullptr;
-            if (d.counts_host[4])
-                mig_append_kernel<T><<<blocks_for(d.counts_host[4]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[0]), d.counts_host[4], slab, s.n_pad,
-                                                                                        s.id[s.cur], s.n, census, st->nx, st->ny, st->nz, st->ntx, st->nty);
-            if (d.counts_host[5])
-                mig_append_kernel<T><<<blocks_for(d.counts_host[5]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[1]), d.counts_host[5], slab, s.n_pad,
-                                                                                        s.id[s.cur], s.n + d.counts_host[4], census, st->nx, st->ny, st->nz, st->ntx,
-                                                                                        st->nty);
+            if (c[4])
+                mig_append_kernel<T><<<blocks_for(c[4]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[0]), c[4], slab, s.n_pad, s.id[s.cur], s.n, census, st->nx,
+                                                                             st->ny, st->nz, st->ntx, st->nty);
+            if (c[5])
+                mig_append_kernel<T><<<blocks_for(c[5]), 256, 0, h->stream>>>(static_cast<const MigRecord<T>*>(d.mig_recv[1]), c[5], slab, s.n_pad, s.id[s.cur], s.n + c[4], census,
+                                                                             st->nx, st->ny, st->nz, st->ntx, st->nty);
             HIP_TRY(h, hipGetLastError());
             if (riding) {
                 // the next bin table from the corrected census; the push that follows skips the dead slots, takes the
@@ -2907,7 +2929,7 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     int rc;
     if ((rc = dev_alloc(h, reinterpret_cast<void**>(&d->ghost_recv[0]), ghost_planes * plane * 8, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&d->ghost_recv[1]), (ghost_planes + 1) * plane * 8, acc)) ||
-        (rc = dev_alloc(h, reinterpret_cast<void**>(&d->counts_dev), 8 * sizeof(unsigned), acc)))
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&d->counts_dev), kMigWords * sizeof(unsigned), acc)))
         return rc;
     for (int k = 0; k < 2; ++k)
         if ((rc = dev_alloc(h, &d->mig_send[k], d->mig_cap * rec, acc)) || (rc = dev_alloc(h, &d->mig_recv[k], d->mig_cap * rec, acc))) return rc;
@@ -2916,7 +2938,7 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
         for (int k = 0; k < 2; ++k)
             if ((rc = dev_alloc(h, reinterpret_cast<void**>(&d->j_recv[k]), static_cast<size_t>(d->H) * plane * 3 * sizeof(long long), acc))) return rc;
     }
-    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&d->counts_host), 8 * sizeof(unsigned)));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&d->counts_host), kMigWords * sizeof(unsigned)));
     if (const char* v = std::getenv("FPIC_DOMAIN_OVERLAP")) d->overlap = std::strcmp(v, "0") != 0;
     if (world > 1 && d->overlap) {
         int lo = 0, hi = 0;
@@ -2925,7 +2947,7 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
         HIP_TRY(h, hipEventCreateWithFlags(&d->ev_boundary, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&d->ev_ghost, hipEventDisableTiming));
     }
-    std::memset(d->counts_host, 0, 8 * sizeof(unsigned));
+    std::memset(d->counts_host, 0, kMigWords * sizeof(unsigned));
     for (Species& s : st->sp) s.n = 0; // the rank's particles arrive through domain_set_particles
     // the full-EM mode solves once, for the initial field: with the library's own transforms (whose decomposed solve is the
     // one handle's, bit for bit) its ranks can take the decomposed solve too, and then never hold the whole grid

@@ -1972,7 +1972,7 @@ template <typename T>
 struct MigRecord {
     T v[6];
     uint32_t id;
-    uint32_t slot;   // where the sender held it (mig_restore_kernel: a migration called off puts it back)
+    uint32_t slot;   // where the sender held it (keeps the record at 8-byte multiples; rounds 2-3 put a called-off migration back through it)
 };
 
 // Particles whose cell has left this rank's slab [z0, z0 + nzl) are appended to the send buffer of the
@@ -1980,7 +1980,9 @@ struct MigRecord {
 // the re-binning that follows drops dead slots.  A particle further than `reach` planes from the slab has
 // outrun the ghost planes (its charge was lost from the exchange): counted in lost.
 constexpr int kMigPer = 16; // particles per lane of the pack: one reservation on the message counters per 4096 particles
-template <typename T>
+// COUNT_ONLY: the same scan, the counters only — nothing is packed and no slot is touched (the count of every species
+// is agreed by all ranks before the first particle of any species moves: fes_api.hip, migrate).
+template <typename T, bool COUNT_ONLY = false>
 __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, const uint32_t* __restrict__ id, size_t n, int nz, int z0, int nzl,
                                                        int reach, int world, MigRecord<T>* down, MigRecord<T>* up, unsigned cap,
                                                        unsigned* __restrict__ counts /* down, up, lost, overflow */,
@@ -2033,6 +2035,7 @@ __global__ __launch_bounds__(256) void mig_pack_kernel(T* slab, size_t stride, c
         }
         if (threadIdx.x == 2 && l_lost) atomicAdd(counts + 2, l_lost);
         __syncthreads();
+        if constexpr (COUNT_ONLY) continue; // (every thread of the workgroup: the barriers above are the round's last)
 #pragma unroll
         for (int k = 0; k < kMigPer; ++k) {
             const unsigned dir = (flags >> (2 * k)) & 3u;
@@ -2078,22 +2081,13 @@ __global__ __launch_bounds__(256) void mig_append_kernel(const MigRecord<T>* __r
 }
 
 // the two message counters counted every leaver; the messages hold at most `cap` records each (the others stayed)
-static __global__ void mig_clamp_kernel(unsigned* counts, unsigned cap)
+// (record_overflow, after a COUNT_ONLY scan: counts[3] <- the leavers that will stay behind, which the pack itself counts)
+static __global__ void mig_clamp_kernel(unsigned* counts, unsigned cap, int record_overflow = 0)
 {
-    if (threadIdx.x < 2 && counts[threadIdx.x] > cap) counts[threadIdx.x] = cap;
-}
-
-// a migration that the ranks called off before any payload moved: the packed particles go back to their slots (only x
-// was overwritten) and into the census
-template <typename T>
-__global__ __launch_bounds__(256) void mig_restore_kernel(const MigRecord<T>* __restrict__ sent, unsigned count, T* slab, uint32_t* __restrict__ census, int nx, int ny,
-                                                          int nz, int ntx, int nty)
-{
-    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= count) return;
-    const MigRecord<T> m = sent[r];
-    slab[m.slot] = m.v[0];
-    if (census) atomicAdd(census + key_of<T>(m.v[0], m.v[1], m.v[2], nx, ny, nz, ntx, nty), 1u);
+    if (threadIdx.x < 2 && counts[threadIdx.x] > cap) {
+        if (record_overflow) atomicAdd(counts + 3, counts[threadIdx.x] - cap);
+        counts[threadIdx.x] = cap;
+    }
 }
 
 // ghost planes received from a neighbour, added onto this rank's own planes (exact: int64)

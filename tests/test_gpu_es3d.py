@@ -1234,3 +1234,66 @@ def test_decomposed_checkpoint_resume_is_bit_identical(fp, eo, tmp_path, precisi
         b[0].loadCheckpoint(tmp_path / "short.ckpt")
     for s in a + b:
         s.destroy()
+
+
+@pytest.mark.parametrize("solver", ["poisson_fft", "yee"])
+def test_a_refused_migration_moves_nothing(fp, solver):
+    """ADVICE r03 (low), closed in round 4: the ranks agree ONCE, over every species, whether a migration can be held — before
+    the first particle of any species is touched.  Two ranks, two species: the electrons spread evenly and migrate happily,
+    the ions all stream upwards out of rank 0 into rank 1, whose ion capacity is a few particles above what it starts with.
+    The step whose migration would overfill rank 1 raises on the whole group, with the capacity in the message — and every
+    rank still holds exactly the particles (both species, bit for bit) it held before that call: rounds 2-3 agreed species
+    by species, so the electrons had already moved when the ions were refused."""
+    rng = np.random.default_rng(17)
+    world, shape = 2, (16, 16, 32)
+    L = tuple(1e-3 * s for s in shape)
+    n, ni = 6000, 4000
+    nzl = shape[2] // world
+    em = solver == "yee"
+    dt = 5e-12
+    if em:
+        d = [L[a] / shape[a] for a in range(3)]
+        dt = 0.5 / (2.998e8 * np.sqrt(sum(1 / x ** 2 for x in d)))
+    spec = box_spec(shape, L, count=2 * n, dt=dt, solver=solver, macro_weight=1.0)
+    pe, ve = rng.random((n, 3)) * L, rng.normal(0, 0.01, (n, 3))
+    pi = rng.random((ni, 3)) * L
+    pi[:, 2] = rng.random(ni) * L[2] * 0.5                       # every ion starts in rank 0 ...
+    dz = L[2] / shape[2]
+    vz = 0.9 * dz / (dt * 2.998e8)                               # ... and moves 0.9 cells up per sub-step
+    vi = np.stack([np.zeros(ni), np.zeros(ni), np.full(ni, vz)], axis=1)
+    ranks = []
+    for r in range(world):
+        s = fp.makeCylindricalParticlePusher(spec, precision="fp32")
+        s.addSpecies(MP, -QE, ni if r == 0 else 300)             # rank 1 can hold 300 ions
+        s.domainInit(r, world, ghost_planes=2, migrate_every=2, distributed_solve=False)
+        own = np.floor(pe[:, 2] / L[2] * shape[2]).astype(int) // nzl == r
+        s.domainSet(pe[own], ve[own], first_id=0 if r == 0 else int((~own).sum()), species=0)
+        if r == 0:
+            s.domainSet(pi, vi, first_id=0, species=1)
+        ranks.append(s)
+    group = fp.BoxGroup(ranks)
+    group.precalc()
+
+    def snapshot():
+        return [[s.domainGet(species=sp) for sp in (0, 1)] for s in ranks]
+
+    raised = None
+    for frame in range(12):
+        before = snapshot()
+        try:
+            group.step()
+        except fp.FusionPicError as e:
+            raised = str(e)
+            break
+    assert raised is not None and "capacity" in raised and "species 1" in raised, raised
+    assert frame > 0                                            # (some migrations went through first)
+    after = snapshot()
+    for r in range(world):
+        for sp in (0, 1):
+            a, b = before[r][sp], after[r][sp]
+            ia, ib = np.argsort(a["ids"]), np.argsort(b["ids"])
+            assert np.array_equal(a["ids"][ia], b["ids"][ib]), (r, sp)
+            assert same_bits(a["position"][ia], b["position"][ib]) and same_bits(a["velocity"][ia], b["velocity"][ib]), (r, sp)
+    assert len(after[1][0]["ids"]) > 0 and len(after[1][1]["ids"]) <= 300
+    for s in ranks:
+        s.destroy()
