@@ -2,6 +2,8 @@
 // Builds a uniform plasma already sorted by tile (256^3 nodes, P particles per cell), a random field, and
 // times push3_tiles_kernel<float> with parts switched off and with 512 / 1024 threads per workgroup.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I fusion-sim_amd/csrc -I include scripts/ablate_push3.hip -o /tmp/ablate_push3
+#include <hip/hip_runtime.h>
+#include "fpic_handle.hpp"
 #include "fes_kernels.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +65,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(spilled, 0, 8)); CK(hipDeviceSynchronize());
     Push3Args<float> a{};
     a.slab = slab; a.stride = stride; a.n = n; a.E4 = E4; a.rho = rho; a.nx = a.ny = a.nz = g;
+    a.held = Held{ 0, g };   // (every plane is held: without this no window would be staged nor flushed — the slab-only arrays of round 3)
     a.hc = 1e-9f; a.dx = a.dy = a.dz = 1e-5f;   // tiny steps: the order stays as generated over all repetitions
     a.Z = 1; a.ntx = ntx; a.nty = nty; a.ntz = ntz; a.work = work; a.nwork = nwork; a.spilled = spilled; a.tile_count = tcount;
     const unsigned grid = ntiles * per;
@@ -70,6 +73,12 @@ int main(int argc, char** argv) {
            sorted ? "cell-sorted" : "random", chunk, grid);
     const int R = 5;
 #define ROW(TH, ABL, what) { float ms = run<TH, ABL>(a, grid, R); printf("%-52s %4d threads  %7.3f ms  %6.0f GB/s\n", what, TH, ms, 48.0 * n / ms / 1e6); }
+    if (argc > 5) { // short form for density sweeps: the 1024-thread rows only
+        ROW(1024, 0, "full kernel");
+        ROW(1024, 4, "no window staging or flush");
+        ROW(1024, 3, "no LDS accumulation, no gather (staging/flush kept)");
+        ROW(1024, 7, "neither, no window staging or flush");
+    } else {
     ROW(512, 0, "full kernel");
     ROW(1024, 0, "full kernel");
     ROW(512, 1, "no LDS accumulation");
@@ -80,6 +89,7 @@ int main(int argc, char** argv) {
     ROW(1024, 3, "neither (stream + arithmetic + staging/flush)");
     ROW(512, 7, "neither, no window staging or flush");
     ROW(1024, 7, "neither, no window staging or flush");
+    }
     unsigned long long sp; CK(hipMemcpy(&sp, spilled, 8, hipMemcpyDeviceToHost)); printf("(out-of-window deposits over all runs: %llu)\n", sp);
     return 0;
 }
