@@ -652,6 +652,9 @@ __global__ __launch_bounds__(push_threads<CTR>()) void push_tiles_kernel(PushArg
         __syncthreads();
         // flush: consecutive lanes take consecutive scalars of one LDS row = consecutive
         // global addresses, so a wave's atomic is one 256-byte piece
+#if defined(FPIC_ABL_PUSH) && (FPIC_ABL_PUSH & 1)   // development probe (timing only): the window's sums are not flushed
+        if (false)
+#endif
         for (int k = threadIdx.x; SUMS && k < SW * SW * 4; k += kPushThreads) {
             const int lj = k / (SW * 4);
             const int rem = k - lj * (SW * 4);
