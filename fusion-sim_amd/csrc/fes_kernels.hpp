@@ -653,7 +653,7 @@ constexpr size_t push3_lds_bytes() { return static_cast<size_t>(Win<T>::N) * (4 
 // range + rank of arrival in the other particle set: no separate count / scatter passes in steady state.
 //
 // ABL: development probe bits, timing only (scripts/ablate_push3.hip): 1 = no LDS accumulation, 2 = no field
-// gather, 4 = no window staging / flush.  The library instantiates ABL = 0 only.
+// gather, 4 = no window staging / flush, 8 = the flush stores instead of adding atomically.  The library instantiates ABL = 0 only.
 template <typename T, bool HAS_B, bool DEPOSIT_ONLY, bool REBIN = false, int THREADS = kPushThreads3, int ABL = 0>
 __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
 {
@@ -855,6 +855,10 @@ __global__ __launch_bounds__(THREADS) void push3_tiles_kernel(Push3Joint<T> J)
         // (wrap_window: no division by a run-time number for boxes of 32 nodes or more)
         const int gi = wrap_window(ox + l, c0.nx), gj = wrap_window(oy + m, c0.ny),
                   gk = wrap_window(oz - c0.held.zs0 + n, c0.nz);
+        if constexpr ((ABL & 8) != 0) { // development probe (timing only): plain stores where the library adds atomically
+            if (gk < c0.held.nzs) c0.rho[static_cast<size_t>(gi) + static_cast<size_t>(c0.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(c0.ny) * gk)] = v;
+            continue;
+        }
         if (gk < c0.held.nzs) atomicAdd(c0.rho + (static_cast<size_t>(gi) + static_cast<size_t>(c0.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(c0.ny) * gk)), v);
     }
     if (my_spill) atomicAdd(c0.spilled, static_cast<unsigned long long>(my_spill));

@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
     if (argc > 5) { // short form for density sweeps: the 1024-thread rows only
         ROW(1024, 0, "full kernel");
         ROW(1024, 4, "no window staging or flush");
+        ROW(1024, 8, "flush by plain stores instead of atomics");
         ROW(1024, 3, "no LDS accumulation, no gather (staging/flush kept)");
         ROW(1024, 7, "neither, no window staging or flush");
     } else {

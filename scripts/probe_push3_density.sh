@@ -4,5 +4,5 @@
 # that is the window (ABL 4: no staging, no flush).
 cd $GRAFT_REPO_ROOT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I fusion-sim_amd/csrc -I include scripts/ablate_push3.hip -o /tmp/ablate_push3 || exit 1
-for PPC in 4 8 15 30; do /tmp/ablate_push3 256 $PPC 0 65536 short || exit 1; done
+for PPC in ${PPCS:-4 8 15 30}; do /tmp/ablate_push3 256 $PPC 0 65536 short || exit 1; done
 /tmp/ablate_push3 512 8 0 65536 short
