@@ -705,6 +705,7 @@ def main():
     ap.add_argument("--no-sink", action="store_true", help="development: no sink cells, hence no re-injected particles (ablation of the re-binning trigger)")
     ap.add_argument("--sort-interval", type=int, default=0, help="development: fixed re-binning period in frames (0 = the adaptive trigger)")
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
+    ap.add_argument("--no-c5", action="store_true", help="skip extensions.c5_one_gpu (BASELINE configs[4] at full size on one GPU: about a minute)")
     ap.add_argument("--no-strong-c4", action="store_true", help="development: skip the strong_c4 block (BASELINE configs[3] as one decomposed run over the ranks)")
     args = ap.parse_args()
 
@@ -1004,6 +1005,19 @@ def main():
         out["extensions"]["em"] = em_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, "fp64")
         out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(8, args.steps // 4), 1, stream=stream,
                                             cpu=not args.no_cpu_baseline)
+        if not args.no_c5:
+            # BASELINE configs[4] at its stated size — 512^3 Yee lattice, 2e9 electrons, fp64 — on this ONE GPU (233 of its 288 GB):
+            # the 8-GPU form of that configuration is a decomposition of exactly this.  A report, never a reason to lose
+            # the lines above: whatever goes wrong is recorded in its place.
+            try:
+                torch.cuda.empty_cache()
+                free = torch.cuda.mem_get_info(local_rank)[0]
+                if free < 250e9:
+                    raise RuntimeError("%.0f GB free on the device, 250 asked for" % (free / 1e9))
+                out["extensions"]["c5_one_gpu"] = em_line(local_rank, 2_000_000_000, 512, 2, 1, "fp64")
+            except Exception as e:
+                out["extensions"]["c5_one_gpu"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
     if not args.no_strong_c4:
         # north_star's scaling target lives on another workload than the parity-pinned headline: BASELINE configs[3]
         # (512^3 nodes, 2e9 particles, two species) as ONE decomposed run over the launcher's ranks — a fixed total, so
