@@ -251,7 +251,10 @@ int launch_push(fpic_handle* h, int nsub)
     t.id = h->id[h->cur];
     t.dst_slab = static_cast<T*>(h->slab[h->cur ^ 1]); t.dst_alive = h->alive[h->cur ^ 1]; t.dst_id = h->id[h->cur ^ 1];
     t.dst_tile_start = h->tile_start2[h->wl ^ 1]; t.dst_tile_cursor = h->tile_cursor;
+    t.chunk_census = h->chunk_census;
+    t.census_valid = scatter && h->chunk_census_fresh ? 1 : 0; // (the launch before was an in-place fused push over this very work list)
     h->sums_fresh = h->census_fresh = false;
+    h->chunk_census_fresh = false;
     h->scatter_pending = false;
     const unsigned grid = static_cast<unsigned>(h->work_cap);
     timing_begin(h, KC_PUSH);
@@ -294,6 +297,7 @@ int launch_push(fpic_handle* h, int nsub)
     if (fuse) {
         h->sums_fresh = sums;
         h->census_fresh = true;
+        h->chunk_census_fresh = !scatter; // (a re-binning launch writes none: its items are those of the list it leaves)
         if (scatter) { // this launch was the binning: the other set and the other tables are live now
             h->cur ^= 1;
             h->wl ^= 1;
@@ -571,7 +575,7 @@ void release(fpic_handle* h)
     }
     void* bufs[] = { h->E, h->B, h->sink, h->sink_alive, h->inv_cdf_xy, h->entropy, h->coef, h->cell_sums, h->moments,
                      h->norm, h->avg, h->stamp, h->shape_half, h->shape_tenth, h->tile_count, h->tile_start2[0],
-                     h->tile_start2[1], h->tile_cursor, h->coarse_cursor, h->nwork2[0], h->nwork2[1], h->work2[0], h->work2[1], h->spilled };
+                     h->tile_start2[1], h->tile_cursor, h->coarse_cursor, h->nwork2[0], h->nwork2[1], h->work2[0], h->work2[1], h->spilled, h->chunk_census };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->spilled_host) (void)hipHostFree(h->spilled_host);
     for (hipEvent_t e : h->spill_event) if (e) (void)hipEventDestroy(e);
@@ -900,6 +904,7 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->nwork2[1]), sizeof(uint32_t), acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work2[0]), sizeof(BlockWork) * h->work_cap, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->work2[1]), sizeof(BlockWork) * h->work_cap, acc)) ||
+        (rc = dev_alloc(h, reinterpret_cast<void**>(&h->chunk_census), sizeof(uint32_t) * kNbrSlots * h->work_cap, acc)) ||
         (rc = dev_alloc(h, reinterpret_cast<void**>(&h->spilled), sizeof(unsigned long long), acc)))
         return bail(rc);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->spilled_host), 2 * sizeof(unsigned long long))) != hipSuccess ||

@@ -76,6 +76,10 @@ struct fpic_handle {
     uint32_t* tile_cursor = nullptr;
     size_t two_level_min = size_t(1) << 20; // populations from this size on are binned in two levels (FPIC_TWO_LEVEL_MIN overrides: tests)
     uint32_t* coarse_cursor = nullptr; // two-level first binning: first chunk of each coarse bin (sort_chunks_kernel)
+    // per work item the neighbour-slot counts of the positions its particles were left at by the last IN-PLACE fused push:
+    // what the re-binning launch that follows (same work list, same slots) needs to reserve its ranges without counting
+    uint32_t* chunk_census = nullptr;
+    bool chunk_census_fresh = false;
     size_t work_cap = 0;
     bool binned = false;
     int deposits_since_bin = 0;

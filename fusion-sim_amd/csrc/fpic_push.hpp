@@ -87,6 +87,11 @@ struct TileArgs {
     uint32_t* dst_id;
     const uint32_t* dst_tile_start;
     uint32_t* dst_tile_cursor;
+    // kNbrSlots counts per work item: written by an in-place fused launch (the census of its new positions per neighbour
+    // tile), read by the re-binning launch that follows it when census_valid (then its count pass — one more read of x, y,
+    // z — is skipped: the electrostatic push has done so since round 3)
+    uint32_t* chunk_census;
+    int census_valid;
 };
 
 template <typename T>
@@ -556,6 +561,9 @@ __global__ __launch_bounds__(push_threads<CTR>()) void push_tiles_kernel(PushArg
         // LDS atomics in lane order), so cache lines are completed by a single L2 instead of
         // being written piecemeal by many workgroups on several XCDs.
         uint32_t own_count = 0;
+        if (t.census_valid) { // counted by the launch before, item for item
+            if (threadIdx.x < kNbrSlots) lrank[threadIdx.x] = t.chunk_census[static_cast<size_t>(blockIdx.x) * kNbrSlots + threadIdx.x];
+        } else
         for (size_t g = g_begin + threadIdx.x; g < g_end; g += kPushThreads) {
             const size_t base = g * PPT;
             const int cnt = (base + PPT <= a.n) ? PPT : static_cast<int>(a.n - base);
@@ -670,6 +678,9 @@ __global__ __launch_bounds__(push_threads<CTR>()) void push_tiles_kernel(PushArg
             const uint32_t c = lcensus[threadIdx.x];
             const uint32_t bin = nb.bin_of_slot(threadIdx.x);
             if (c && bin != ~0u) atomicAdd(t.tile_count + bin, c);
+            if constexpr (!SCATTER) {
+                if (t.chunk_census) t.chunk_census[static_cast<size_t>(blockIdx.x) * kNbrSlots + threadIdx.x] = c;
+            }
         }
         if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));
     }
