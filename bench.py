@@ -571,7 +571,7 @@ def box_workload(args, rank, world, local_rank, dist, steps=None, warmup=None, c
     elapsed = time.perf_counter() - t0
     st, dom = sim.stats(), sim.domainStats()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=getattr(args, "reduce_device", "cuda"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sim.destroy()
@@ -707,6 +707,11 @@ def main():
     ap.add_argument("--no-extensions", action="store_true", help="skip the extension measurements at N=1 (counter RNG, dense solver)")
     ap.add_argument("--no-c5", action="store_true", help="skip extensions.c5_one_gpu (BASELINE configs[4] at full size on one GPU: about a minute)")
     ap.add_argument("--no-strong-c4", action="store_true", help="development: skip the strong_c4 block (BASELINE configs[3] as one decomposed run over the ranks)")
+    ap.add_argument("--bootstrap", choices=["nccl", "gloo"], default="nccl",
+                    help="the launcher-side process group that hands the library's unique id round and takes the maximum of the ranks' clocks. "
+                         "nccl (= RCCL, the default: one GPU per rank).  gloo is for REHEARSAL ONLY: every rank runs on the visible device "
+                         "LOCAL_RANK %% device_count, so that N processes can share one GPU with a stand-in bound through FPIC_RCCL_LIBRARY "
+                         "(tests/fake_rccl/fake_rccl_shm.cpp) and run the exact process topology of the N-GPU launch; its line says so and is no measurement")
     args = ap.parse_args()
 
     import torch
@@ -722,8 +727,14 @@ def main():
         if distributed or args.gpus != 1:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, world, args.gpus))
+    rehearsal = args.bootstrap == "gloo"
+    if rehearsal:  # (device_count() does not initialise the GPU; the launcher started this process before any GPU call)
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if distributed:
+    if distributed and rehearsal:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+    elif distributed:
         import torch.distributed as dist
         # the exchange overlaps the next frame's push (ShardedPusher): give RCCL's stream priority so its
         # few workgroups are placed as soon as a push workgroup retires
@@ -733,10 +744,19 @@ def main():
         except (AttributeError, TypeError):
             pass
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+    # the launcher-side reductions (a flag, a clock): device tensors over RCCL, host tensors over gloo
+    args.reduce_device = "cpu" if rehearsal else "cuda"
+    rehearsal_note = None
+    if rehearsal:
+        rehearsal_note = ("REHEARSAL, not a measurement: --bootstrap gloo, %d processes on visible device(s) %s, the library's communicator bound to "
+                          "FPIC_RCCL_LIBRARY=%s" % (world, "0..%d" % (torch.cuda.device_count() - 1) if torch.cuda.device_count() > 1 else "0",
+                                                    os.environ.get("FPIC_RCCL_LIBRARY", "(unset: the real RCCL)")))
 
     if args.workload == "box":
         line = box_workload(args, rank, world, local_rank, dist if distributed else None, cpu=not args.no_cpu_baseline)
         if rank == 0:
+            if rehearsal_note:
+                line["rehearsal"] = rehearsal_note
             print(json.dumps(line), flush=True)
         if distributed:
             dist.destroy_process_group()
@@ -818,7 +838,7 @@ def main():
                 comm_note = str(e)
         else:
             comm_note = box[0]
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=args.reduce_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             # NEVER silently: a value measured over torch.distributed is not the product's transport.  With more than
@@ -880,7 +900,7 @@ def main():
     sim.profile(False)
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -935,6 +955,8 @@ def main():
         out["roofline"]["cycle_frac_of_hbm_read_roofline"] = out["value"] / world * 24.0 / (HBM_PEAK_GBS * 1e9)
         if comm_fallback:
             out["comm_fallback"] = comm_fallback
+        if rehearsal_note:
+            out["rehearsal"] = rehearsal_note
         tr = measured_traffic({"particles_per_gpu": n_local, "grid": [spec["nr"], spec["nz"]], "rng": args.rng, "dtype": "f32"})
         if tr is None:
             out["roofline"]["traffic_source"] = "no committed PMC pass for this configuration (profiles/r*_traffic.json)"
@@ -1029,15 +1051,17 @@ def main():
         # prints the line with the block marked as failed, every rank leaves.  
         import threading
         limit = float(os.environ.get("FPIC_BENCH_C4_LIMIT_S", "420"))
+        headline = json.dumps(out) if rank == 0 else None   # (the timer's thread prints a snapshot, not the dictionary the main thread holds)
 
         def give_up():
             if rank == 0:
-                out["strong_c4"] = {"value": None, "error": "the strong_c4 block did not finish within %.0f s on rank 0 (a rank failed or an exchange "
-                                                            "never completed); the headline above was measured before it" % limit}
-                print(json.dumps(out), flush=True)
+                line = json.loads(headline)
+                line["strong_c4"] = {"value": None, "error": "the strong_c4 block did not finish within %.0f s on rank 0 (a rank failed or an exchange "
+                                                             "never completed); the headline above was measured before it" % limit}
+                print(json.dumps(line), flush=True)
             sys.stderr.write("bench.py: rank %d gives up on the strong_c4 block after %.0f s\n" % (rank, limit))
             sys.stderr.flush()
-            os._exit(0 if rank == 0 else 5)
+            os._exit(5)  # every rank, rank 0 included: a block that hung is a failed run, as on the exception path below (the line is on stdout)
 
         watchdog = threading.Timer(limit, give_up)
         watchdog.daemon = True

@@ -137,6 +137,11 @@ struct Domain {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_boundary = nullptr, ev_ghost = nullptr;
     bool overlap = true;                // FPIC_DOMAIN_OVERLAP=0: everything on the handle's stream, one launch per species
+    bool em_chain = true, em_chain_agreed = false; // FPIC_EM_CHAIN=0 (read by fpic_domain_init, agreed by the ranks before the first full-EM sub-step)
+    // TEST SWITCH (FPIC_TEST_FAULT, read by fpic_domain_init; tests/test_gpu_fake_rccl.py's negative controls): bit 0 drops the
+    // wait of the communicator's stream for the handle's stream (comm_fork), bit 1 the wait of the handle's stream for the
+    // exchange (comm_join) — the two dependencies a stream-ordered transport must show as wrong bits when they are missing
+    int test_fault = 0;
     uint64_t migrated = 0, lost = 0, deferred = 0; // deferred: leavers that did not fit a message and left with a later one
     // slab-decomposed Poisson solve (distributed = true): 2-D transforms of the owned planes, transpose over the ranks,
     // transforms along z of the rank's share of the ky rows, and back; otherwise every rank transforms the whole grid
@@ -944,6 +949,22 @@ struct EmCoef {
     }
 };
 
+// the two half-time arrays of the chained lattice step: both or none (a launch must never see one of them null)
+template <typename T>
+int alloc_half_time(fpic_handle* h, size_t nodes)
+{
+    State* st = h->es;
+    for (int k = 0; k < 2; ++k) {
+        if (st->Bh[k]) continue;
+        if (int rc = dev_alloc(h, &st->Bh[k], nodes * 4 * sizeof(T), &h->bytes_grid)) {
+            for (int j = 0; j < 2; ++j)
+                if (st->Bh[j]) { (void)hipFree(st->Bh[j]); st->Bh[j] = nullptr; h->bytes_grid -= nodes * 4 * sizeof(T); }
+            return rc;
+        }
+    }
+    return FPIC_OK;
+}
+
 template <typename T>
 int em_half_b(fpic_handle* h, const EmCoef<T>& c, int k0, int nk, const void* from = nullptr, void* to = nullptr)
 {
@@ -1053,10 +1074,8 @@ int em_substep(fpic_handle* h)
     const EmCoef<T> co(h);
     if (!chain && st->em_open)      // (the switch was turned off between two sub-steps)
         if (int rc = em_close<T>(h)) return rc;
-    if (chain && !st->Bh[0]) {
-        int rc;
-        if ((rc = dev_alloc(h, &st->Bh[0], st->nodes * 4 * sizeof(T), &h->bytes_grid)) || (rc = dev_alloc(h, &st->Bh[1], st->nodes * 4 * sizeof(T), &h->bytes_grid))) return rc;
-    }
+    if (chain && (!st->Bh[0] || !st->Bh[1]))
+        if (int rc = alloc_half_time<T>(h, st->nodes)) return rc;
     if (chain && st->em_open) {
         timing_begin(h, KC_SOLVE);
         if (std::strcmp(chain_env, "flat") == 0) {
@@ -2093,7 +2112,7 @@ int comm_fork(Ranks& rk)
     Domain& d = *h->es->dom;
     if (!d.comm_stream) return FPIC_OK;
     HIP_TRY(h, hipEventRecord(d.ev_boundary, h->stream));
-    HIP_TRY(h, hipStreamWaitEvent(d.comm_stream, d.ev_boundary, 0));
+    if (!(d.test_fault & 1)) HIP_TRY(h, hipStreamWaitEvent(d.comm_stream, d.ev_boundary, 0));
     return FPIC_OK;
 }
 int comm_join(Ranks& rk)
@@ -2103,7 +2122,7 @@ int comm_join(Ranks& rk)
     Domain& d = *h->es->dom;
     if (!d.comm_stream) return FPIC_OK;
     HIP_TRY(h, hipEventRecord(d.ev_ghost, d.comm_stream));
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, d.ev_ghost, 0));
+    if (!(d.test_fault & 2)) HIP_TRY(h, hipStreamWaitEvent(h->stream, d.ev_ghost, 0));
     return FPIC_OK;
 }
 
@@ -2629,8 +2648,19 @@ int dom_em_substep(Ranks& rk)
     // (half the lattice halo bytes).  B of the integer time is formed when somebody reads or replaces it (em_close), plane
     // for plane on whatever the rank holds — no exchange, so one rank may close and reopen without the others.
     // FPIC_EM_CHAIN=0 keeps the four sweeps and both halo copies.
-    const char* chain_env = std::getenv("FPIC_EM_CHAIN");
-    const bool chain = multi && em_deep_halo(s0) && !(chain_env && std::strcmp(chain_env, "0") == 0);
+    // The switch is read ONCE, by fpic_domain_init, and agreed by the ranks before the first sub-step: it changes the exchange
+    // sequence (a chained rank skips X_EM_B and sends the deeper E halo), so ranks that disagreed would wait for ever.
+    if (multi && !s0->dom->em_chain_agreed) {
+        std::vector<unsigned> off(rk.hs.size());
+        for (size_t r = 0; r < rk.hs.size(); ++r) off[r] = rk.hs[r]->es->dom->em_chain ? 0u : 1u;
+        unsigned any_off = 0;
+        if (int e = agree_max(rk, off[0], off, any_off)) return e;
+        for (fpic_handle* h : rk.hs) {
+            if (any_off) h->es->dom->em_chain = false;   // one rank without it: nobody chains
+            h->es->dom->em_chain_agreed = true;
+        }
+    }
+    const bool chain = multi && em_deep_halo(s0) && s0->dom->em_chain;
     for (fpic_handle* h : rk.hs) {
         State* st = h->es;
         const Domain& d = *st->dom;
@@ -2638,10 +2668,8 @@ int dom_em_substep(Ranks& rk)
         HIP_TRY(h, hipMemsetAsync(st->spilled, 0, sizeof(unsigned long long), h->stream));
         if (!chain && st->em_open)      // (the switch was turned off between two sub-steps)
             if (int e = em_close<T>(h)) return e;
-        if (chain && !st->Bh[0]) {
-            int e;
-            if ((e = dev_alloc(h, &st->Bh[0], held_nodes(st) * 4 * sizeof(T), &h->bytes_grid)) || (e = dev_alloc(h, &st->Bh[1], held_nodes(st) * 4 * sizeof(T), &h->bytes_grid))) return e;
-        }
+        if (chain && (!st->Bh[0] || !st->Bh[1]))
+            if (int e = alloc_half_time<T>(h, held_nodes(st))) return e;
         // node-centred fields where this rank's particles can be: cells [z0 - G, z0 + nzl + G) -> nodes one further up
         if (chain && st->em_open) {
             timing_begin(h, KC_SOLVE);
@@ -2912,6 +2940,7 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     if (world == 2 && 2 * ghost_planes + 1 > nzl)
         return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- with two slabs of %d planes at most %d ghost planes", nzl, (nzl - 1) / 2);
     if (migrate_every < 1) return fail(h, FPIC_ERR_INVALID_ARG, ".migrate_every <- must be at least 1");
+    if (distributed_solve < 0 || distributed_solve > 2) return fail(h, FPIC_ERR_INVALID_ARG, ".distributed_solve <- %d is none of 0 (replicated), 1 (transposed spectrum), 2 (interface solve along z)", distributed_solve);
     if (st->solver == FPIC_SOLVER_YEE && world > 1 && 2 * (ghost_planes + 2) > nzl)
         return fail(h, FPIC_ERR_INVALID_ARG, ".ghost_planes <- the full-EM mode keeps ghost_planes + 2 halo planes per side: a slab of %d planes holds at most %d ghost planes",
                     nzl, nzl / 2 - 2);
@@ -2940,6 +2969,8 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     }
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&d->counts_host), kMigWords * sizeof(unsigned)));
     if (const char* v = std::getenv("FPIC_DOMAIN_OVERLAP")) d->overlap = std::strcmp(v, "0") != 0;
+    if (const char* v = std::getenv("FPIC_EM_CHAIN")) d->em_chain = std::strcmp(v, "0") != 0;
+    if (const char* v = std::getenv("FPIC_TEST_FAULT")) d->test_fault = std::atoi(v);
     if (world > 1 && d->overlap) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -2952,6 +2983,8 @@ int domain_init(fpic_handle* h, int rank, int world, int ghost_planes, int migra
     // the full-EM mode solves once, for the initial field: with the library's own transforms (whose decomposed solve is the
     // one handle's, bit for bit) its ranks can take the decomposed solve too, and then never hold the whole grid
     const bool yee_decomposed = st->solver == FPIC_SOLVER_YEE && st->own_fft && st->ny % world == 0;
+    if (distributed_solve == 2 && world > 1 && st->solver == FPIC_SOLVER_YEE && !yee_decomposed)
+        return fail(h, FPIC_ERR_INVALID_ARG, ".distributed_solve <- 2 on a full-EM handle needs a power-of-two grid whose %d rows along y divide into %d shares", st->ny, world);
     if (distributed_solve && world > 1 && (st->solver == FPIC_SOLVER_POISSON_FFT || yee_decomposed)) {
         d->phi_below = st->solver == FPIC_SOLVER_YEE ? d->H : ghost_planes + 1;
         d->phi_above = d->phi_below + 1;

@@ -360,7 +360,7 @@ int launch_bin(fpic_handle* h)
     HIP_TRY(h, hipGetLastError());
     if (!two_level) h->cur ^= 1;
     h->wl = nw;
-    h->census_fresh = false; // tile_count now describes this binning, not a fused push
+    h->census_fresh = h->chunk_census_fresh = false; // tile_count now describes this binning, not a fused push
     h->scatter_pending = false;
     h->binned = true;
     h->deposits_since_bin = 0;
@@ -951,7 +951,7 @@ int fpic_set_particles(fpic_handle* h, const void* pos_aos, const void* vel_aos,
     }
     if (pos_aos) { // positions changed under the bins
         h->binned = false;
-        h->census_fresh = h->scatter_pending = false;
+        h->census_fresh = h->chunk_census_fresh = h->scatter_pending = false;
     }
     if (pos_aos || vel_aos) h->sums_fresh = false;
     return rc;
@@ -1298,7 +1298,7 @@ int fpic_load_checkpoint(fpic_handle* h, const char* path)
     // from here on the particle arrays are overwritten in the caller's order: whatever the bins, the
     // census and the fused sums said about the old order is void, also if a read fails half-way
     h->binned = false;
-    h->sums_fresh = h->census_fresh = h->scatter_pending = false;
+    h->sums_fresh = h->census_fresh = h->chunk_census_fresh = h->scatter_pending = false;
     h->spill_pending[0] = h->spill_pending[1] = false;
     h->last_spill = 0;
     iota_kernel<<<blocks_for(h->n), 256, 0, h->stream>>>(h->id[h->cur], h->n);

@@ -18,111 +18,55 @@ pytestmark = pytest.mark.gpu
 
 DRIVER = r'''
 import json, os, sys, threading
-import numpy as np
 sys.path.insert(0, os.path.join(sys.argv[1], "fusion-sim_amd"))
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 import fusionpic as fp
-case = json.loads(sys.argv[2])
-world, shape, G, every = case["world"], tuple(case["shape"]), case["ghost"], case["every"]
-em, dist_solve, precision = case["em"], case["distributed_solve"], case["precision"]
-rng = np.random.default_rng(case["seed"])
-n = case["n"]
-L = tuple(1e-3 * s for s in shape)
-C = 2.998e8
-if em:
-    d = [L[a] / shape[a] for a in range(3)]
-    dt = 0.5 / (C * np.sqrt(sum(1 / x ** 2 for x in d)))
-else:
-    dt = 5e-12
-spec = dict(radius=L[0], length_y=L[1], height=L[2], nr=shape[0], ny=shape[1], nz=shape[2], dt=dt, nparticles=0, count=n,
-            particle_mass=9.109e-31, particle_charge=-1.602e-19, geometry="cart3d", solver="yee" if em else "poisson_fft",
-            macro_weight=(1e9 if case.get("emptying") else 1e15) * np.prod(L) / n)   # (a beam that must not blow itself beyond the ghost planes)
-nzl = shape[2] // world
-pos = rng.random((n, 3)) * L
-vz = 0.7 * G * 1e-3 / (every * dt * C)
-vel = np.stack([rng.normal(0, 0.05, n), rng.normal(0, 0.05, n), rng.uniform(-min(vz, 0.9), min(vz, 0.9), n)], axis=1)
-if case.get("emptying"):  # everything starts in slab 0 and streams upwards: rank 0 empties, the others fill
-    pos[:, 2] = (0.1 + 0.8 * rng.random(n)) * L[2] / world
-    vel[:, 2] = min(vz, 0.9)
-owner = np.floor(pos[:, 2] / L[2] * shape[2]).astype(int) // nzl
-order = np.argsort(owner, kind="stable")
-pos, vel, counts = pos[order], vel[order], np.bincount(owner, minlength=world)
-E, B = rng.normal(0, 1e4, shape + (3,)), rng.normal(0, 0.05, shape + (3,))
-
-one = fp.makeCylindricalParticlePusher(spec, precision=precision)
-one.set(position=pos, velocity=vel)
-em_from_precalc = em and case.get("precalc")
-if em and not em_from_precalc:
-    one.set(edge_E=E, face_B=B)
-else:
-    if em:
-        one.addB(0.0, 0.0, 0.01)
-    one.precalc()
-frames = case.get("frames", 4)
-for _ in range(frames):
-    one.step()
-ref = one.getParticles()
-# (the library's own transforms on power-of-two grids: the decomposed solve is the one handle's, bit for bit)
-own_fft = all(s_ & (s_ - 1) == 0 and s_ >= 8 for s_ in shape)
-fields = [fp.F3_J_FIXED, fp.F3_EDGE_E, fp.F3_FACE_B] if em else [fp.F3_RHO_FIXED] + ([] if (dist_solve and not own_fft) or dist_solve == 2 else [fp.F3_E])
-ref_f = {w: one.readField(w).reshape(shape[2], -1) for w in fields}
-
+import decomp_scene as ds
+sc = ds.build(fp, json.loads(sys.argv[2]))
+world = sc["world"]
+ref, ref_f = ds.run_one(fp, sc)
 uid = fp.commUniqueId()
 out, err = [None] * world, [None] * world
 def rank_main(r):
     try:
-        s = fp.makeCylindricalParticlePusher(dict(spec, count=3 * n), precision=precision)
-        s.commInit(uid, r, world)
-        s.domainInit(r, world, ghost_planes=G, migrate_every=every, distributed_solve=dist_solve)
-        first = int(counts[:r].sum())
-        s.domainSet(pos[first:first + counts[r]], vel[first:first + counts[r]], first_id=first)
-        if em and not em_from_precalc:
-            s.set(edge_E=E, face_B=B)
-        else:
-            if em:
-                s.addB(0.0, 0.0, 0.01)
-            s.precalc()
-        for _ in range(frames):
-            s.step()
-        got = s.domainGet()
-        out[r] = (got, {w: s.readField(w).reshape(shape[2], -1)[r * nzl:(r + 1) * nzl].copy() for w in fields}, s.domainStats(), len(got["ids"]))
-        s.destroy()
-    except Exception as e:  # a failed rank leaves the others waiting: the test's timeout ends them
+        out[r] = ds.run_rank(fp, sc, r, uid)
+    except Exception as e:  # a failed rank leaves the others waiting: the stand-in's patience ends them
         err[r] = repr(e)
 threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
 for t in threads: t.start()
 for t in threads: t.join()
 if any(err):
     print(json.dumps({"error": err})); sys.exit(0)
-ids = np.concatenate([o[0]["ids"] for o in out])
-idx = np.argsort(ids)
-same = lambda a, b: a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
-res = {"ids_ok": bool(np.array_equal(ids[idx], np.arange(n))),
-       "pos_same": bool(same(np.concatenate([o[0]["position"] for o in out])[idx], ref["position"])),
-       "vel_same": bool(same(np.concatenate([o[0]["velocity"] for o in out])[idx], ref["velocity"])),
-       "migrated": int(sum(o[2]["migrated"] for o in out)), "lost": int(sum(o[2]["lost"] for o in out)), "fields": {},
-       "held": [o[3] for o in out]}
-d = np.abs(np.concatenate([o[0]["position"] for o in out])[idx].astype(np.float64) - ref["position"].astype(np.float64)); d = np.minimum(d, 1 - d)
-res["pos_err"] = float(d.max())
-for w in fields:
-    res["fields"][str(w)] = all(bool(same(out[r][1][w], ref_f[w][r * nzl:(r + 1) * nzl])) for r in range(world))
-# the integer charge grid of all ranks' own planes: its total is exact whatever the solve's summation order did to the particles
-own = np.concatenate([out[r][1][fields[0]] for r in range(world)]).astype(np.int64)
-res["charge_total_same"] = bool(int(own.sum()) == int(ref_f[fields[0]].astype(np.int64).sum())) if fields[0] == fp.F3_RHO_FIXED else True
-res["charge_max_rel_diff"] = float(np.abs(own - ref_f[fields[0]].astype(np.int64)).max() / max(1, np.abs(ref_f[fields[0]].astype(np.int64)).max())) if fields[0] == fp.F3_RHO_FIXED else 0.0
-print(json.dumps(res))
+print(json.dumps(ds.compare(fp, sc, ref, ref_f, out)))
 '''
 
-
-def build_fake(tmp_path):
-    so = tmp_path / "libfakerccl.so"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                           os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp"), "-o", str(so), "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"])
-    return so
+_built = {}
 
 
-def run_case(tmp_path, **case):
-    so = build_fake(tmp_path)
-    env = dict(os.environ, FPIC_RCCL_LIBRARY=str(so))
+def fake_lib(kind="threads"):
+    """the stand-ins are HIP sources (a delay kernel, a reduction): built once per session by their Makefile (build() of
+    __graft_entry__ has usually done it already and the .so travelled with the tree)"""
+    if not _built:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "fake_rccl")])
+        _built["threads"] = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+        _built["procs"] = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl_shm.so")
+    return _built[kind]
+
+
+def build_fake(tmp_path=None):
+    return fake_lib("threads")
+
+
+# how the stand-in completes an operation (tests/fake_rccl/fake_rccl.cpp): stream-ordered like the real library (the
+# default), the same with 1.5 ms spinning kernels in front of every arrival and behind every operation, or rounds 2-4's
+# synchronous form
+TRANSPORTS = {"stream": {}, "delayed": {"FAKE_RCCL_DELAY_US": "1500"}, "sync": {"FAKE_RCCL_MODE": "sync"}}
+
+
+def run_case(tmp_path, transport="stream", fault=0, **case):
+    env = dict(os.environ, FPIC_RCCL_LIBRARY=fake_lib("threads"), **TRANSPORTS[transport])
+    if fault:
+        env["FPIC_TEST_FAULT"] = str(fault)
     raw = subprocess.check_output([sys.executable, "-c", DRIVER, ROOT, json.dumps(case)], env=env, timeout=300)
     res = json.loads(raw.decode().strip().splitlines()[-1])
     assert "error" not in res, res
@@ -190,6 +134,53 @@ def test_rccl_transport_with_a_rank_that_empties(tmp_path, em):
     assert res["ids_ok"] and res["pos_same"] and res["vel_same"] and all(res["fields"].values()), res
 
 
+# ---- the transport under real concurrency (round 5).  The cases above run over the STREAM-ORDERED stand-in: a call only
+# enqueues, and nothing but the caller's own events orders its streams.  The same scenes with spinning kernels in front of
+# every arrival and behind every operation (every window a missing dependency leaves is 1.5 ms wide), and — the negative
+# controls — with one of the library's two cross-stream waits REMOVED (FPIC_TEST_FAULT): the run must then differ from one
+# handle's, or the cases above prove nothing about those waits.  Scenes with >= 24 planes per slab take the two-part push
+# (part 1 -> ghost exchange on the communicator's stream beside the interior push -> join), the decomposed solves the
+# potential's planes beside the inner gradient.
+SPLIT_SCENES = {
+    "electrostatic, replicated solve": dict(world=2, shape=(20, 24, 64), ghost=3, every=4, em=False, distributed_solve=False, precision="fp32", n=20000, seed=2),
+    "electrostatic, transposed spectrum": dict(world=2, shape=(32, 16, 64), ghost=3, every=2, em=False, distributed_solve=True, precision="fp32", n=20000, seed=7),
+    "electrostatic, interface solve, 4 ranks": dict(world=4, shape=(16, 32, 128), ghost=2, every=2, em=False, distributed_solve=2, precision="fp32", n=20000, seed=7),
+    "full EM": dict(world=2, shape=(12, 16, 64), ghost=3, every=4, em=True, distributed_solve=False, precision="fp64", n=15000, seed=11),
+    "full EM from a decomposed precalc": dict(world=2, shape=(16, 16, 64), ghost=2, every=4, em=True, distributed_solve=True, precalc=True, precision="fp32", n=15000, seed=13),
+}
+
+
+def identical(res, scene):
+    if scene["distributed_solve"] == 2:   # (another arithmetic in the solve: agreement to its rounding, the integer charge exact in total)
+        return res["ids_ok"] and res["pos_err"] <= 1e-4 and res["charge_total_same"] and res["charge_max_rel_diff"] <= 1e-3
+    return res["ids_ok"] and res["pos_same"] and res["vel_same"] and all(res["fields"].values())
+
+
+@pytest.mark.parametrize("name", sorted(SPLIT_SCENES))
+def test_rccl_transport_with_late_arrivals_and_late_producers(tmp_path, name):
+    res = run_case(tmp_path, transport="delayed", **SPLIT_SCENES[name])
+    assert identical(res, SPLIT_SCENES[name]), res
+    assert res["migrated"] > 0 and res["lost"] == 0
+
+
+@pytest.mark.parametrize("name", ["electrostatic, replicated solve", "full EM"])
+def test_rccl_transport_synchronous_stand_in_still_agrees(tmp_path, name):
+    res = run_case(tmp_path, transport="sync", **SPLIT_SCENES[name])
+    assert identical(res, SPLIT_SCENES[name]), res
+
+
+@pytest.mark.parametrize("fault", [1, 2])
+@pytest.mark.parametrize("name", ["electrostatic, replicated solve", "electrostatic, transposed spectrum", "full EM"])
+def test_a_missing_stream_dependency_shows_as_wrong_bits(tmp_path, name, fault):
+    """NEGATIVE CONTROL.  fault 1: the communicator's stream does not wait for the part-1 push (comm_fork's wait removed) —
+    the ghost planes leave before they are complete; fault 2: the handle's stream does not wait for the exchange (comm_join's
+    wait removed) — the received planes are added before they have arrived.  Under the stream-ordered stand-in with delays
+    both MUST change the result; under the synchronous stand-in of rounds 2-4 neither could."""
+    scene = SPLIT_SCENES[name]
+    res = run_case(tmp_path, transport="delayed", fault=fault, **scene)
+    assert not identical(res, scene), ("the stand-in did not notice the missing wait", fault, res)
+
+
 MISUSE_DRIVER = r'''
 import ctypes, json, sys, threading
 hip = ctypes.CDLL("libamdhip64.so")
@@ -250,12 +241,13 @@ print(json.dumps(rcs))
 
 @pytest.mark.parametrize("what", ["ok", "size_mismatch", "send_without_receive", "receive_without_send", "self_peer", "allgather_overlap", "allreduce_unsupported",
                                   "unbalanced_group", "join_twice"])
-def test_the_stand_in_rejects_what_the_real_library_would_not_survive(tmp_path, what):
+@pytest.mark.parametrize("mode", ["stream", "sync"])
+def test_the_stand_in_rejects_what_the_real_library_would_not_survive(tmp_path, what, mode):
     """The stand-in is only worth something if a misuse of RCCL's rules FAILS under it (DESIGN.md section 6 lists the rules
     the transport relies on): each misuse returns an error on at least one rank, leaves the world broken for every rank's
     next call, and never hangs; the correct sequences return ncclSuccess."""
     so = build_fake(tmp_path)
-    raw = subprocess.check_output([sys.executable, "-c", MISUSE_DRIVER, str(so), what], timeout=120)
+    raw = subprocess.check_output([sys.executable, "-c", MISUSE_DRIVER, str(so), what], timeout=120, env=dict(os.environ, FAKE_RCCL_MODE=mode))
     rcs = json.loads(raw.decode().strip().splitlines()[-1])
     if what == "ok":
         assert all(rc == 0 for r in rcs for rc in r), rcs
@@ -314,15 +306,14 @@ print(json.dumps(res))
 '''
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-@pytest.mark.parametrize("world", [2, 3])
-def test_rccl_transport_parity_mode_all_reduce(tmp_path, world, overlap):
+@pytest.mark.parametrize("world,overlap,transport", [(2, True, "stream"), (3, True, "stream"), (2, False, "stream"), (3, False, "sync"), (2, True, "delayed"), (3, True, "delayed")])
+def test_rccl_transport_parity_mode_all_reduce(tmp_path, world, overlap, transport):
     """(r,z) reference-parity mode, SURVEY 8(e) row 1, with the library's communicator and `world` ranks as threads: every
     rank ends up with the density of the WHOLE population (one ncclAllReduce of the per-cell sums per frame, on the side
     stream when overlapping), equal on all ranks bit for bit and equal to one handle's up to the summation order; the
     particles are those of one handle."""
     so = build_fake(tmp_path)
-    env = dict(os.environ, FPIC_RCCL_LIBRARY=str(so))
+    env = dict(os.environ, FPIC_RCCL_LIBRARY=str(so), **TRANSPORTS[transport])
     raw = subprocess.check_output([sys.executable, "-c", RZ_DRIVER, ROOT, str(world), "1" if overlap else "0"], env=env, timeout=300)
     res = json.loads(raw.decode().strip().splitlines()[-1])
     assert "error" not in res, res
