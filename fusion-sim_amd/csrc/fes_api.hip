@@ -496,7 +496,7 @@ int launch_bin_two_level_census(fpic_handle* h, Species& s)
         kern<<<nc + ncoarse, fpic::kSortThreads, lds, h->stream>>>(columns(s.cur ^ 1), s.n, key, st->ntiles, div, ncoarse, s.tile_start2[nw], s.tile_cursor, aux);
         return FPIC_OK;
     };
-    if (int rc = em ? run(BoxTileKey<T, kEL, kEL, kEL>{ st->nx, st->ny, st->nz, st->ntx, st->nty }) : run(BoxTileKey<T>{ st->nx, st->ny, st->nz, st->ntx, st->nty }))
+    if (int rc = em ? run(BoxTileKey<T, EmWin<T>::LX, EmWin<T>::LY, EmWin<T>::LZ>{ st->nx, st->ny, st->nz, st->ntx, st->nty }) : run(BoxTileKey<T>{ st->nx, st->ny, st->nz, st->ntx, st->nty }))
         return rc;
     HIP_TRY(h, hipGetLastError());
     s.wl = nw;                // (two passes: the compact sorted array is back in the set it started in)
@@ -522,9 +522,9 @@ int launch_bin(fpic_handle* h, Species& s)
     const bool em = st->ltx == kEL;
     const bool many_tiles = st->ntiles > static_cast<uint32_t>(kMaxTiles3); // no LDS histogram of that size
     if (many_tiles && !std::getenv("FPIC_CENSUS_GLOBAL")) return launch_bin_two_level_census<T>(h, s);
-    if (many_tiles && em) bin3_count_global_kernel<T, kEL, kEL, kEL><<<blocks_for(s.n), 256, 0, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, s.tile_count);
+    if (many_tiles && em) bin3_count_global_kernel<T, EmWin<T>::LX, EmWin<T>::LY, EmWin<T>::LZ><<<blocks_for(s.n), 256, 0, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, s.tile_count);
     else if (many_tiles) bin3_count_global_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, s.tile_count);
-    else if (em) bin3_count_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
+    else if (em) bin3_count_kernel<T, EmWin<T>::LX, EmWin<T>::LY, EmWin<T>::LZ><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
     else bin3_count_kernel<T><<<nb, 256, shmem, h->stream>>>(src, s.n_pad, s.n, st->nx, st->ny, st->nz, st->ntx, st->nty, st->ntiles, s.tile_count);
     bin_scan_kernel<<<1, 1024, 0, h->stream>>>(s.tile_count, st->ntiles, s.tile_start2[nw], s.tile_cursor, s.work2[nw], s.nwork2[nw], static_cast<uint32_t>(kChunk3));
     // large populations: scatter staged through LDS (fpic_kernels.hpp, sort_scatter_kernel), in two levels when there
@@ -560,11 +560,11 @@ int launch_bin(fpic_handle* h, Species& s)
             }
             return FPIC_OK;
         };
-        if (int rc = em ? run(BoxTileKey<T, kEL, kEL, kEL>{ st->nx, st->ny, st->nz, st->ntx, st->nty })
+        if (int rc = em ? run(BoxTileKey<T, EmWin<T>::LX, EmWin<T>::LY, EmWin<T>::LZ>{ st->nx, st->ny, st->nz, st->ntx, st->nty })
                         : run(BoxTileKey<T>{ st->nx, st->ny, st->nz, st->ntx, st->nty }))
             return rc;
     } else if (em) {
-        bin3_scatter_kernel<T, kEL, kEL, kEL><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
+        bin3_scatter_kernel<T, EmWin<T>::LX, EmWin<T>::LY, EmWin<T>::LZ><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx,
                                                                         st->nty, st->ntiles, s.tile_start2[nw], s.tile_cursor);
     } else {
         bin3_scatter_kernel<T><<<nb, 256, shmem, h->stream>>>(src, dst, s.n_pad, s.id[s.cur], s.id[s.cur ^ 1], s.n, st->nx, st->ny, st->nz, st->ntx, st->nty,
@@ -922,7 +922,9 @@ int em_push_all(fpic_handle* h, int part = 0)
                 store_args_kernel<EmPushArgs<T>><<<1, 1, 0, h->stream>>>(a, static_cast<EmPushArgs<T>*>(s.em_args));
             }
             t.resident = static_cast<const EmPushArgs<T>*>(s.em_args);
-            em_push_tiles_kernel<T><<<static_cast<unsigned>(s.work_cap), em_threads<T>(), em_lds_bytes<T>(), h->stream>>>(t);
+            // (FES_EM_PIPE: a persistent workgroup per CU walks the list with two windows; otherwise one workgroup per item)
+            const unsigned grid = FES_EM_PIPE ? static_cast<unsigned>(std::min<size_t>(s.work_cap, static_cast<size_t>(h->cus))) : static_cast<unsigned>(s.work_cap);
+            em_push_tiles_kernel<T><<<grid, em_threads<T>(), em_lds_bytes<T>(), h->stream>>>(t);
         } else if (part != 2) { // (an unbinned species is pushed whole with the first part)
             em_push_kernel<T><<<blocks_for(s.n), 256, 0, h->stream>>>(a);
         }
@@ -1299,8 +1301,8 @@ int create_state(fpic_handle* h)
         (e = set_lds(push3_tiles_kernel<T, true, false, true>, push3_lds_bytes<T>())) != hipSuccess ||
         (e = set_lds(bin3_count_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
         (e = set_lds(bin3_scatter_kernel<T>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
-        (e = set_lds(bin3_count_kernel<T, kEL, kEL, kEL>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
-        (e = set_lds(bin3_scatter_kernel<T, kEL, kEL, kEL>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
+        (e = set_lds(bin3_count_kernel<T, EmWin<T>::LX, EmWin<T>::LY, EmWin<T>::LZ>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
+        (e = set_lds(bin3_scatter_kernel<T, EmWin<T>::LX, EmWin<T>::LY, EmWin<T>::LZ>, static_cast<size_t>(kMaxTiles3) * 4)) != hipSuccess ||
         (e = set_lds(em_push_tiles_kernel<T>, em_lds_bytes<T>())) != hipSuccess)
         return fail(h, FPIC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
 
@@ -1400,7 +1402,10 @@ int create(fpic_handle* h)
     st->nodes = static_cast<size_t>(st->nx) * st->ny * st->nz;
     st->zs0 = 0; st->nzs = st->nz; // (a rank of a decomposition may keep its slab and halo only: domain_init)
     if (st->nodes >= (1ull << 31)) return fail(h, FPIC_ERR_INVALID_ARG, ".nr <- at most 2^31 nodes per device");
-    if (sp.solver == FPIC_SOLVER_YEE) st->ltx = st->lty = st->ltz = kEL;
+    if (sp.solver == FPIC_SOLVER_YEE) { // (the full-EM tile: 8 x 8 x 8 cells in float, 8 x 4 x 8 in double — EmWin, fes_kernels.hpp)
+        st->ltx = st->ltz = kEL;
+        st->lty = h->prec == FPIC_F32 ? EmWin<float>::LY : EmWin<double>::LY;
+    }
     st->ntx = (st->nx + (1 << st->ltx) - 1) >> st->ltx;
     st->nty = (st->ny + (1 << st->lty) - 1) >> st->lty;
     st->ntz = (st->nz + (1 << st->ltz) - 1) >> st->ltz;

@@ -1540,9 +1540,9 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
     a.slab[3 * a.stride + p] = q.vx; a.slab[4 * a.stride + p] = q.vy; a.slab[5 * a.stride + p] = q.vz;
 }
 
-// Tiled form of the full-EM push: 8x8x8-cell tiles, so that both node-centred fields (2 x 4 T per node) and the three
-// int64 current accumulators of a tile and its halo fit in LDS (11^3 nodes x 56 B = 74.5 KB float, x 88 B = 117 KB double).
-// A particle's gather is 16 ds_read_b128 (float), its current 12 ds_add_u64 when it stays in its cell (the two
+// Tiled form of the full-EM push: 8x8x8-cell tiles, so that both node-centred fields (6 T per node) and the three
+// int64 current accumulators of a tile and its halo fit in LDS (11^3 nodes x 48 B = 64 KB float, x 72 B = 96 KB double).
+// A particle's gather is 24 LDS reads of two T each, its current 12 ds_add_u64 when it stays in its cell (the two
 // half-segments of es3d_current are merged: their sum equals the whole segment's fluxes exactly).  Everything else — a
 // face crossing, a cell outside the window, a weight rounded up to a whole cell — is an out-of-line call with the
 // particle's numbers BY VALUE (and the grid through a resident copy of the arguments), so that the common path keeps no
@@ -1552,16 +1552,37 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 #else
 #define FES_ABL_EM_V 0
 #endif
-constexpr int kEL = 3;                 // log2 of the EM tile edge
-constexpr int kET = 1 << kEL;
-// Workgroup sizes of the full-EM push (development switches; profiles/r04_em_tile_overhead.txt).  The kernel needs 149 (float)
-// / 166 (double) VGPRs: three waves per SIMD, and a workgroup's waves go to the SIMDs in turn, so a CU holds twelve waves as ONE
-// workgroup or eight as TWO of four waves each (two of six do not fit: a fourth wave on SIMD 0).  Double: 117 KB of LDS, one
-// workgroup per CU anyway, 768 threads.  Float: 74.5 KB, and two workgroups of 256 threads — one stages or flushes its
-// window while the other computes, and their uneven last turns interleave — beat one of 768 by 11 % at 7.45 particles per
-// cell and tie at 30.
+// Round 5 ("two workgroups per CU for the 3-D pushes ... or the same-box ablation that shows why not";
+// profiles/r05_em_pipe_ablation.txt).  The window's records are UNPADDED AND INTERLEAVED — (E0 E1 E2 B0 B1 B2), 6 T per
+// node, read as three 2 T vectors: double three ds_read_b128 where the padded pair of records took four instructions, float
+// three ds_read_b64 feeding three v_pk_fma_f32 where the padded pair fed four — 11^3 nodes x (6 T + 24 B) = 64 KB float /
+// 96 KB double instead of 74.5 / 117.  That alone took the double-precision push from 30.9 to 26.2 ms at 512^3 / 1e9 (7.45
+// per cell) and from 11.6 to 11.1 ms at 256^3 / 5e8.  Two further forms were built on it, measured on one box and NOT kept
+// as the default:
+//   B  an 8 x 4 x 8-cell tile in double (11 x 7 x 11 nodes x 72 B = 61 KB), two workgroups of 256 threads per CU (the form the
+//      verdict asked for): 11.2 / 26.7 ms — a tie with one workgroup of 768 on the 8^3 tile (11.1 / 26.2): with 166 VGPRs a
+//      SIMD holds three waves, so two workgroups are 8 waves where one is 12, and twice the tiles are twice the windows;
+//   A  FES_EM_PIPE=1: a PERSISTENT workgroup of 768 threads (all twelve waves) that walks the work list with TWO windows —
+//      while its waves push item k out of window k & 1 each of them first flushes item k - 1's currents from the other
+//      window and stages item k + 1's fields into it, no barrier in between, ONE barrier per item.  Two windows fit only
+//      with the 8 x 4 x 8 tile in double (2 x 61 KB), and a tile of 256 cells holds 1 900 particles at 7.45 per cell: 950
+//      groups on 768 threads are 1.24 turns, the second a quarter full — 11.8 / 35.1 ms.  In float (8^3 tile, 2 x 64 KB,
+//      768 threads) it runs like two workgroups of 256: 7.46 / 19.2 against 7.47 / 19.8 ms, both 4-14 % ahead of one
+//      workgroup of 768 with one window (7.74 / 22.4).
+// So what a second resident tile buys is what the float kernel already had (two workgroups of 256), the double kernel cannot
+// have it without halving its tile, and halving the tile costs what it buys.  The default: one item per workgroup, one
+// window; float 2 x 256 threads, double 1 x 768.  Bit-identical results in every form (the whole EM suite ran on A).
+#if !defined(FES_EM_PIPE)
+#define FES_EM_PIPE 0
+#endif
+#if !defined(FES_EM_LY_F32)
+#define FES_EM_LY_F32 3                // log2 of the tile's extent along y
+#endif
+#if !defined(FES_EM_LY_F64)
+#define FES_EM_LY_F64 (FES_EM_PIPE ? 2 : 3)
+#endif
 #if !defined(FES_EM_THREADS_F32)
-#define FES_EM_THREADS_F32 256
+#define FES_EM_THREADS_F32 (FES_EM_PIPE ? 768 : 256)
 #endif
 #if !defined(FES_EM_THREADS_F64)
 #define FES_EM_THREADS_F64 768
@@ -1569,18 +1590,24 @@ constexpr int kET = 1 << kEL;
 #if !defined(FES_EM_WAVES)
 #define FES_EM_WAVES 3          // waves per SIMD the register allocation aims at
 #endif
+constexpr int kEL = 3;                 // log2 of the EM tile's extent along x and z
 template <typename T>
 constexpr int em_threads() { return sizeof(T) == 4 ? FES_EM_THREADS_F32 : FES_EM_THREADS_F64; }
 template <typename T>
 struct EmWin {
-    // one halo cell: an EM step moves a particle by a small fraction of a cell (c dt < dx / sqrt 3), and at 74.5 KB the
-    // float window lets two workgroups share a CU (one stages or flushes while the other computes)
+    static constexpr int LX = kEL, LY = sizeof(T) == 4 ? FES_EM_LY_F32 : FES_EM_LY_F64, LZ = kEL;
+    static constexpr int TX = 1 << LX, TY = 1 << LY, TZ = 1 << LZ;
+    // one halo cell: an EM step moves a particle by a small fraction of a cell (c dt < dx / sqrt 3)
     static constexpr int H = 1;
-    static constexpr int W = kET + 2 * H + 1;
-    static constexpr int N = W * W * W;
+    static constexpr int WX = TX + 2 * H + 1, WY = TY + 2 * H + 1, WZ = TZ + 2 * H + 1;
+    static constexpr int N = WX * WY * WZ;
+    static constexpr int BUFFERS = FES_EM_PIPE ? 2 : 1;
+    static constexpr size_t kFieldBytes = static_cast<size_t>(N) * 6 * sizeof(T);
+    static constexpr size_t kBufBytes = (kFieldBytes + static_cast<size_t>(N) * 24 + 15) / 16 * 16;
+    static_assert(kFieldBytes % 8 == 0 && kBufBytes % 16 == 0, "the accumulators behind the records are 8-byte aligned, a window's records as aligned as a pair of T");
 };
 template <typename T>
-constexpr size_t em_lds_bytes() { return static_cast<size_t>(EmWin<T>::N) * (8 * sizeof(T) + 24) + 16; }
+constexpr size_t em_lds_bytes() { return EmWin<T>::BUFFERS * EmWin<T>::kBufBytes + 16; }
 
 template <typename T>
 struct EmTileArgs {
@@ -1603,9 +1630,9 @@ template <typename T>
 __device__ __forceinline__ int em_slot(int i, int j, int k, int ox, int oy, int oz, int nx, int ny, int nz)
 {
     const unsigned l = wrap_near(i - ox, nx), m = wrap_near(j - oy, ny), n = wrap_near(k - oz, nz);
-    constexpr unsigned W = EmWin<T>::W;
-    const bool in = l <= W - 2 && m <= W - 2 && n <= W - 2;
-    return in ? static_cast<int>(__umul24(__umul24(n, W) + m, W) + l) : -1;
+    constexpr unsigned WX = EmWin<T>::WX, WY = EmWin<T>::WY, WZ = EmWin<T>::WZ;
+    const bool in = l <= WX - 2 && m <= WY - 2 && n <= WZ - 2;
+    return in ? static_cast<int>(__umul24(__umul24(n, WY) + m, WX) + l) : -1;
 }
 
 // fluxes of one straight segment inside the cell whose window slot is s (current_segment, LDS accumulators)
@@ -1613,8 +1640,7 @@ template <typename T>
 __device__ __forceinline__ void current_cell(const int (&p1)[3], const int (&p2)[3], const int (&cell)[3], int s, int Z, FPIC_LDS unsigned long long* lJ)
 {
     constexpr int S = 32768;
-    constexpr int W = EmWin<T>::W;
-    const int step[3] = { 1, W, W * W };
+    const int step[3] = { 1, EmWin<T>::WX, EmWin<T>::WX * EmWin<T>::WY };
     long long d[3], A0[3], A1[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -1649,8 +1675,7 @@ __device__ __forceinline__ void current_cell(const int (&p1)[3], const int (&p2)
 template <typename T>
 __device__ __forceinline__ void current_cell_fast(int wx, int wy, int wz, int d0, int d1, int d2, int s, int Z, FPIC_LDS unsigned long long* lJ)
 {
-    constexpr int W = EmWin<T>::W;
-    const int step[3] = { 1, W, W * W };
+    const int step[3] = { 1, EmWin<T>::WX, EmWin<T>::WX * EmWin<T>::WY };
     const int d[3] = { d0, d1, d2 };
     const unsigned A1[3] = { static_cast<unsigned>(2 * wx + d0), static_cast<unsigned>(2 * wy + d1), static_cast<unsigned>(2 * wz + d2) };
     unsigned A[3][2], A3[3][2];
@@ -1725,62 +1750,74 @@ __device__ __attribute__((noinline)) P3<T> em_particle_rare(P3<T> p, const EmPus
     return p;
 }
 
+// two T as one LDS access (ds_read/write_b64 in float, _b128 in double)
+template <typename T> struct Pair2;
+template <> struct Pair2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Pair2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
 template <typename T>
-__global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu(FES_EM_WAVES))) void em_push_tiles_kernel(EmTileArgs<T> t)
+__device__ __forceinline__ void em_tile_origin(const EmTileArgs<T>& t, uint32_t tile, int& ox, int& oy, int& oz)
 {
-    constexpr int kEmThreads = em_threads<T>();
-    const EmPushArgs<T>& a = t.p;
-    constexpr int PPT = Vec16<T>::N;
-    constexpr int W = EmWin<T>::W, WN = EmWin<T>::N, H = EmWin<T>::H;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsem[];
-    FPIC_LDS T* lE = (FPIC_LDS T*)ldsem;
-    FPIC_LDS T* lB = lE + 4 * WN;
-    FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(lB + 4 * WN);
-    // (the item is read before the count that may send the workgroup home: one memory latency instead of two; the list
-    // has a slot for every workgroup of the launch)
-    const BlockWork w = t.work[blockIdx.x];
-    if (blockIdx.x >= *t.nwork) return;
-    if (!in_part(w.tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) return;
-    const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
-    const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
-    using V = typename NatVec16<T>::type;
-    constexpr int PIECES = static_cast<int>(4 * sizeof(T) / 16);
+    const int ti = static_cast<int>(tile % t.ntx), tj = static_cast<int>((tile / t.ntx) % t.nty), tk = static_cast<int>(tile / (t.ntx * t.nty));
+    ox = ti * EmWin<T>::TX - EmWin<T>::H; oy = tj * EmWin<T>::TY - EmWin<T>::H; oz = tk * EmWin<T>::TZ - EmWin<T>::H;
+}
+
+// the node-centred fields of a tile's window into LDS: one record (E0 E1 E2 B0 B1 B2) per node; ZERO: the window's current
+// accumulators are cleared on the way (the one-window form; the pipelined form's flush leaves them clear)
+template <typename T, int THREADS, bool ZERO>
+__device__ __forceinline__ void em_stage(const EmPushArgs<T>& a, int ox, int oy, int oz, FPIC_LDS T* lF, FPIC_LDS unsigned long long* lJ)
+{
+    using P2 = typename Pair2<T>::type;
+    constexpr int WX = EmWin<T>::WX, WY = EmWin<T>::WY, WN = EmWin<T>::N;
     const Held hs = a.held;
-    const Held hf = a.held;
-    // The lane's first particles are asked for BEFORE the window is staged: a tile of configs[4]'s lattice holds 4 000 to 8 000
-    // particles — one or two turns of the loop below — and with one workgroup per CU nothing else hides the latencies of
-    // a workgroup's start (work item -> window -> barrier -> particles, each a trip to memory under full load); this way the
-    // window's and the particles' trips overlap.
-    size_t g_begin, g_end;
-    fesgrp::groups_exact(w.begin, w.end, PPT, g_begin, g_end); // (exactly the item's own slots: fes_groups.hpp)
-    size_t g = g_begin + threadIdx.x;
-    T v[6][PPT];
-    if (g < g_end) {
-#pragma unroll
-        for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, g * PPT, v[f]);
-    }
-    for (int s = threadIdx.x; s < ((FES_ABL_EM_V & 8) ? 0 : WN); s += kEmThreads) {
-        const int n = s / (W * W), rem = s - n * (W * W);
-        const int m = rem / W, l = rem - m * W;
+    for (int s = threadIdx.x; s < ((FES_ABL_EM_V & 8) ? 0 : WN); s += THREADS) {
+        const int n = s / (WX * WY), rem = s - n * (WX * WY);
+        const int m = rem / WX, l = rem - m * WX;
         // (wrap_window: no division by a run-time number for boxes of 32 nodes or more)
         const int gi = wrap_window(ox + l, a.nx), gj = wrap_window(oy + m, a.ny),
                   gk = wrap_window(oz - hs.zs0 + n, a.nz); // gk: among the planes held
         const int lk = gk < hs.nzs ? gk : -1;
         const size_t node = static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * (lk < 0 ? 0 : lk));
-        lJ[3 * s] = 0ull; lJ[3 * s + 1] = 0ull; lJ[3 * s + 2] = 0ull;
+        if constexpr (ZERO) { lJ[3 * s] = 0ull; lJ[3 * s + 1] = 0ull; lJ[3 * s + 2] = 0ull; }
+        T e[4] = { 0, 0, 0, 0 }, b[4] = { 0, 0, 0, 0 }; // (a plane the rank does not hold: no particle of the tile gathers there)
         if (lk >= 0) {
-#pragma unroll
-            for (int p = 0; p < PIECES; ++p) {
-                *reinterpret_cast<FPIC_LDS V*>(lE + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.E4n + 4 * node + p * Vec16<T>::N);
-                *reinterpret_cast<FPIC_LDS V*>(lB + 4 * s + p * Vec16<T>::N) = *reinterpret_cast<const V*>(a.B4n + 4 * node + p * Vec16<T>::N);
-            }
-        } else { // a plane the rank does not hold: no particle of the tile gathers there
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { lE[4 * s + c] = static_cast<T>(0); lB[4 * s + c] = static_cast<T>(0); }
+            fpic::load4(a.E4n + 4 * node, e);
+            fpic::load4(a.B4n + 4 * node, b);
         }
+        FPIC_LDS P2* rec = reinterpret_cast<FPIC_LDS P2*>(lF + 6 * s);
+        rec[0] = P2{ e[0], e[1] }; rec[1] = P2{ e[2], b[0] }; rec[2] = P2{ b[1], b[2] };
     }
-    __syncthreads();
-    unsigned my_spill = 0;
+}
+
+// the window's currents onto the grid (8-byte global atomics, the non-zero ones); the accumulators are left clear
+template <typename T, int THREADS>
+__device__ __forceinline__ void em_flush(const EmPushArgs<T>& a, int ox, int oy, int oz, FPIC_LDS unsigned long long* lJ)
+{
+    constexpr int WX = EmWin<T>::WX, WY = EmWin<T>::WY, WN = EmWin<T>::N;
+    const Held hf = a.held;
+    for (int s3 = threadIdx.x; s3 < ((FES_ABL_EM_V & 8) ? 0 : 3 * WN); s3 += THREADS) {
+        const unsigned long long val = lJ[s3];
+        if (val == 0ull) continue;
+        lJ[s3] = 0ull;
+        const int s = s3 / 3, m3 = s3 - 3 * s;
+        const int n = s / (WX * WY), rem = s - n * (WX * WY);
+        const int m = rem / WX, l = rem - m * WX;
+        const int gi = wrap_window(ox + l, a.nx), gj = wrap_window(oy + m, a.ny),
+                  gk = wrap_window(oz - hf.zs0 + n, a.nz);
+        if (gk < hf.nzs) atomicAdd(a.Jfix + 3 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)) + m3, val);
+    }
+}
+
+// the particles of one work item against one window; v holds the lane's first group (asked for by the caller before the
+// window work, so that the two trips to memory overlap), g its index
+template <typename T, int THREADS>
+__device__ __forceinline__ void em_push_item(const EmTileArgs<T>& t, const BlockWork w, int ox, int oy, int oz, const FPIC_LDS T* lF, FPIC_LDS unsigned long long* lJ,
+                                             T (&v)[6][Vec16<T>::N], size_t g, size_t g_end, unsigned& my_spill)
+{
+    using P2 = typename Pair2<T>::type;
+    const EmPushArgs<T>& a = t.p;
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int WX = EmWin<T>::WX, WY = EmWin<T>::WY;
     while (g < g_end) {
         const size_t base = g * PPT;
         const bool whole = base >= w.begin && base + PPT <= w.end; // (w.end <= n)
@@ -1805,25 +1842,22 @@ __global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu
             weights_of(wx1, fx); weights_of(wy1, fy); weights_of(wz1, fz);
             T E[3], B[3];
             if constexpr (sizeof(T) == 4) {
-                // float: each record of a ds_read_b128 is two register pairs; (E0, E1), (E2, -), (B0, B1), (B2, -) are
-                // accumulated by one v_pk_fma_f32 each (the fourth lane of a record is zero and unused)
-                f32x2 e01 = { 0.f, 0.f }, e2_ = { 0.f, 0.f }, b01 = { 0.f, 0.f }, b2_ = { 0.f, 0.f };
+                // float: (E0, E1), (E2, B0), (B1, B2) are accumulated by one v_pk_fma_f32 each
+                f32x2 e01 = { 0.f, 0.f }, e2b0 = { 0.f, 0.f }, b12 = { 0.f, 0.f };
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
                         for (int aa = 0; aa < 2; ++aa) {
-                            const int sl = s0 + aa + W * b + W * W * c;
-                            const V ve = *reinterpret_cast<const FPIC_LDS V*>(lE + 4 * sl);
-                            const V vb = *reinterpret_cast<const FPIC_LDS V*>(lB + 4 * sl);
+                            const FPIC_LDS P2* rec = reinterpret_cast<const FPIC_LDS P2*>(lF + 6 * (s0 + aa + WX * b + WX * WY * c));
+                            const P2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                             const T wgt = (fx[aa] * fy[b]) * fz[c];
-                            e01 = fma2_(wgt, f32x2{ ve.x, ve.y }, e01);
-                            e2_ = fma2_(wgt, f32x2{ ve.z, ve.w }, e2_);
-                            b01 = fma2_(wgt, f32x2{ vb.x, vb.y }, b01);
-                            b2_ = fma2_(wgt, f32x2{ vb.z, vb.w }, b2_);
+                            e01 = fma2_(wgt, f32x2{ r0.x, r0.y }, e01);
+                            e2b0 = fma2_(wgt, f32x2{ r1.x, r1.y }, e2b0);
+                            b12 = fma2_(wgt, f32x2{ r2.x, r2.y }, b12);
                         }
-                E[0] = e01.x; E[1] = e01.y; E[2] = e2_.x; B[0] = b01.x; B[1] = b01.y; B[2] = b2_.x;
+                E[0] = e01.x; E[1] = e01.y; E[2] = e2b0.x; B[0] = e2b0.y; B[1] = b12.x; B[2] = b12.y;
             } else {
                 E[0] = E[1] = E[2] = B[0] = B[1] = B[2] = static_cast<T>(0);
 #pragma unroll
@@ -1832,16 +1866,11 @@ __global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
                         for (int aa = 0; aa < 2; ++aa) {
-                            T e[4], bb[4];
-                            const int sl = s0 + aa + W * b + W * W * c;
-                            load4_lds3(lE + 4 * sl, e);
-                            load4_lds3(lB + 4 * sl, bb);
+                            const FPIC_LDS P2* rec = reinterpret_cast<const FPIC_LDS P2*>(lF + 6 * (s0 + aa + WX * b + WX * WY * c));
+                            const P2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                             const T wgt = (fx[aa] * fy[b]) * fz[c];
-#pragma unroll
-                            for (int m = 0; m < 3; ++m) {
-                                E[m] = fma_(wgt, e[m], E[m]);
-                                B[m] = fma_(wgt, bb[m], B[m]);
-                            }
+                            E[0] = fma_(wgt, r0.x, E[0]); E[1] = fma_(wgt, r0.y, E[1]); E[2] = fma_(wgt, r1.x, E[2]);
+                            B[0] = fma_(wgt, r1.y, B[0]); B[1] = fma_(wgt, r2.x, B[1]); B[2] = fma_(wgt, r2.y, B[2]);
                         }
             }
             {
@@ -1886,23 +1915,93 @@ __global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu
                     for (int f = 0; f < 6; ++f) a.slab[f * a.stride + base + q] = v[f][q];
                 }
         }
-        g += kEmThreads;
+        g += THREADS;
         if (g < g_end) {
 #pragma unroll
             for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, g * PPT, v[f]);
         }
     }
-    __syncthreads();
-    for (int s3 = threadIdx.x; s3 < ((FES_ABL_EM_V & 8) ? 0 : 3 * WN); s3 += kEmThreads) {
-        const unsigned long long val = lJ[s3];
-        if (val == 0ull) continue;
-        const int s = s3 / 3, m3 = s3 - 3 * s;
-        const int n = s / (W * W), rem = s - n * (W * W);
-        const int m = rem / W, l = rem - m * W;
-        // (wrap_window: no division by a run-time number for boxes of 32 nodes or more)
-        const int gi = wrap_window(ox + l, a.nx), gj = wrap_window(oy + m, a.ny),
-                  gk = wrap_window(oz - hf.zs0 + n, a.nz);
-        if (gk < hf.nzs) atomicAdd(a.Jfix + 3 * (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)) + m3, val);
+}
+
+template <typename T>
+__global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu(FES_EM_WAVES))) void em_push_tiles_kernel(EmTileArgs<T> t)
+{
+    constexpr int kEmThreads = em_threads<T>();
+    const EmPushArgs<T>& a = t.p;
+    constexpr int PPT = Vec16<T>::N;
+    constexpr int WN = EmWin<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsem[];
+    unsigned my_spill = 0;
+    T v[6][PPT];
+    // the lane's first particles of an item: asked for BEFORE any window work, so that the trips overlap
+    auto first_group = [&](const BlockWork& w, size_t& g, size_t& g_end) {
+        size_t g_begin;
+        fesgrp::groups_exact(w.begin, w.end, PPT, g_begin, g_end); // (exactly the item's own slots: fes_groups.hpp)
+        g = g_begin + threadIdx.x;
+        if (g < g_end) {
+#pragma unroll
+            for (int f = 0; f < 6; ++f) load_lane<T, PPT>(a.slab + f * a.stride, g * PPT, v[f]);
+        }
+    };
+    if constexpr (!FES_EM_PIPE) {
+        FPIC_LDS T* lF = (FPIC_LDS T*)ldsem;
+        FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(ldsem + EmWin<T>::kFieldBytes);
+        // (the item is read before the count that may send the workgroup home: one memory latency instead of two; the list
+        // has a slot for every workgroup of the launch)
+        const BlockWork w = t.work[blockIdx.x];
+        if (blockIdx.x >= *t.nwork) return;
+        if (!in_part(w.tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) return;
+        int ox, oy, oz;
+        em_tile_origin(t, w.tile, ox, oy, oz);
+        size_t g, g_end;
+        first_group(w, g, g_end);
+        em_stage<T, kEmThreads, true>(a, ox, oy, oz, lF, lJ);
+        __syncthreads();
+        em_push_item<T, kEmThreads>(t, w, ox, oy, oz, lF, lJ, v, g, g_end, my_spill);
+        __syncthreads();
+        em_flush<T, kEmThreads>(a, ox, oy, oz, lJ);
+    } else {
+        // persistent: items blockIdx.x, + gridDim.x, ... of the part being launched; every wave of the workgroup walks the
+        // same items (the list and the count are the same for all of them), so every barrier is reached by all
+        const uint32_t nwork = *t.nwork, stride = gridDim.x;
+        auto next_item = [&](uint32_t idx) {
+            while (idx < nwork && !in_part(t.work[idx].tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) idx += stride;
+            return idx;
+        };
+        uint32_t cur = next_item(blockIdx.x);
+        if (cur >= nwork) return;
+        auto fields = [&](int b) { return (FPIC_LDS T*)(ldsem + b * EmWin<T>::kBufBytes); };
+        auto currents = [&](int b) { return (FPIC_LDS unsigned long long*)(ldsem + b * EmWin<T>::kBufBytes + EmWin<T>::kFieldBytes); };
+        BlockWork w = t.work[cur];
+        int ox, oy, oz;
+        em_tile_origin(t, w.tile, ox, oy, oz);
+        size_t g, g_end;
+        first_group(w, g, g_end);
+        for (int s3 = threadIdx.x; s3 < 3 * WN; s3 += kEmThreads) { currents(0)[s3] = 0ull; currents(1)[s3] = 0ull; }
+        em_stage<T, kEmThreads, false>(a, ox, oy, oz, fields(0), currents(0));
+        __syncthreads();
+        int b = 0, pox = 0, poy = 0, poz = 0;
+        bool have_prev = false;
+        for (;;) {
+            const uint32_t nxt = next_item(cur + stride);
+            // the other window: the previous item's currents out, the next item's fields in — no barrier between this and
+            // the particles below, which touch this item's window only
+            if (have_prev) em_flush<T, kEmThreads>(a, pox, poy, poz, currents(b ^ 1));
+            BlockWork wn = w;
+            int nox = 0, noy = 0, noz = 0;
+            if (nxt < nwork) {
+                wn = t.work[nxt];
+                em_tile_origin(t, wn.tile, nox, noy, noz);
+                em_stage<T, kEmThreads, false>(a, nox, noy, noz, fields(b ^ 1), currents(b ^ 1));
+            }
+            em_push_item<T, kEmThreads>(t, w, ox, oy, oz, fields(b), currents(b), v, g, g_end, my_spill);
+            pox = ox; poy = oy; poz = oz; have_prev = true;
+            if (nxt < nwork) first_group(wn, g, g_end); // (its loads fly across the barrier)
+            __syncthreads();
+            if (nxt >= nwork) break;
+            cur = nxt; w = wn; ox = nox; oy = noy; oz = noz; b ^= 1;
+        }
+        em_flush<T, kEmThreads>(a, pox, poy, poz, currents(b));
     }
     if (my_spill) atomicAdd(t.spilled, static_cast<unsigned long long>(my_spill));
 }
@@ -1918,13 +2017,13 @@ __global__ __launch_bounds__(kEmRhoThreads) void em_rho_tiles_kernel(EmTileArgs<
 {
     const EmPushArgs<T>& a = t.p;
     constexpr int PPT = Vec16<T>::N;
-    constexpr int W = EmWin<T>::W, WN = EmWin<T>::N, H = EmWin<T>::H;
+    constexpr int WX = EmWin<T>::WX, WY = EmWin<T>::WY, WN = EmWin<T>::N;
     __shared__ unsigned long long lrho[WN];
     const BlockWork w = t.work[blockIdx.x];
     if (blockIdx.x >= *t.nwork) return;
     if (!in_part(w.tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) return;
-    const int ti = static_cast<int>(w.tile % t.ntx), tj = static_cast<int>((w.tile / t.ntx) % t.nty), tk = static_cast<int>(w.tile / (t.ntx * t.nty));
-    const int ox = ti * kET - H, oy = tj * kET - H, oz = tk * kET - H;
+    int ox, oy, oz;
+    em_tile_origin(t, w.tile, ox, oy, oz);
     for (int s = threadIdx.x; s < WN; s += kEmRhoThreads) lrho[s] = 0ull;
     __syncthreads();
     const GlobalGrid<T> grid{ nullptr, rho, a.nx, a.ny, a.nz, a.held };
@@ -1953,7 +2052,7 @@ __global__ __launch_bounds__(kEmRhoThreads) void em_rho_tiles_kernel(EmTileArgs<
 #pragma unroll
                     for (int aa = 0; aa < 2; ++aa) {
                         const long long v = weight3(wx[aa], wy[b], wz[c] * a.Z);
-                        __hip_atomic_fetch_add(lrho + (s0 + aa + W * b + W * W * c), static_cast<unsigned long long>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(lrho + (s0 + aa + WX * b + WX * WY * c), static_cast<unsigned long long>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
         }
     }
@@ -1961,8 +2060,8 @@ __global__ __launch_bounds__(kEmRhoThreads) void em_rho_tiles_kernel(EmTileArgs<
     for (int s = threadIdx.x; s < WN; s += kEmRhoThreads) {
         const unsigned long long val = lrho[s];
         if (val == 0ull) continue;
-        const int n = s / (W * W), rem = s - n * (W * W);
-        const int m = rem / W, l = rem - m * W;
+        const int n = s / (WX * WY), rem = s - n * (WX * WY);
+        const int m = rem / WX, l = rem - m * WX;
         const int gi = wrap_window(ox + l, a.nx), gj = wrap_window(oy + m, a.ny), gk = wrap_window(oz - a.held.zs0 + n, a.nz);
         if (gk < a.held.nzs) atomicAdd(rho + (static_cast<size_t>(gi) + static_cast<size_t>(a.nx) * (static_cast<size_t>(gj) + static_cast<size_t>(a.ny) * gk)), val);
     }

@@ -843,6 +843,7 @@ int fpic_create(const fpic_spec* spec, fpic_handle** out)
     h->prec = spec->precision;
     h->esize = spec->precision == FPIC_F64 ? 8 : 4;
     h->device = spec->device;
+    h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->nr = spec->nr;
     h->nz = spec->nz;
     h->ncell = static_cast<size_t>(spec->nr) * spec->nz;

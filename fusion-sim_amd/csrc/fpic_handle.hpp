@@ -29,6 +29,7 @@ struct fpic_handle {
     fpic::Constants k{};
     int prec = FPIC_F32;
     int device = 0;
+    int cus = 256;            // compute units of the device: the grid of a persistent launch
     size_t n = 0, n_pad = 0;
     int nr = 0, nz = 0;
     size_t ncell = 0;
