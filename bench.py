@@ -156,6 +156,30 @@ def js_twin_baseline(grid, seconds_target=8.0):
         return {"value": None, "note": "node run failed: %s" % e}
 
 
+def node_host_line(side, grid, steps, warmup, ctypes_ms_per_step):
+    """The headline frame driven from the host north_star names — JavaScript: examples/bench_node.js under `node`, the scene
+    uploaded from Float32Arrays through empic_native.js + the N-API addon, `precalc(); step(); density();` per frame timed in
+    Node.  Run as a child process AFTER this process has given its particles back (both hold 1e8 particles on the card)."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "fusion-sim_amd", "lib", "fusionpic_napi.node")
+    if node is None or not os.path.exists(addon):
+        return {"value": None, "note": "node %s, addon %s" % ("found" if node else "not on this machine", "built" if os.path.exists(addon) else "not built (make -C fusion-sim_amd napi)")}
+    cmd = [node, "--max-old-space-size=8192", os.path.join(ROOT, "examples", "bench_node.js"), "--side", str(side), "--grid", str(grid), "--steps", str(steps), "--warmup", str(warmup)]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if p.returncode != 0:
+            return {"value": None, "error": "exit %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
+        line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:  # a report, never a reason to lose the headline
+        return {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+    line["what"] = ("the SAME frame as the headline, through the JavaScript host (Node N-API addon + empic_native.js) instead of Python ctypes; "
+                    "vs_ctypes = its ms_per_step / the headline's")
+    line["vs_ctypes"] = line["ms_per_step"] / ctypes_ms_per_step if ctypes_ms_per_step else None
+    return line
+
+
 def dense_sor_line(device, n_power=6, products=60):
     """SURVEY 8(f) next-4, the reference's dense iterative solver (matrix_webgl.js): products/s of
     x <- R x + C on an L = 16384 system (1 GiB iteration matrix, streamed once per product)."""
@@ -998,9 +1022,15 @@ def main():
             "value": 2.0 * n_local * args.steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / args.steps,
             "push_avg_launch_ms": pm, "cell_sums_avg_launch_ms": es["ms_deposit"] / max(1, es["deposit_launches"]),
             "rebinning_launches": es["sort_passes"],
-            "roofline_achieved_GBs": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9,
-            "roofline_frac": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # Two accountings, named for what they are.  (1) SURVEY 8(d)'s 48 B per update x the two updates of a
+            # launch: a THROUGHPUT figure comparable with the headline's roofline.frac, not bus utilisation — the launch fuses two
+            # sub-steps and moves each particle once.  (2) What the launch really streams: six coordinates read + written and
+            # the alive flag, 50 B per particle and launch (no per-particle random state in this mode), over its time and the peak.
+            "accounting_48B_per_update_GBs": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9,
+            "accounting_48B_per_update_frac": ALGO_BYTES_PER_UPDATE * 2.0 * n_local / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "streamed_bytes_per_launch": 50.0 * n_local,
+            "streamed_GBs": 50.0 * n_local / (pm * 1e-3) / 1e9,
+            "streamed_frac": 50.0 * n_local / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS,
         }}
         ext.destroy()
         # "C2 with both cic and ref11 reported": the same frame with the bilinear deposit (extension key shape:'cic')
@@ -1023,6 +1053,8 @@ def main():
             "push_avg_launch_ms": cs["ms_push"] / max(1, cs["step_launches"]),
             "cic_sums_avg_launch_ms": cs["ms_deposit"] / max(1, cs["deposit_launches"]), "rebinning_launches": cs["sort_passes"]}
         cic.destroy()
+        torch.cuda.empty_cache()
+        out["extensions"]["node_host"] = node_host_line(args.side, args.grid, args.steps, args.warmup, out["ms_per_step"])
         out["extensions"]["dense_sor"] = dense_sor_line(local_rank)
         out["extensions"]["em"] = em_line(local_rank, args.c3_particles, args.c3_grid, max(2, args.steps // 4), 1, "fp64")
         out["extensions"]["c3"] = es3d_line(local_rank, args.c3_particles, args.c3_grid, max(8, args.steps // 4), 1, stream=stream,

@@ -40,7 +40,20 @@ using fpic::Vec16;
 #define FPIC_LDS __attribute__((address_space(3)))
 #endif
 
-constexpr int kTX = 16, kTY = 16, kTZ = 8;       // cells per tile
+// (development switches for the tile shape and the workgroup of the electrostatic push: scripts/probe_push3_tile.sh)
+#if !defined(FES_LTX)
+#define FES_LTX 4
+#endif
+#if !defined(FES_LTY)
+#define FES_LTY 4
+#endif
+#if !defined(FES_LTZ)
+#define FES_LTZ 3
+#endif
+#if !defined(FES_PUSH_THREADS)
+#define FES_PUSH_THREADS 1024
+#endif
+constexpr int kTX = 1 << FES_LTX, kTY = 1 << FES_LTY, kTZ = 1 << FES_LTZ;       // cells per tile: 16 x 16 x 8
 // The LDS window of a tile: its nodes plus a halo of H cells.  A node costs 16 B of field record + 8 B of
 // accumulator in float (H = 2: 21 * 21 * 13 = 5733 nodes, 137.6 KB) and 32 + 8 B in double (H = 1:
 // 19 * 19 * 11 = 3971 nodes, 158.8 KB of the CU's 160 KB).
@@ -50,7 +63,7 @@ struct Win {
     static constexpr int X = kTX + 2 * H + 1, Y = kTY + 2 * H + 1, Z = kTZ + 2 * H + 1;
     static constexpr int N = X * Y * Z;
 };
-constexpr int kPushThreads3 = 1024;                // 16 waves per CU: 14 % faster than 512 (profiles/r02_push3_ablation.txt)
+constexpr int kPushThreads3 = FES_PUSH_THREADS;                // 16 waves per CU: 14 % faster than 512 (profiles/r02_push3_ablation.txt)
 constexpr int kChunk3 = 65536;                   // particles per workgroup and chunk
 constexpr int kMaxTiles3 = 40960;                // LDS histogram limit of the one-level binning passes: 160 KB (256^3: 8192 tiles of 16x16x8, 32768 of 8x8x8)
 constexpr int kMaxTilesStaged3 = 1 << 20;        // beyond kMaxTiles3 (512^3: 65536 / 262144 tiles): global-atomic census + the staged two-level scatter (<= 1024^2 bins)
@@ -405,16 +418,15 @@ __device__ __forceinline__ void store_state3_own(const Push3Args<T>& a, size_t b
 
 static_assert((kTX & (kTX - 1)) == 0 && (kTY & (kTY - 1)) == 0 && (kTZ & (kTZ - 1)) == 0, "tile edges are powers of two: cell -> tile is a shift");
 // LX, LY, LZ: log2 of the tile edges (the electrostatic cycle bins by 16x16x8 cells, the full-EM cycle by 8x8x8)
-template <int LX = 4, int LY = 4, int LZ = 3>
+template <int LX = FES_LTX, int LY = FES_LTY, int LZ = FES_LTZ>
 __device__ __forceinline__ uint32_t tile_key3(int i, int j, int k, int ntx, int nty)
 {
-    static_assert((1 << LX) == kTX || LX == 3, "default shape = the electrostatic tile");
     const unsigned tx = static_cast<unsigned>(i) >> LX, ty = static_cast<unsigned>(j) >> LY, tz = static_cast<unsigned>(k) >> LZ;
     return tx + __umul24(static_cast<unsigned>(ntx), ty + __umul24(static_cast<unsigned>(nty), tz));
 }
 
 // the tile of a position
-template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+template <typename T, int LX = FES_LTX, int LY = FES_LTY, int LZ = FES_LTZ>
 __device__ __forceinline__ uint32_t key_of(T x, T y, T z, int nx, int ny, int nz, int ntx, int nty)
 {
     int i, j, k, w;
@@ -981,7 +993,7 @@ __global__ __launch_bounds__(256) void init3_kernel(T* slab, size_t stride, uint
 constexpr int kBinPer3 = 8;
 
 // the key of the LDS-staged two-level binning (fpic_kernels.hpp); a slot with x < 0 is dead and is not copied
-template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+template <typename T, int LX = FES_LTX, int LY = FES_LTY, int LZ = FES_LTZ>
 struct BoxTileKey {
     int nx, ny, nz, ntx, nty;
     __device__ __forceinline__ uint32_t operator()(T x, T y, T z) const
@@ -990,7 +1002,7 @@ struct BoxTileKey {
     }
 };
 
-template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+template <typename T, int LX = FES_LTX, int LY = FES_LTY, int LZ = FES_LTZ>
 __global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ slab, size_t stride, size_t n, int nx, int ny, int nz, int ntx, int nty,
                                                          uint32_t ntiles, uint32_t* __restrict__ tile_count)
 {
@@ -1010,7 +1022,7 @@ __global__ __launch_bounds__(256) void bin3_count_kernel(const T* __restrict__ s
 
 // the census of a grid with more tiles than an LDS histogram holds: atomics on the global table, two rounds of
 // wave-level aggregation first (an already sorted input sends one atomic per wave instead of 64 to one address)
-template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+template <typename T, int LX = FES_LTX, int LY = FES_LTY, int LZ = FES_LTZ>
 __global__ __launch_bounds__(256) void bin3_count_global_kernel(const T* __restrict__ slab, size_t stride, size_t n, int nx, int ny, int nz, int ntx, int nty,
                                                                 uint32_t* __restrict__ tile_count)
 {
@@ -1099,7 +1111,7 @@ __global__ __launch_bounds__(1024) void bin3_count_sorted_kernel(const T* __rest
     if (threadIdx.x < div && hist[threadIdx.x]) atomicAdd(&tile_count[c0 * div + threadIdx.x], hist[threadIdx.x]);
 }
 
-template <typename T, int LX = 4, int LY = 4, int LZ = 3>
+template <typename T, int LX = FES_LTX, int LY = FES_LTY, int LZ = FES_LTZ>
 __global__ __launch_bounds__(256) void bin3_scatter_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t stride, const uint32_t* __restrict__ src_id,
                                                            uint32_t* __restrict__ dst_id, size_t n, int nx, int ny, int nz, int ntx, int nty,
                                                            uint32_t ntiles, const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor)

@@ -813,6 +813,9 @@ def test_against_the_reference_run_under_webgl(fp, scene, fuse):
         top = np.nanmax(np.abs(w), axis=0)
         assert np.all(np.nanmax(np.abs(g - w), axis=0) <= 1e-5 * top), (k, np.nanmax(np.abs(g - w), axis=0) / top)
         solid = w[:, 3] > 1e-30          # cells that hold more than the stamp's outermost ring (<= 1.7e-34 of a particle)
+        # ... and texel by texel on the count channel (north_star's fp32 bar, relative to the texel itself): a sprite put one
+        # cell off changes its footprint's rim texels by far more than 1e-3 of their own value
+        np.testing.assert_allclose(g[solid, 3], w[solid, 3], rtol=RTOL32, atol=0, err_msg="moments01 count channel, frame %d" % k)
         gn, wn = sim.readGrid(fp.READ_NORM).reshape(-1, 4)[solid], get("density%d/moments01_norm" % k).reshape(-1, 4)[solid]
         assert np.array_equal(np.isnan(gn), np.isnan(wn)), k
         ok = ~np.isnan(wn)
@@ -934,6 +937,9 @@ def test_demo_scene_of_the_reference_under_webgl(fp, po):
         # ~3600 sprites overlap per cell here: the reference's own float32 blend, one rounding per sprite in particle order,
         # is 2e-5 away from the per-cell sums kept in double (north_star's bar for fp32 field values is 1e-3)
         assert np.all(np.abs(img[b0:b1, a0:a1] - want).max(axis=(0, 1)) <= 1e-4 * top), k
+        # ... and texel by texel on the count channel, relative to the texel's own value (north_star's fp32 bar)
+        solid = want[..., 3] > 1e-30
+        np.testing.assert_allclose(img[b0:b1, a0:a1, 3][solid], want[..., 3][solid], rtol=RTOL32, atol=0, err_msg="moments01 count channel, frame %d" % k)
         outside = img.copy(); outside[b0:b1, a0:a1] = 0
         assert np.abs(outside).max() <= 1e-30
 
