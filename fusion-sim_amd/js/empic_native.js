@@ -42,7 +42,8 @@ const path = require('path');
 let native = null;
 function addon() {
     if (native) return native;
-    const file = path.join(__dirname, '..', 'lib', 'fusionpic_napi.node');
+    // (FUSIONPIC_NAPI_ADDON: another build of the same addon — `make -C fusion-sim_amd sanitize` points it at the ASan / UBSan build)
+    const file = process.env.FUSIONPIC_NAPI_ADDON || path.join(__dirname, '..', 'lib', 'fusionpic_napi.node');
     try {
         native = require(file);
     } catch (e) {
