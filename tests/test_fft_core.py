@@ -10,7 +10,7 @@ from helpers import ROOT
 
 def test_fft_core_matches_a_direct_transform(tmp_path):
     exe = tmp_path / "fft_core_test"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "fft_core_test.cpp"), "-o", str(exe)])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("FPIC_NATIVE_CXXFLAGS", "").split(), os.path.join(ROOT, "tests", "native", "fft_core_test.cpp"), "-o", str(exe)])
     out = subprocess.check_output([str(exe)], timeout=120).decode()
     assert out.strip().splitlines()[-1] == "ok", out
     assert out.count("N=") == 10

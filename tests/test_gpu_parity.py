@@ -354,6 +354,37 @@ def test_binning_preserves_particles_and_order_of_readback(fp, po):
     assert_particles_equal(sim, ora)
 
 
+def test_rebinning_launch_reserves_the_same_ranges_with_and_without_the_census(fp, monkeypatch):
+    """A re-binning launch reserves one range per destination bin either from the per-item census the in-place launch before
+    it left (round 4) or from a count pass of its own (the launch before was no in-place fused push).  FPIC_TEST_COUNT_PASS
+    forces the count pass where the census is at hand: particles, read-back order, cell indices and the deposit of six frames
+    must be the same bits (nothing pinned the count pass against the census path)."""
+    spec = make_spec(96, 72, 160, radius=0.5, height=0.4)
+    rng = np.random.default_rng(7)
+    E, B = random_fields(rng, 96, 72)
+    n = 160 * 160
+    pos, vel, entropy, rand = uniform_plasma(n, spec, seed=8, v_th=0.02)
+    runs = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("FPIC_TEST_COUNT_PASS", "1")
+        sim = fp.makeCylindricalParticlePusher(spec, sort_interval=2)
+        sim.set(E=E, B=B, position=pos, velocity=vel, sink_mask=frame_sink(96, 72), source_pdf=frame_sink(96, 72))
+        sim.setRandomState(entropy, rand)
+        sim.precalc(); sim.density()
+        for _ in range(6):
+            sim.step(); sim.density()
+        got = sim.getParticles()
+        runs.append((got["position"], got["velocity"], got["rand"], got["alive"], sim.getCells(), sim.readMoments(), sim.stats()["sort_passes"]))
+        sim.destroy()
+    assert runs[0][6] >= 3 and runs[0][6] == runs[1][6]
+    for a, b in zip(runs[0][:5], runs[1][:5]):
+        assert np.array_equal(a, b, equal_nan=True)
+    # (the per-cell sums are float additions in the order the workgroups happen to flush: equal to rounding, not to the bit)
+    a, b = runs[0][5].reshape(-1, 4), runs[1][5].reshape(-1, 4)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.all(np.nanmax(np.abs(a - b), axis=0) <= 1e-5 * np.nanmax(np.abs(b), axis=0))
+
+
 @pytest.mark.parametrize("fuse", [True, False, "census"])
 def test_rebinning_inside_the_push_every_frame(fp, po, fuse):
     """sort_interval=1 asks for a re-binning at every density(): with the fused push the

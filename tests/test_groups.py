@@ -15,7 +15,7 @@ from helpers import ROOT
 
 def test_group_rules_partition_every_bin_table(tmp_path):
     exe = tmp_path / "groups_test"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "groups_test.cpp"), "-o", str(exe)])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("FPIC_NATIVE_CXXFLAGS", "").split(), os.path.join(ROOT, "tests", "native", "groups_test.cpp"), "-o", str(exe)])
     out = subprocess.check_output([str(exe)], timeout=120).decode()
     assert out.strip().splitlines()[-1] == "ok", out
     assert int(out.split("cases=")[1].split()[0]) > 30000

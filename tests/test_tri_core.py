@@ -16,7 +16,7 @@ from helpers import ROOT
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     out = tmp_path_factory.mktemp("tri") / "tri_core_test"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "tri_core_test.cpp"), "-o", str(out)])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("FPIC_NATIVE_CXXFLAGS", "").split(), os.path.join(ROOT, "tests", "native", "tri_core_test.cpp"), "-o", str(out)])
     return str(out)
 
 
