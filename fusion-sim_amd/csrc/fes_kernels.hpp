@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 #define FES_EM_LY_F32 3                // log2 of the tile's extent along y
 #endif
 #if !defined(FES_EM_LY_F64)
-#define FES_EM_LY_F64 (FES_EM_PIPE ? 2 : 3)
+#define FES_EM_LY_F64 (FES_EM_PIPE == 1 ? 2 : 3)
 #endif
 #if !defined(FES_EM_THREADS_F32)
 #define FES_EM_THREADS_F32 (FES_EM_PIPE ? 768 : 256)
@@ -1618,8 +1618,12 @@ struct EmWin {
     static constexpr size_t kBufBytes = (kFieldBytes + static_cast<size_t>(N) * 24 + 15) / 16 * 16;
     static_assert(kFieldBytes % 8 == 0 && kBufBytes % 16 == 0, "the accumulators behind the records are 8-byte aligned, a window's records as aligned as a pair of T");
 };
+// FES_EM_PIPE == 2: two FIELD windows and ONE accumulator window (double, 8^3 tile: 2 x 64 KB + 32 KB = 159.7 KB)
 template <typename T>
-constexpr size_t em_lds_bytes() { return EmWin<T>::BUFFERS * EmWin<T>::kBufBytes + 16; }
+constexpr size_t em_lds_bytes()
+{
+    return FES_EM_PIPE == 2 ? 2 * EmWin<T>::kFieldBytes + static_cast<size_t>(EmWin<T>::N) * 24 + 16 : EmWin<T>::BUFFERS * EmWin<T>::kBufBytes + 16;
+}
 
 template <typename T>
 struct EmTileArgs {
@@ -1972,6 +1976,43 @@ __global__ __launch_bounds__(em_threads<T>()) __attribute__((amdgpu_waves_per_eu
         em_push_item<T, kEmThreads>(t, w, ox, oy, oz, lF, lJ, v, g, g_end, my_spill);
         __syncthreads();
         em_flush<T, kEmThreads>(a, ox, oy, oz, lJ);
+    } else if constexpr (FES_EM_PIPE == 2) {
+        // persistent, the tile's FIELDS double-buffered (the next item's records are staged by the waves before they push this
+        // item's particles: no barrier in between), ONE accumulator window: push - barrier - flush - barrier per item
+        const uint32_t nwork = *t.nwork, stride = gridDim.x;
+        auto next_item = [&](uint32_t idx) {
+            while (idx < nwork && !in_part(t.work[idx].tile, t.part, t.tiles_per_layer, t.layer_lo, t.layer_hi)) idx += stride;
+            return idx;
+        };
+        uint32_t cur = next_item(blockIdx.x);
+        if (cur >= nwork) return;
+        auto fields = [&](int b) { return (FPIC_LDS T*)(ldsem + b * EmWin<T>::kFieldBytes); };
+        FPIC_LDS unsigned long long* lJ = (FPIC_LDS unsigned long long*)(ldsem + 2 * EmWin<T>::kFieldBytes);
+        BlockWork w = t.work[cur];
+        int ox, oy, oz;
+        em_tile_origin(t, w.tile, ox, oy, oz);
+        size_t g, g_end;
+        first_group(w, g, g_end);
+        em_stage<T, kEmThreads, true>(a, ox, oy, oz, fields(0), lJ);
+        __syncthreads();
+        int b = 0;
+        for (;;) {
+            const uint32_t nxt = next_item(cur + stride);
+            BlockWork wn = w;
+            int nox = 0, noy = 0, noz = 0;
+            if (nxt < nwork) {
+                wn = t.work[nxt];
+                em_tile_origin(t, wn.tile, nox, noy, noz);
+                em_stage<T, kEmThreads, false>(a, nox, noy, noz, fields(b ^ 1), lJ);
+            }
+            em_push_item<T, kEmThreads>(t, w, ox, oy, oz, fields(b), lJ, v, g, g_end, my_spill);
+            if (nxt < nwork) first_group(wn, g, g_end); // (its loads fly across the barriers)
+            __syncthreads();
+            em_flush<T, kEmThreads>(a, ox, oy, oz, lJ);   // (leaves the accumulators clear)
+            if (nxt >= nwork) break;
+            __syncthreads();
+            cur = nxt; w = wn; ox = nox; oy = noy; oz = noz; b ^= 1;
+        }
     } else {
         // persistent: items blockIdx.x, + gridDim.x, ... of the part being launched; every wave of the workgroup walks the
         // same items (the list and the count are the same for all of them), so every barrier is reached by all

@@ -4,6 +4,9 @@
 #   A  pipelined, double 8x4x8 tile / float 8x8x8, 768 threads                      (the default build)
 #   B  one window, double 8x4x8 tile (61 KB) in TWO workgroups of 256 threads per CU  (what VERDICT r04 asked to be measured)
 #   C  one window, double 8x8x8 tile (96 KB unpadded), one workgroup of 768           (round 4's shape with round 5's records)
+#   D  FES_EM_PIPE=0 with its own defaults (double as C, float two workgroups of 256)
+#   E  FES_EM_PIPE=2: persistent, 8x8x8 tile, the FIELD window double-buffered (the next item's records staged while this
+#      item's particles are pushed), ONE accumulator window: double 2 x 64 + 32 KB, 768 threads; float 768 threads
 # Rebuilds fes_api.o ON THE GPU BOX and restores the real build.  scripts/probe_em_pipe.sh > gpurun_out/r5_em_pipe.txt
 cd $GRAFT_REPO_ROOT
 em() { python bench.py --only-em --c3-particles $3 --c3-grid $4 --em-precision $2 --steps 4 --warmup 1 2>/dev/null | python -c "
@@ -21,6 +24,8 @@ for V in ${VARIANTS:-A B C}; do
     A) build "" ;;
     B) build "-DFES_EM_PIPE=0 -DFES_EM_THREADS_F64=256 -DFES_EM_THREADS_F32=256" ;;
     C) build "-DFES_EM_PIPE=0 -DFES_EM_LY_F64=3 -DFES_EM_THREADS_F64=768 -DFES_EM_THREADS_F32=768" ;;
+    D) build "-DFES_EM_PIPE=0" ;;
+    E) build "-DFES_EM_PIPE=2" ;;
   esac
   scenes $V || exit 1
 done
