@@ -1581,6 +1581,9 @@ __global__ __launch_bounds__(256) void em_push_kernel(EmPushArgs<T> a)
 //      groups on 768 threads are 1.24 turns, the second a quarter full — 11.8 / 35.1 ms.  In float (8^3 tile, 2 x 64 KB,
 //      768 threads) it runs like two workgroups of 256: 7.46 / 19.2 against 7.47 / 19.8 ms, both 4-14 % ahead of one
 //      workgroup of 768 with one window (7.74 / 22.4).
+//   E  FES_EM_PIPE=2: persistent, 8^3 tile, only the FIELD window double-buffered (double: 2 x 64 + 32 KB; the next item's records
+//      are staged while this item's particles are pushed; push - barrier - flush - barrier per item): on one box, alternating
+//      with the default, 6 % SLOWER in double (10.74 / 26.8 against 10.07 / 25.3 ms), 2 % faster in float.
 // So what a second resident tile buys is what the float kernel already had (two workgroups of 256), the double kernel cannot
 // have it without halving its tile, and halving the tile costs what it buys.  The default: one item per workgroup, one
 // window; float 2 x 256 threads, double 1 x 768.  Bit-identical results in every form (the whole EM suite ran on A).
