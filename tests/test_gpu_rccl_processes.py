@@ -155,3 +155,27 @@ def test_bench_default_command_under_the_launcher(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["comm"]["world"] == 2 and "comm_fallback" not in line and "REHEARSAL" in line["rehearsal"], line
     assert line["strong_c4"]["value"] > 0 and line["strong_c4"]["comm"]["world"] == 2 and line["strong_c4"]["lost_rank0"] == 0, line["strong_c4"]
+
+
+@pytest.mark.parametrize("mode,world", [("rz", 2), ("rz", 3), ("box", 2)])
+def test_javascript_host_drives_ranks_as_processes(mode, world):
+    """`north_star`: "host code stays JavaScript".  examples/multi_gpu_node.js — INTEGRATION.md 4a as a program: one NODE
+    process per rank through the N-API addon, rank 0 makes the unique id (empic.commUniqueId), the parent relays it, every rank
+    calls simulation.commInit (and domainInit / domainSet for the box) and runs the unchanged frame loop.  Ranks share this one
+    GPU over the shared-memory stand-in.  --check compares with ONE handle: particles bit for bit; the (r,z) density equal on
+    all ranks bit for bit and equal to one handle's up to the summation order."""
+    import shutil
+    if shutil.which("node") is None or not os.path.exists(os.path.join(ROOT, "fusion-sim_amd", "lib", "fusionpic_napi.node")):
+        pytest.skip("node or the N-API addon is not on this machine")
+    env = dict(os.environ, FPIC_RCCL_LIBRARY=fake_lib("procs"))
+    p = subprocess.run(["node", os.path.join(ROOT, "examples", "multi_gpu_node.js"), "--ranks", str(world), "--mode", mode, "--one-device", "--check"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.stdout.strip(), p.stderr.decode()[-2000:]
+    res = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert p.returncode == 0 and res["ok"], (res, p.stderr.decode()[-2000:])
+    assert all(c["world"] == world for c in res["comm"]) and sorted(c["rank"] for c in res["comm"]) == list(range(world)), res
+    assert res["particles_same"], res
+    if mode == "rz":
+        assert res["ranks_agree"] and res["nan_sites_agree"] and res["density_rel_err"] <= 1e-5, res
+    else:
+        assert res["lost"] == 0 and res["migrated"] > 0 and res["every_particle_once"], res
