@@ -150,6 +150,14 @@ SPLIT_SCENES = {
 }
 
 
+# eight ranks — the world of the driver's scaling run — fit one process as threads (as processes a GPU box allows four)
+EIGHT_RANKS = {
+    "electrostatic, interface solve": dict(world=8, shape=(16, 16, 128), ghost=2, every=2, em=False, distributed_solve=2, precision="fp32", n=24000, seed=3),
+    "electrostatic, transposed spectrum": dict(world=8, shape=(16, 16, 128), ghost=2, every=2, em=False, distributed_solve=True, precision="fp32", n=24000, seed=3),
+    "full EM from a decomposed precalc": dict(world=8, shape=(16, 16, 128), ghost=2, every=4, em=True, distributed_solve=True, precalc=True, precision="fp64", n=16000, seed=4),
+}
+
+
 def identical(res, scene):
     if scene["distributed_solve"] == 2:   # (another arithmetic in the solve: agreement to its rounding, the integer charge exact in total)
         return res["ids_ok"] and res["pos_err"] <= 1e-4 and res["charge_total_same"] and res["charge_max_rel_diff"] <= 1e-3
@@ -160,6 +168,14 @@ def identical(res, scene):
 def test_rccl_transport_with_late_arrivals_and_late_producers(tmp_path, name):
     res = run_case(tmp_path, transport="delayed", **SPLIT_SCENES[name])
     assert identical(res, SPLIT_SCENES[name]), res
+    assert res["migrated"] > 0 and res["lost"] == 0
+
+
+@pytest.mark.parametrize("transport", ["stream", "delayed"])
+@pytest.mark.parametrize("name", sorted(EIGHT_RANKS))
+def test_rccl_transport_with_eight_ranks(tmp_path, name, transport):
+    res = run_case(tmp_path, transport=transport, **EIGHT_RANKS[name])
+    assert identical(res, EIGHT_RANKS[name]), res
     assert res["migrated"] > 0 and res["lost"] == 0
 
 
