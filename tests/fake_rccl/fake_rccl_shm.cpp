@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include "ring_alloc.hpp"
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -159,8 +161,7 @@ void pin(Mapping& m)
     }
 }
 
-struct Outstanding {                 // one group's messages to a peer: one region of the segment
-    size_t offset, bytes;
+struct Outstanding {                 // one group's messages to a peer: one region of the segment (ring.in_use, same order)
     std::vector<std::pair<Entry*, uint64_t>> entries; // (descriptor, sequence number it was posted with)
     bool consumed() const
     {
@@ -172,7 +173,7 @@ struct Outstanding {                 // one group's messages to a peer: one regi
 struct SendSide {                    // my data segment towards one peer
     Mapping seg;
     uint32_t gen = 0;
-    size_t write_off = 0;
+    fakerccl::RingAlloc ring;        // where the next group's bytes go (ring_alloc.hpp: host-tested on its own)
     std::deque<Outstanding> out;     // regions not yet known to be consumed, oldest first
     uint64_t sent = 0;
 };
@@ -301,8 +302,7 @@ bool reserve(Comm* c, int peer, size_t need, size_t& offset)
     SendSide& s = c->tx[peer];
     const int patience = settings().patience_ms;
     auto reclaim = [&] {
-        while (!s.out.empty() && s.out.front().consumed()) s.out.pop_front();
-        if (s.out.empty()) s.write_off = 0;
+        while (!s.out.empty() && s.out.front().consumed()) { s.out.pop_front(); s.ring.release_oldest(); }
     };
     reclaim();
     if (!s.seg.base || need > s.seg.bytes) {
@@ -312,24 +312,10 @@ bool reserve(Comm* c, int peer, size_t need, size_t& offset)
         const size_t cap = std::max<size_t>(size_t(1) << 20, 2 * need);
         if (!map_file(seg_path(c, c->rank, peer, s.gen), cap, true, s.seg)) return false;
         pin(s.seg);
-        s.write_off = 0;
+        s.ring.reset(cap);
     }
-    // the regions in use run from the oldest one's offset forwards (around the end of the segment) to write_off
-    auto fits = [&]() -> bool {
-        reclaim();
-        if (s.out.empty()) { offset = 0; return true; }
-        const size_t begin = s.out.front().offset;
-        if (begin <= s.write_off) {   // in use: [begin, write_off)
-            if (s.write_off + need <= s.seg.bytes) { offset = s.write_off; return true; }
-            if (need < begin) { offset = 0; return true; }
-            return false;
-        }
-        if (s.write_off + need < begin) { offset = s.write_off; return true; }   // in use: [begin, end) and [0, write_off)
-        return false;
-    };
-    if (!wait_until(c, fits, patience)) return false;
-    s.write_off = offset + need;
-    s.out.push_back({ offset, need, {} });
+    if (!wait_until(c, [&] { reclaim(); return s.ring.try_alloc(need, offset); }, patience)) return false;
+    s.out.push_back({});
     return true;
 }
 
