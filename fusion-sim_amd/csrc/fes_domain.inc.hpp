@@ -489,8 +489,9 @@ int solve_distributed(Ranks& rk)
     for (fpic_handle* h : rk.hs) split &= h->es->dom->overlap && h->es->dom->nzl >= 3;
     auto gradient = [&](fpic_handle* h, int first, int count) -> int {
         State* st = h->es;
-        const size_t plane = static_cast<size_t>(st->nx) * st->ny;
-        gradient_planes_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
+        if (count <= 0) return FPIC_OK;
+        const NodeLaunch nl = node_launch(st->nx, st->ny, count);
+        gradient_planes_kernel<T><<<nl.grid, nl.block, 0, h->stream>>>(
             static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, first, count, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
             static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4), held_of(st));
         HIP_TRY(h, hipGetLastError());
@@ -514,10 +515,9 @@ int solve_distributed(Ranks& rk)
     return each([&](fpic_handle* h) -> int {
         State* st = h->es;
         Domain& d = *st->dom;
-        const size_t plane = static_cast<size_t>(st->nx) * st->ny;
         if (st->solver == FPIC_SOLVER_YEE) { // the initial E on the edges of the slab and of its H halo planes on either side
             const int count = d.nzl + 2 * d.H;
-            em_edge_gradient_kernel<T><<<blocks_for(plane * count), 256, 0, h->stream>>>(
+            em_edge_gradient_kernel<T><<<node_launch(st->nx, st->ny, count).grid, node_launch(st->nx, st->ny, count).block, 0, h->stream>>>(
                 static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
                 static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey), ((d.z0 - d.H) % st->nz + st->nz) % st->nz, count, held_of(st));
             HIP_TRY(h, hipGetLastError());

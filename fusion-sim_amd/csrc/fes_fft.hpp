@@ -131,6 +131,9 @@ namespace fes {
 
 using fesfft::C2;
 
+#if !defined(FES_FFT_VEC)
+#define FES_FFT_VEC 1
+#endif
 constexpr int kFftThreads = 512;
 constexpr int kFftMaxLog = 9, kFftMinLog = 3;           // 8 .. 512 points per axis (a padded tile of 1024-point double columns would not fit the LDS; such grids keep rocFFT)
 // columns of a tile: 128 contiguous bytes of a row (16 complex floats, 8 complex doubles)
@@ -231,11 +234,39 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
     fft_tile<T, false>(buf, ld, pairs, tw, nx, logn);
     C2<T>* out = reinterpret_cast<C2<T>*>(hat);
     const T half = static_cast<T>(0.5);
-    for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
-        const int p = e / nxh, k = e - p * nxh;
+    auto spectra = [&](int p, int k, C2<T>& A, C2<T>& B) {
         const C2<T> z = fesfft::ldc<T>(buf, p * ld + fesfft::swz(k)), w = fesfft::ldc<T>(buf, p * ld + fesfft::swz((nx - k) & (nx - 1)));
-        out[(row0 + 2 * p) * pitch + k] = C2<T>{ (z.x + w.x) * half, (z.y - w.y) * half };
-        out[(row0 + 2 * p + 1) * pitch + k] = C2<T>{ (z.y + w.y) * half, (w.x - z.x) * half };
+        A = C2<T>{ (z.x + w.x) * half, (z.y - w.y) * half };
+        B = C2<T>{ (z.y + w.y) * half, (w.x - z.x) * half };
+    };
+    if constexpr (sizeof(T) == 4 && FES_FFT_VEC) {
+        // float: two spectral values — 16 bytes — per lane and store (rows start 16-byte aligned: the pitch is a multiple of the
+        // tile width); k = nx / 2, the odd one out of nx / 2 + 1, goes alone
+        using V4 = typename fpic::NatVec16<T>::type;
+        const int h2 = nx / 4;   // pairs (k, k + 1), k even, k + 1 < nx / 2 + 1
+        for (int e = threadIdx.x; e < pairs * (h2 + 1); e += kFftThreads) {
+            const int p = e / (h2 + 1), q = e - p * (h2 + 1);
+            C2<T> A0, B0;
+            if (q == h2) {
+                spectra(p, nx / 2, A0, B0);
+                out[(row0 + 2 * p) * pitch + nx / 2] = A0;
+                out[(row0 + 2 * p + 1) * pitch + nx / 2] = B0;
+                continue;
+            }
+            C2<T> A1, B1;
+            spectra(p, 2 * q, A0, B0);
+            spectra(p, 2 * q + 1, A1, B1);
+            *reinterpret_cast<V4*>(out + (row0 + 2 * p) * pitch + 2 * q) = V4{ A0.x, A0.y, A1.x, A1.y };
+            *reinterpret_cast<V4*>(out + (row0 + 2 * p + 1) * pitch + 2 * q) = V4{ B0.x, B0.y, B1.x, B1.y };
+        }
+    } else {
+        for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
+            const int p = e / nxh, k = e - p * nxh;
+            C2<T> A, B;
+            spectra(p, k, A, B);
+            out[(row0 + 2 * p) * pitch + k] = A;
+            out[(row0 + 2 * p + 1) * pitch + k] = B;
+        }
     }
 }
 
@@ -261,12 +292,26 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
     }
     __syncthreads();
     fft_tile<T, true>(buf, ld, pairs, tw, nx, logn);
-    for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
-        const int p = e / nx, i = e - p * nx;
-        const C2<T> z = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i));
-        const size_t g = (row0 + 2 * p) * nx + i;
-        phi[g] = z.x;
-        phi[g + nx] = z.y;
+    if constexpr (sizeof(T) == 4 && FES_FFT_VEC) {
+        // float: four consecutive values of a row — 16 bytes — per lane and store (nx >= 8 is a power of two)
+        using V4 = typename fpic::NatVec16<T>::type;
+        const int quads = nx / 4;
+        for (int e = threadIdx.x; e < pairs * quads; e += kFftThreads) {
+            const int p = e / quads, i = 4 * (e - p * quads);
+            const C2<T> z0 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i)), z1 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i + 1)),
+                        z2 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i + 2)), z3 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i + 3));
+            const size_t g = (row0 + 2 * p) * nx + i;
+            *reinterpret_cast<V4*>(phi + g) = V4{ z0.x, z1.x, z2.x, z3.x };
+            *reinterpret_cast<V4*>(phi + g + nx) = V4{ z0.y, z1.y, z2.y, z3.y };
+        }
+    } else {
+        for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
+            const int p = e / nx, i = e - p * nx;
+            const C2<T> z = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i));
+            const size_t g = (row0 + 2 * p) * nx + i;
+            phi[g] = z.x;
+            phi[g + nx] = z.y;
+        }
     }
 }
 
@@ -310,10 +355,26 @@ __global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict_
     C2<T>* base = reinterpret_cast<C2<T>*>(hat) + static_cast<size_t>(o) * L.outer_stride + i0;
     C2<T>* xb = reinterpret_cast<C2<T>*>(xbuf);
     const bool load_exchanged = MODE == 1 && L.nyl > 0, store_exchanged = MODE == 0 && L.nyl > 0;
-    for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
-        const int idx = e / C, c = e - idx * C;
-        if (c < cols)
-            fesfft::stc<T>(buf, c * ld + fesfft::swz(idx), load_exchanged ? xb[exchange_index(L, o, idx, i0 + c)] : base[static_cast<size_t>(idx) * L.stride + c]);
+    // (float: two complex values — 16 bytes — per lane and access; rows are padded to whole tiles, so the pair of an odd last
+    // column is inside the row's padding: loaded and stored like the rest, never transformed.  FES_FFT_VEC=0: one per lane)
+    constexpr bool kPairs = sizeof(T) == 4 && (C % 2) == 0 && FES_FFT_VEC;
+    if constexpr (kPairs) {
+        using V4 = typename fpic::NatVec16<T>::type;
+        constexpr int H = C / 2;
+        for (int e = threadIdx.x; e < N * H; e += kFftThreads) {
+            const int idx = e / H, c = 2 * (e - idx * H);
+            if (c >= cols) continue;
+            const C2<T>* src = load_exchanged ? xb + exchange_index(L, o, idx, i0 + c) : base + static_cast<size_t>(idx) * L.stride + c;
+            const V4 v = *reinterpret_cast<const V4*>(src);
+            fesfft::stc<T>(buf, c * ld + fesfft::swz(idx), C2<T>{ v.x, v.y });
+            fesfft::stc<T>(buf, (c + 1) * ld + fesfft::swz(idx), C2<T>{ v.z, v.w });
+        }
+    } else {
+        for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
+            const int idx = e / C, c = e - idx * C;
+            if (c < cols)
+                fesfft::stc<T>(buf, c * ld + fesfft::swz(idx), load_exchanged ? xb[exchange_index(L, o, idx, i0 + c)] : base[static_cast<size_t>(idx) * L.stride + c]);
+        }
     }
     __syncthreads();
     if constexpr (MODE == 1) fft_tile<T, true>(buf, ld, cols, tw, N, logn);
@@ -332,12 +393,24 @@ __global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict_
         __syncthreads();
         fft_tile<T, true>(buf, ld, cols, tw, N, logn);
     }
-    for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
-        const int idx = e / C, c = e - idx * C;
-        if (c >= cols) continue;
-        const C2<T> v = fesfft::ldc<T>(buf, c * ld + fesfft::swz(idx));
-        if (store_exchanged) xb[exchange_index(L, o, idx, i0 + c)] = v;
-        else base[static_cast<size_t>(idx) * L.stride + c] = v;
+    if constexpr (kPairs) {
+        using V4 = typename fpic::NatVec16<T>::type;
+        constexpr int H = C / 2;
+        for (int e = threadIdx.x; e < N * H; e += kFftThreads) {
+            const int idx = e / H, c = 2 * (e - idx * H);
+            if (c >= cols) continue;
+            const C2<T> a = fesfft::ldc<T>(buf, c * ld + fesfft::swz(idx)), b = fesfft::ldc<T>(buf, (c + 1) * ld + fesfft::swz(idx));
+            C2<T>* dst = store_exchanged ? xb + exchange_index(L, o, idx, i0 + c) : base + static_cast<size_t>(idx) * L.stride + c;
+            *reinterpret_cast<V4*>(dst) = V4{ a.x, a.y, b.x, b.y };
+        }
+    } else {
+        for (int e = threadIdx.x; e < N * C; e += kFftThreads) {
+            const int idx = e / C, c = e - idx * C;
+            if (c >= cols) continue;
+            const C2<T> v = fesfft::ldc<T>(buf, c * ld + fesfft::swz(idx));
+            if (store_exchanged) xb[exchange_index(L, o, idx, i0 + c)] = v;
+            else base[static_cast<size_t>(idx) * L.stride + c] = v;
+        }
     }
 }
 

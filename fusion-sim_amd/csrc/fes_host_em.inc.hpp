@@ -146,7 +146,9 @@ int em_full_e(fpic_handle* h, const EmCoef<T>& c, int k0, int nk, const void* b 
 {
     State* st = h->es;
     k0 = (k0 % st->nz + st->nz) % st->nz;
-    em_update_e_kernel<T><<<blocks_for(static_cast<size_t>(st->nx) * st->ny * nk), 256, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(b ? b : st->By), st->Jfix, st->nx,
+    if (nk <= 0) return FPIC_OK;
+    const NodeLaunch nl = node_launch(st->nx, st->ny, nk);
+    em_update_e_kernel<T><<<nl.grid, nl.block, 0, h->stream>>>(static_cast<T*>(st->Ey), static_cast<const T*>(b ? b : st->By), st->Jfix, st->nx,
                                                                                                      st->ny, st->nz, c.ce[0], c.ce[1], c.ce[2], c.je, c.js[0], c.js[1],
                                                                                                      c.js[2], k0, nk, held_of(st));
     HIP_TRY(h, hipGetLastError());

@@ -121,12 +121,12 @@ int launch_solve(fpic_handle* h, bool convert = true)
             return rc;
         if (convert) st->rho_fresh = false;
         if (st->solver == FPIC_SOLVER_YEE) {
-            em_edge_gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
+            em_edge_gradient_kernel<T><<<node_launch(st->nx, st->ny, st->nz).grid, node_launch(st->nx, st->ny, st->nz).block, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
                                                                                    static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
                                                                                    static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey), 0, st->nz, held_of(st));
             HIP_TRY(h, hipGetLastError());
         } else {
-            gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(
+            gradient_kernel<T><<<node_launch(st->nx, st->ny, st->nz).grid, node_launch(st->nx, st->ny, st->nz).block, 0, h->stream>>>(
                 static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
                 static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4));
             HIP_TRY(h, hipGetLastError());
@@ -158,11 +158,11 @@ int launch_solve(fpic_handle* h, bool convert = true)
         void* out_i[1] = { st->phi };
         if (int rc = fft_status(h, ff.execute(st->inv, in_i, out_i, st->info_i), "rocfft_execute (inverse)")) return rc;
         if (st->solver == FPIC_SOLVER_YEE) // the field on the lattice's edges: Gauss's law holds exactly there
-            em_edge_gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
+            em_edge_gradient_kernel<T><<<node_launch(st->nx, st->ny, st->nz).grid, node_launch(st->nx, st->ny, st->nz).block, 0, h->stream>>>(static_cast<const T*>(st->phi), st->nx, st->ny, st->nz,
                                                                                    static_cast<T>(1.0 / (st->lx / st->nx)), static_cast<T>(1.0 / (st->ly / st->ny)),
                                                                                    static_cast<T>(1.0 / (st->lz / st->nz)), static_cast<T*>(st->Ey), 0, st->nz, held_of(st));
         else
-            gradient_kernel<T><<<blocks_for(st->nodes), 256, 0, h->stream>>>(
+            gradient_kernel<T><<<node_launch(st->nx, st->ny, st->nz).grid, node_launch(st->nx, st->ny, st->nz).block, 0, h->stream>>>(
                 static_cast<const T*>(st->phi), st->nx, st->ny, st->nz, static_cast<T>(1.0 / (2.0 * (st->lx / st->nx))),
                 static_cast<T>(1.0 / (2.0 * (st->ly / st->ny))), static_cast<T>(1.0 / (2.0 * (st->lz / st->nz))), static_cast<T*>(st->E4));
         HIP_TRY(h, hipGetLastError());

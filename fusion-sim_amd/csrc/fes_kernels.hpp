@@ -69,6 +69,19 @@ constexpr int kMaxTiles3 = 40960;                // LDS histogram limit of the o
 constexpr int kMaxTilesStaged3 = 1 << 20;        // beyond kMaxTiles3 (512^3: 65536 / 262144 tiles): global-atomic census + the staged two-level scatter (<= 1024^2 bins)
 constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
 
+// launch shape of a per-node sweep: 256 threads, along x first (a power of two up to 256), the rest along y; one plane per grid.z
+struct NodeLaunch {
+    dim3 grid, block;
+};
+inline NodeLaunch node_launch(int nx, int ny, int planes)
+{
+    unsigned bx = 1;
+    while (bx < static_cast<unsigned>(nx) && bx < 256u) bx <<= 1;
+    const unsigned by = 256u / bx;
+    return { dim3((nx + bx - 1) / bx, (ny + by - 1) / by, static_cast<unsigned>(planes)), dim3(bx, by, 1) };
+}
+
+
 template <typename T> __device__ __forceinline__ T floor_(T v);
 template <> __device__ __forceinline__ float floor_<float>(float v) { return floorf(v); }
 template <> __device__ __forceinline__ double floor_<double>(double v) { return floor(v); }
@@ -907,12 +920,12 @@ __global__ __launch_bounds__(256) void kspace_kernel(T* __restrict__ hat, int nx
 template <typename T>
 __global__ __launch_bounds__(256) void gradient_kernel(const T* __restrict__ phi, int nx, int ny, int nz, T hx, T hy, T hz, T* __restrict__ E4)
 {
-    const size_t c = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // (node_launch: threads along x, then y, the plane on grid.z — a flat index cost three 64-bit divisions by run-time numbers
+    // per node, more instructions than the sweep's seven loads and one store: 661 -> 5xx us at 512^3, profiles/r05_fft_vec.txt)
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x), j = static_cast<int>(blockIdx.y * blockDim.y + threadIdx.y), k = static_cast<int>(blockIdx.z);
+    if (i >= nx || j >= ny) return;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (c >= sz * nz) return;
-    const int i = static_cast<int>(c % nx);
-    const int j = static_cast<int>((c / nx) % ny);
-    const int k = static_cast<int>(c / sz);
+    const size_t c = i + sy * j + sz * k;
     const int im = i ? i - 1 : nx - 1, ip = (i + 1 == nx) ? 0 : i + 1;
     const int jm = j ? j - 1 : ny - 1, jp = (j + 1 == ny) ? 0 : j + 1;
     const int km = k ? k - 1 : nz - 1, kp = (k + 1 == nz) ? 0 : k + 1;
@@ -1341,10 +1354,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void em_update_e_kernel(T* __restrict__ Ey, const T* __restrict__ By, const long long* __restrict__ Jfix, int nx, int ny,
                                                           int nz, T cex, T cey, T cez, T je, double jsx, double jsy, double jsz, int k0, int nk, Held held)
 {
-    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x), j = static_cast<int>(blockIdx.y * blockDim.y + threadIdx.y); // (node_launch)
+    if (i >= nx || j >= ny || static_cast<int>(blockIdx.z) >= nk) return;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (t >= sz * nk) return;
-    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny), kg = (k0 + static_cast<int>(t / sz)) % nz;
+    const int kg = (k0 + static_cast<int>(blockIdx.z)) % nz;
     const int k = held_plane(kg, held, nz), km = held_plane(kg ? kg - 1 : nz - 1, held, nz);
     if ((k | km) < 0) return;
     const size_t c = i + sy * j + sz * k;
@@ -1365,11 +1378,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void em_edge_gradient_kernel(const T* __restrict__ phi, int nx, int ny, int nz, T hx, T hy, T hz, T* __restrict__ Ey, int k0, int nk,
                                                                Held held)
 {
-    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x), j = static_cast<int>(blockIdx.y * blockDim.y + threadIdx.y); // (node_launch)
+    if (i >= nx || j >= ny || static_cast<int>(blockIdx.z) >= nk) return;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (t >= sz * nk) return;
-    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny);
-    int kg = (k0 + static_cast<int>(t / sz)) % nz;
+    int kg = (k0 + static_cast<int>(blockIdx.z)) % nz;
     if (kg < 0) kg += nz;
     const int k = held_plane(kg, held, nz), kp = held_plane((kg + 1 == nz) ? 0 : kg + 1, held, nz);
     if ((k | kp) < 0) return;
@@ -2349,12 +2361,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void gradient_planes_kernel(const T* __restrict__ phi, int nx, int ny, int nz, int k0, int count, T hx, T hy, T hz,
                                                               T* __restrict__ E4, Held held)
 {
-    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x), j = static_cast<int>(blockIdx.y * blockDim.y + threadIdx.y); // (node_launch)
+    if (i >= nx || j >= ny || static_cast<int>(blockIdx.z) >= count) return;
     const size_t sy = static_cast<size_t>(nx), sz = static_cast<size_t>(nx) * ny;
-    if (t >= sz * count) return;
-    const int i = static_cast<int>(t % nx), j = static_cast<int>((t / nx) % ny);
-    int k = k0 + static_cast<int>(t / sz);
-    k %= nz;
+    int k = (k0 + static_cast<int>(blockIdx.z)) % nz;   // (uniform over the workgroup: scalar arithmetic)
     if (k < 0) k += nz;
     const int im = i ? i - 1 : nx - 1, ip = (i + 1 == nx) ? 0 : i + 1;
     const int jm = j ? j - 1 : ny - 1, jp = (j + 1 == ny) ? 0 : j + 1;
