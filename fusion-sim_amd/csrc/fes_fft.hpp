@@ -221,14 +221,27 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
     fft_twiddles<T>(tw, twt, nx);
     const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
     const int pairs = static_cast<int>((rows - row0 < static_cast<size_t>(2 * pairs_per_wg) ? rows - row0 : 2 * pairs_per_wg) / 2); // (rows is even: ny is a power of two)
-    for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
-        const int p = e / nx, i = e - p * nx;
-        const size_t g = (row0 + 2 * p) * nx + i;
-        // (rho given: the charge density already converted — a rank of a replicated solve has gathered the others' planes)
-        // (the charge grid is read once per sub-step: non-temporal)
-        const T a = fixed ? static_cast<T>(static_cast<double>(__builtin_nontemporal_load(fixed + g)) * scale) : rho[g];
-        const T b = fixed ? static_cast<T>(static_cast<double>(__builtin_nontemporal_load(fixed + g + nx)) * scale) : rho[g + nx];
-        fesfft::stc<T>(buf, p * ld + fesfft::swz(i), C2<T>{ a, b });
+    if (fixed && FES_FFT_VEC) {
+        // two accumulators — 16 bytes — per lane and load (nx is even; rows of the int64 grid are 16-byte aligned)
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        const int half_nx = nx / 2;
+        for (int e = threadIdx.x; e < pairs * half_nx; e += kFftThreads) {
+            const int p = e / half_nx, i = 2 * (e - p * half_nx);
+            const size_t g = (row0 + 2 * p) * nx + i;
+            // (the charge grid is read once per sub-step: non-temporal)
+            const ll2 va = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(fixed + g)), vb = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(fixed + g + nx));
+            fesfft::stc<T>(buf, p * ld + fesfft::swz(i), C2<T>{ static_cast<T>(static_cast<double>(va.x) * scale), static_cast<T>(static_cast<double>(vb.x) * scale) });
+            fesfft::stc<T>(buf, p * ld + fesfft::swz(i + 1), C2<T>{ static_cast<T>(static_cast<double>(va.y) * scale), static_cast<T>(static_cast<double>(vb.y) * scale) });
+        }
+    } else {
+        for (int e = threadIdx.x; e < pairs * nx; e += kFftThreads) {
+            const int p = e / nx, i = e - p * nx;
+            const size_t g = (row0 + 2 * p) * nx + i;
+            // (rho given: the charge density already converted — a rank of a replicated solve has gathered the others' planes)
+            const T a = fixed ? static_cast<T>(static_cast<double>(__builtin_nontemporal_load(fixed + g)) * scale) : rho[g];
+            const T b = fixed ? static_cast<T>(static_cast<double>(__builtin_nontemporal_load(fixed + g + nx)) * scale) : rho[g + nx];
+            fesfft::stc<T>(buf, p * ld + fesfft::swz(i), C2<T>{ a, b });
+        }
     }
     __syncthreads();
     fft_tile<T, false>(buf, ld, pairs, tw, nx, logn);
@@ -284,11 +297,26 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
     const size_t row0 = static_cast<size_t>(blockIdx.x) * (2 * pairs_per_wg);
     const int pairs = static_cast<int>((rows - row0 < static_cast<size_t>(2 * pairs_per_wg) ? rows - row0 : 2 * pairs_per_wg) / 2);
     const C2<T>* in = reinterpret_cast<const C2<T>*>(hat);
-    for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
-        const int p = e / nxh, k = e - p * nxh;
-        const C2<T> A = in[(row0 + 2 * p) * pitch + k], B = in[(row0 + 2 * p + 1) * pitch + k];
+    auto place = [&](int p, int k, C2<T> A, C2<T> B) {
         fesfft::stc<T>(buf, p * ld + fesfft::swz(k), C2<T>{ A.x - B.y, A.y + B.x });
         if (k && k < nx - k) fesfft::stc<T>(buf, p * ld + fesfft::swz(nx - k), C2<T>{ A.x + B.y, B.x - A.y });
+    };
+    if constexpr (sizeof(T) == 4 && FES_FFT_VEC) {
+        // float: two spectral values — 16 bytes — per lane and load; k = nx / 2 goes alone (as in the forward pass's store)
+        using V4 = typename fpic::NatVec16<T>::type;
+        const int h2 = nx / 4;
+        for (int e = threadIdx.x; e < pairs * (h2 + 1); e += kFftThreads) {
+            const int p = e / (h2 + 1), q = e - p * (h2 + 1);
+            if (q == h2) { place(p, nx / 2, in[(row0 + 2 * p) * pitch + nx / 2], in[(row0 + 2 * p + 1) * pitch + nx / 2]); continue; }
+            const V4 a = *reinterpret_cast<const V4*>(in + (row0 + 2 * p) * pitch + 2 * q), b = *reinterpret_cast<const V4*>(in + (row0 + 2 * p + 1) * pitch + 2 * q);
+            place(p, 2 * q, C2<T>{ a.x, a.y }, C2<T>{ b.x, b.y });
+            place(p, 2 * q + 1, C2<T>{ a.z, a.w }, C2<T>{ b.z, b.w });
+        }
+    } else {
+        for (int e = threadIdx.x; e < pairs * nxh; e += kFftThreads) {
+            const int p = e / nxh, k = e - p * nxh;
+            place(p, k, in[(row0 + 2 * p) * pitch + k], in[(row0 + 2 * p + 1) * pitch + k]);
+        }
     }
     __syncthreads();
     fft_tile<T, true>(buf, ld, pairs, tw, nx, logn);
