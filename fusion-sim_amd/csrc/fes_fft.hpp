@@ -97,7 +97,7 @@ template <typename T, int R, bool INV, typename Col, typename Tw>
 FESFFT_HD void pass_load(Col col, Tw tw, int N, int Ns, int j, C2<T> (&v)[R], int stride = 1)
 {
     const int per = N / R, k = j & (Ns - 1);
-    const int tstep = k * (N / (Ns * R));
+    const int tstep = k * (per >> __builtin_ctz(static_cast<unsigned>(Ns)));   // N / (Ns R): Ns is a power of two (no division by a run-time number)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         v[r] = ldc<T>(col, swz(j + r * per) * stride);
@@ -174,14 +174,15 @@ __device__ __forceinline__ void fft_twiddles(FPIC_LDS C2<T>* tw, const T* __rest
 // takes whole columns (N / R butterflies each, a power of two that divides the workgroup), so "every butterfly of the
 // column has read" is one barrier
 template <typename T, int R, bool INV>
-__device__ __forceinline__ void fft_pass(FPIC_LDS C2<T>* buf, int ld, int cols, const FPIC_LDS C2<T>* tw, int N, int Ns)
+__device__ __forceinline__ void fft_pass(FPIC_LDS C2<T>* buf, int ld, int cols, const FPIC_LDS C2<T>* tw, int N, int Ns, int logn)
 {
-    const int per = N / R;                       // <= 512 = kFftThreads for N <= 1024, R >= 2
+    constexpr int kLogR = R == 8 ? 3 : (R == 4 ? 2 : 1);
+    const int per = N >> kLogR;                  // <= 512 = kFftThreads for N <= 1024, R >= 2; a power of two
     const int total = per * cols;
     for (int b0 = 0; b0 < total; b0 += kFftThreads) {
         const int b = b0 + static_cast<int>(threadIdx.x);
         const bool active = b < total;
-        const int c = b / per, j = b - c * per;
+        const int c = b >> (logn - kLogR), j = b & (per - 1);
         C2<T> v[R];
         FPIC_LDS C2<T>* col = buf + c * ld;
         if (active) fesfft::pass_load<T, R, INV>(col, tw, N, Ns, j, v);
@@ -198,9 +199,9 @@ __device__ __forceinline__ void fft_tile(FPIC_LDS C2<T>* buf, int ld, int cols, 
     int Ns = 1;
     for (int rem = logn; rem > 0;) {
         const int rl = fesfft::next_radix_log(rem);
-        if (rl == 3) fft_pass<T, 8, INV>(buf, ld, cols, tw, N, Ns);
-        else if (rl == 2) fft_pass<T, 4, INV>(buf, ld, cols, tw, N, Ns);
-        else fft_pass<T, 2, INV>(buf, ld, cols, tw, N, Ns);
+        if (rl == 3) fft_pass<T, 8, INV>(buf, ld, cols, tw, N, Ns, logn);
+        else if (rl == 2) fft_pass<T, 4, INV>(buf, ld, cols, tw, N, Ns, logn);
+        else fft_pass<T, 2, INV>(buf, ld, cols, tw, N, Ns, logn);
         Ns <<= rl;
         rem -= rl;
     }
@@ -224,9 +225,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
     if (fixed && FES_FFT_VEC) {
         // two accumulators — 16 bytes — per lane and load (nx is even; rows of the int64 grid are 16-byte aligned)
         typedef long long ll2 __attribute__((ext_vector_type(2)));
-        const int half_nx = nx / 2;
+        const int half_nx = nx / 2;   // (a power of two: the row and the column of an element are a shift and a mask)
         for (int e = threadIdx.x; e < pairs * half_nx; e += kFftThreads) {
-            const int p = e / half_nx, i = 2 * (e - p * half_nx);
+            const int p = e >> (logn - 1), i = 2 * (e & (half_nx - 1));
             const size_t g = (row0 + 2 * p) * nx + i;
             // (the charge grid is read once per sub-step: non-temporal)
             const ll2 va = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(fixed + g)), vb = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(fixed + g + nx));
@@ -256,17 +257,16 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_forward_kernel(const long l
         // float: two spectral values — 16 bytes — per lane and store (rows start 16-byte aligned: the pitch is a multiple of the
         // tile width); k = nx / 2, the odd one out of nx / 2 + 1, goes alone
         using V4 = typename fpic::NatVec16<T>::type;
-        const int h2 = nx / 4;   // pairs (k, k + 1), k even, k + 1 < nx / 2 + 1
-        for (int e = threadIdx.x; e < pairs * (h2 + 1); e += kFftThreads) {
-            const int p = e / (h2 + 1), q = e - p * (h2 + 1);
+        const int h2 = nx / 4;   // pairs (k, k + 1), k even, k + 1 < nx / 2 + 1: a power of two per row
+        for (int p = threadIdx.x; p < pairs; p += kFftThreads) {
             C2<T> A0, B0;
-            if (q == h2) {
-                spectra(p, nx / 2, A0, B0);
-                out[(row0 + 2 * p) * pitch + nx / 2] = A0;
-                out[(row0 + 2 * p + 1) * pitch + nx / 2] = B0;
-                continue;
-            }
-            C2<T> A1, B1;
+            spectra(p, nx / 2, A0, B0);
+            out[(row0 + 2 * p) * pitch + nx / 2] = A0;
+            out[(row0 + 2 * p + 1) * pitch + nx / 2] = B0;
+        }
+        for (int e = threadIdx.x; e < pairs * h2; e += kFftThreads) {
+            const int p = e >> (logn - 2), q = e & (h2 - 1);
+            C2<T> A0, B0, A1, B1;
             spectra(p, 2 * q, A0, B0);
             spectra(p, 2 * q + 1, A1, B1);
             *reinterpret_cast<V4*>(out + (row0 + 2 * p) * pitch + 2 * q) = V4{ A0.x, A0.y, A1.x, A1.y };
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
         // float: two spectral values — 16 bytes — per lane and load; k = nx / 2 goes alone (as in the forward pass's store)
         using V4 = typename fpic::NatVec16<T>::type;
         const int h2 = nx / 4;
-        for (int e = threadIdx.x; e < pairs * (h2 + 1); e += kFftThreads) {
-            const int p = e / (h2 + 1), q = e - p * (h2 + 1);
-            if (q == h2) { place(p, nx / 2, in[(row0 + 2 * p) * pitch + nx / 2], in[(row0 + 2 * p + 1) * pitch + nx / 2]); continue; }
+        for (int p = threadIdx.x; p < pairs; p += kFftThreads) place(p, nx / 2, in[(row0 + 2 * p) * pitch + nx / 2], in[(row0 + 2 * p + 1) * pitch + nx / 2]);
+        for (int e = threadIdx.x; e < pairs * h2; e += kFftThreads) {
+            const int p = e >> (logn - 2), q = e & (h2 - 1);
             const V4 a = *reinterpret_cast<const V4*>(in + (row0 + 2 * p) * pitch + 2 * q), b = *reinterpret_cast<const V4*>(in + (row0 + 2 * p + 1) * pitch + 2 * q);
             place(p, 2 * q, C2<T>{ a.x, a.y }, C2<T>{ b.x, b.y });
             place(p, 2 * q + 1, C2<T>{ a.z, a.w }, C2<T>{ b.z, b.w });
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_x_inverse_kernel(const T* __r
         using V4 = typename fpic::NatVec16<T>::type;
         const int quads = nx / 4;
         for (int e = threadIdx.x; e < pairs * quads; e += kFftThreads) {
-            const int p = e / quads, i = 4 * (e - p * quads);
+            const int p = e >> (logn - 2), i = 4 * (e & (quads - 1));
             const C2<T> z0 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i)), z1 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i + 1)),
                         z2 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i + 2)), z3 = fesfft::ldc<T>(buf, p * ld + fesfft::swz(i + 3));
             const size_t g = (row0 + 2 * p) * nx + i;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_columns_kernel(T* __restrict_
         // phi_hat = rho_hat / (eps0 K^2 N), K^2 = (k2x + k2y) + k2z in double, the mean mode 0 (es3d_poisson, kspace_kernel)
         const int j = y0 + o;
         for (int e = threadIdx.x; e < N * cols; e += kFftThreads) {
-            const int c = e / N, k = e - c * N;
+            const int c = e >> logn, k = e & (N - 1);   // (N = 2^logn)
             const int i = i0 + c;
             const double K2 = (k2x[i] + k2y[j]) + k2z[k];
             const T g = (i | j | k) ? static_cast<T>(inv_eps0_n / K2) : static_cast<T>(0);
