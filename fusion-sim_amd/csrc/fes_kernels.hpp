@@ -69,14 +69,17 @@ constexpr int kMaxTiles3 = 40960;                // LDS histogram limit of the o
 constexpr int kMaxTilesStaged3 = 1 << 20;        // beyond kMaxTiles3 (512^3: 65536 / 262144 tiles): global-atomic census + the staged two-level scatter (<= 1024^2 bins)
 constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
 
-// launch shape of a per-node sweep: 256 threads, along x first (a power of two up to 256), the rest along y; one plane per grid.z
+// launch shape of a per-node sweep: 256 threads, along x first (a power of two up to FES_NODE_BX), the rest along y; one plane per grid.z
+#if !defined(FES_NODE_BX)
+#define FES_NODE_BX 256u
+#endif
 struct NodeLaunch {
     dim3 grid, block;
 };
 inline NodeLaunch node_launch(int nx, int ny, int planes)
 {
     unsigned bx = 1;
-    while (bx < static_cast<unsigned>(nx) && bx < 256u) bx <<= 1;
+    while (bx < static_cast<unsigned>(nx) && bx < FES_NODE_BX) bx <<= 1;
     const unsigned by = 256u / bx;
     return { dim3((nx + bx - 1) / bx, (ny + by - 1) / by, static_cast<unsigned>(planes)), dim3(bx, by, 1) };
 }
