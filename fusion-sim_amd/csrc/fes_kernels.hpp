@@ -70,8 +70,10 @@ constexpr int kMaxTilesStaged3 = 1 << 20;        // beyond kMaxTiles3 (512^3: 65
 constexpr int kFix = 14;                         // fixed-point bits of a CIC weight per axis
 
 // launch shape of a per-node sweep: 256 threads, along x first (a power of two up to FES_NODE_BX), the rest along y; one plane per grid.z
+// (64 x 4 nodes per workgroup: a patch shares its y- and z-neighbours' lines; 256 x 1 / 128 x 2 / 64 x 4 / 32 x 8 on one box: the
+// gradient 612 / 602 / 577 / 622 us at 512^3, 68 / 62 / 60 / 65 at 256^3 — profiles/r05_node_bx.txt)
 #if !defined(FES_NODE_BX)
-#define FES_NODE_BX 256u
+#define FES_NODE_BX 64u
 #endif
 struct NodeLaunch {
     dim3 grid, block;
